@@ -1,0 +1,191 @@
+"""Parameter schema + deterministic synthetic weights for the SD-1.5 UNet / BlobNet / DINOv2 trunks.
+
+There are no checkpoints offline, so benchmarks and parity tests run on seeded synthetic weights.  The
+schema (names, shapes, order) is the reference's own `state_dict()` layout (SURVEY Appendix B;
+/root/reference/blobctrl/models/blobnet.py:152-491, D/models/unets/unet_2d_condition.py:171-485) so that
+a real `diffusion_pytorch_model.safetensors` drops in unchanged.  Values come from numpy PCG64 streams
+keyed by the parameter NAME (stable across torch versions and across the build container / GPU box).
+"""
+import zlib
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def _resnet(shapes, p, cin, cout, temb):
+    shapes[p + "norm1.weight"] = (cin,)
+    shapes[p + "norm1.bias"] = (cin,)
+    shapes[p + "conv1.weight"] = (cout, cin, 3, 3)
+    shapes[p + "conv1.bias"] = (cout,)
+    shapes[p + "time_emb_proj.weight"] = (cout, temb)
+    shapes[p + "time_emb_proj.bias"] = (cout,)
+    shapes[p + "norm2.weight"] = (cout,)
+    shapes[p + "norm2.bias"] = (cout,)
+    shapes[p + "conv2.weight"] = (cout, cout, 3, 3)
+    shapes[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        shapes[p + "conv_shortcut.weight"] = (cout, cin, 1, 1)
+        shapes[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(shapes, p, c, ctx_dim):
+    shapes[p + "norm.weight"] = (c,)
+    shapes[p + "norm.bias"] = (c,)
+    shapes[p + "proj_in.weight"] = (c, c, 1, 1)
+    shapes[p + "proj_in.bias"] = (c,)
+    b = p + "transformer_blocks.0."
+    shapes[b + "norm1.weight"] = (c,)
+    shapes[b + "norm1.bias"] = (c,)
+    shapes[b + "attn1.to_q.weight"] = (c, c)
+    shapes[b + "attn1.to_k.weight"] = (c, c)
+    shapes[b + "attn1.to_v.weight"] = (c, c)
+    shapes[b + "attn1.to_out.0.weight"] = (c, c)
+    shapes[b + "attn1.to_out.0.bias"] = (c,)
+    if ctx_dim is not None:
+        shapes[b + "norm2.weight"] = (c,)
+        shapes[b + "norm2.bias"] = (c,)
+        shapes[b + "attn2.to_q.weight"] = (c, c)
+        shapes[b + "attn2.to_k.weight"] = (c, ctx_dim)
+        shapes[b + "attn2.to_v.weight"] = (c, ctx_dim)
+        shapes[b + "attn2.to_out.0.weight"] = (c, c)
+        shapes[b + "attn2.to_out.0.bias"] = (c,)
+    shapes[b + "norm3.weight"] = (c,)
+    shapes[b + "norm3.bias"] = (c,)
+    shapes[b + "ff.net.0.proj.weight"] = (8 * c, c)
+    shapes[b + "ff.net.0.proj.bias"] = (8 * c,)
+    shapes[b + "ff.net.2.weight"] = (c, 4 * c)
+    shapes[b + "ff.net.2.bias"] = (c,)
+    shapes[p + "proj_out.weight"] = (c, c, 1, 1)
+    shapes[p + "proj_out.bias"] = (c,)
+
+
+def trunk_param_shapes(in_channels: int, block_out_channels: Tuple[int, ...], layers_per_block: int,
+                       cross_attention_dim: Optional[int], out_channels: Optional[int],
+                       blobnet: bool) -> "OrderedDict[str, tuple]":
+    """Parameter names/shapes of the SD-1.5-topology trunk.  `blobnet=True` drops conv_norm_out/conv_out and
+    attn2/norm2 (cross_attention_dim=None) and appends the 12 + 1 + 15 zero-convs (bn:336-349, 383-399, 480-491)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    boc = tuple(block_out_channels)
+    nb = len(boc)
+    temb = boc[0] * 4
+    s["conv_in.weight"] = (boc[0], in_channels, 3, 3)
+    s["conv_in.bias"] = (boc[0],)
+    s["time_embedding.linear_1.weight"] = (temb, boc[0])
+    s["time_embedding.linear_1.bias"] = (temb,)
+    s["time_embedding.linear_2.weight"] = (temb, temb)
+    s["time_embedding.linear_2.bias"] = (temb,)
+    ch = boc[0]
+    for i in range(nb):
+        cin, cout = ch, boc[i]
+        for j in range(layers_per_block):
+            _resnet(s, f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout, temb)
+            if i < nb - 1:
+                _transformer(s, f"down_blocks.{i}.attentions.{j}.", cout, cross_attention_dim)
+        if i < nb - 1:
+            s[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            s[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (cout,)
+        ch = cout
+    _resnet(s, "mid_block.resnets.0.", boc[-1], boc[-1], temb)
+    _transformer(s, "mid_block.attentions.0.", boc[-1], cross_attention_dim)
+    _resnet(s, "mid_block.resnets.1.", boc[-1], boc[-1], temb)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i in range(nb):
+        cout = rev[i]
+        cin_skip = rev[min(i + 1, nb - 1)]
+        for j in range(layers_per_block + 1):
+            skip_c = cin_skip if j == layers_per_block else cout
+            res_in = prev if j == 0 else cout
+            _resnet(s, f"up_blocks.{i}.resnets.{j}.", res_in + skip_c, cout, temb)
+            if i > 0:
+                _transformer(s, f"up_blocks.{i}.attentions.{j}.", cout, cross_attention_dim)
+        if i < nb - 1:
+            s[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            s[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (cout,)
+        prev = cout
+    if not blobnet:
+        s["conv_norm_out.weight"] = (boc[0],)
+        s["conv_norm_out.bias"] = (boc[0],)
+        s["conv_out.weight"] = (out_channels, boc[0], 3, 3)
+        s["conv_out.bias"] = (out_channels,)
+    else:
+        k = 0
+        dch = [boc[0]]
+        for i in range(nb):
+            dch += [boc[i]] * layers_per_block
+            if i < nb - 1:
+                dch.append(boc[i])
+        for k, c in enumerate(dch):
+            s[f"blobnet_down_blocks.{k}.weight"] = (c, c, 1, 1)
+            s[f"blobnet_down_blocks.{k}.bias"] = (c,)
+        s["blobnet_mid_block.weight"] = (boc[-1], boc[-1], 1, 1)
+        s["blobnet_mid_block.bias"] = (boc[-1],)
+        uch = []
+        for i in range(nb):
+            uch += [rev[i]] * (layers_per_block + 1)
+            if i < nb - 1:
+                uch.append(rev[i])
+        for k, c in enumerate(uch):
+            s[f"blobnet_up_blocks.{k}.weight"] = (c, c, 1, 1)
+            s[f"blobnet_up_blocks.{k}.bias"] = (c,)
+    return s
+
+
+def dinov2_param_shapes(hidden: int, layers: int, mlp_ratio: int, patch: int, num_pos: int) -> "OrderedDict[str, tuple]":
+    """transformers `Dinov2Model.state_dict()` layout (call site pipe:690-703; ViT, pre-LN, LayerScale)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["embeddings.cls_token"] = (1, 1, hidden)
+    s["embeddings.mask_token"] = (1, hidden)
+    s["embeddings.position_embeddings"] = (1, num_pos + 1, hidden)
+    s["embeddings.patch_embeddings.projection.weight"] = (hidden, 3, patch, patch)
+    s["embeddings.patch_embeddings.projection.bias"] = (hidden,)
+    for i in range(layers):
+        p = f"encoder.layer.{i}."
+        s[p + "norm1.weight"] = (hidden,)
+        s[p + "norm1.bias"] = (hidden,)
+        for n in ("query", "key", "value"):
+            s[p + f"attention.attention.{n}.weight"] = (hidden, hidden)
+            s[p + f"attention.attention.{n}.bias"] = (hidden,)
+        s[p + "attention.output.dense.weight"] = (hidden, hidden)
+        s[p + "attention.output.dense.bias"] = (hidden,)
+        s[p + "layer_scale1.lambda1"] = (hidden,)
+        s[p + "norm2.weight"] = (hidden,)
+        s[p + "norm2.bias"] = (hidden,)
+        s[p + "mlp.fc1.weight"] = (hidden * mlp_ratio, hidden)
+        s[p + "mlp.fc1.bias"] = (hidden * mlp_ratio,)
+        s[p + "mlp.fc2.weight"] = (hidden, hidden * mlp_ratio)
+        s[p + "mlp.fc2.bias"] = (hidden,)
+        s[p + "layer_scale2.lambda1"] = (hidden,)
+    s["layernorm.weight"] = (hidden,)
+    s["layernorm.bias"] = (hidden,)
+    return s
+
+
+def synth_tensor(name: str, shape: tuple, seed: int) -> np.ndarray:
+    """One parameter, float32, from a PCG64 stream keyed by (seed, crc32(name)).
+
+    norm scales ~ 1 + 0.1 N(0,1); biases / tokens / position embeddings ~ 0.02..0.05 N(0,1); LayerScale ~ 0.1..0.3;
+    matrices / conv kernels ~ N(0, 1/fan_in) (variance preserving so activations stay O(1));
+    BlobNet zero-convs get small NON-zero values (0.3/sqrt(fan_in)) so the BlobNet->UNet coupling is exercised
+    (they are zero-initialised in the reference, bn:348-349 / bn:959-962)."""
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    n = int(np.prod(shape))
+    x = rng.standard_normal(n, dtype=np.float32).reshape(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if "lambda1" in name:
+        return (0.2 + 0.05 * x).astype(np.float32)
+    if "cls_token" in name or "mask_token" in name or "position_embeddings" in name:
+        return (0.05 * x).astype(np.float32)
+    if leaf == "bias":
+        return (0.02 * x).astype(np.float32)
+    if len(shape) == 1:                       # norm weight
+        return (1.0 + 0.1 * x).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    gain = 0.3 if name.startswith("blobnet_") else 1.0
+    return (x * (gain / np.sqrt(fan_in))).astype(np.float32)
+
+
+def synth_state_dict(shapes: "OrderedDict[str, tuple]", seed: int) -> Dict[str, torch.Tensor]:
+    return OrderedDict((k, torch.from_numpy(synth_tensor(k, v, seed))) for k, v in shapes.items())
