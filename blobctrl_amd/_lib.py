@@ -1,0 +1,109 @@
+"""ctypes binding of libblobctrl_hip.so (the C ABI declared in include/blobctrl_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing any compute entry
+point raises.  Build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblobctrl_hip.so")
+
+A_DENSE, A_CONV3X3 = 0, 1
+ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU = 0, 1, 2, 3
+OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
+
+
+class BcGemm(C.Structure):
+    """Mirror of `struct BcGemm` (include/blobctrl_hip.h) - keep field order identical."""
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("a_mode", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("lda2", C.c_int), ("C1", C.c_int), ("Cin", C.c_int),
+        ("Hin", C.c_int), ("Win", C.c_int), ("Hv", C.c_int), ("Wv", C.c_int),
+        ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int),
+        ("W", C.c_void_p), ("ldw", C.c_int),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int), ("rows_per_batch", C.c_int),
+        ("act", C.c_int), ("colscale", C.c_void_p), ("alpha", C.c_float),
+        ("alpha_dev", C.c_void_p), ("alpha_idx", C.c_void_p),
+        ("R", C.c_void_p), ("ldr", C.c_int),
+        ("R2", C.c_void_p), ("ldr2", C.c_int), ("r2_xmin", C.c_int), ("r2_bmod", C.c_int), ("out_w", C.c_int),
+        ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+        ("splitk", C.c_int), ("slab", C.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "bc_last_error": (C.c_char_p, []),
+    "bc_version": (C.c_int, []),
+    "bc_device_info": (C.c_int, [C.POINTER(C.c_int)]),
+    "bc_gemm": (C.c_int, [C.POINTER(BcGemm), C.c_void_p]),
+    "bc_sizeof_gemm": (C.c_int, []),
+    "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                              C.c_void_p]),
+    "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bc_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                              C.c_void_p, C.c_void_p]),
+    "bc_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                               C.c_int, C.c_void_p]),
+    "bc_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
+                               C.c_longlong, C.c_float, C.c_void_p]),
+    "bc_splat_scores": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_assemble_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "bc_cfg_scheduler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "bc_nchw_to_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "bc_add_cls_pos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_graph_begin": (C.c_int, [C.c_void_p]),
+    "bc_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bc_graph_destroy": (C.c_int, [C.c_void_p]),
+    "bc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "bc_event_destroy": (C.c_int, [C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+class BlobCtrlHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises BlobCtrlHipError if it is missing - there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BlobCtrlHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  blobctrl_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:   # pragma: no cover
+        raise BlobCtrlHipError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError => symbol missing from the build
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bc_sizeof_gemm() != C.sizeof(BcGemm):
+        raise BlobCtrlHipError(f"BcGemm layout mismatch: C {lib.bc_sizeof_gemm()} vs ctypes {C.sizeof(BcGemm)}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bc_last_error()
+        raise BlobCtrlHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

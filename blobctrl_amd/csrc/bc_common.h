@@ -1,0 +1,41 @@
+// Shared device/host helpers for libblobctrl_hip (gfx950 only: wave64, MFMA 32x32x16 f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <algorithm>
+#include "../../include/blobctrl_hip.h"
+
+typedef _Float16 h16;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void bc_set_error(const char* fmt, ...);
+
+#define BC_CHECK_ARG(cond, ...)                                                \
+    do {                                                                       \
+        if (!(cond)) { bc_set_error(__VA_ARGS__); return 1; }                  \
+    } while (0)
+
+#define BC_CHECK_HIP(expr)                                                     \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            bc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 2;                                                          \
+        }                                                                      \
+    } while (0)
+
+#define BC_CHECK_LAUNCH() BC_CHECK_HIP(hipGetLastError())
+
+static inline int bc_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float bc_silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact-erf GELU (activations.py:93-123 uses F.gelu default = erf form)
+__device__ __forceinline__ float bc_gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ uint4 bc_ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void bc_st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }

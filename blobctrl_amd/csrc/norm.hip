@@ -1,0 +1,237 @@
+// GroupNorm(+SiLU) over NHWC (optionally over a channel-concat of two tensors) and LayerNorm, gfx950.
+// HBM-bound kernels: 16-byte (8 x fp16) loads/stores per lane, fp32 statistics, 64-wide wavefront reductions.
+//
+// Reference call sites replaced: F.group_norm + SiLU at D/models/resnet.py:327-328,351-363, transformer_2d.py:481,
+// unet_2d_condition.py:1341-1343; torch.cat([h, skip], 1) at unet_2d_blocks.py:2559,2719 (folded into the two-source
+// read); F.layer_norm at D/models/attention.py:447,491,517 and in transformers' Dinov2Layer.
+#include "bc_common.h"
+
+namespace {
+
+constexpr int GN_PIX_PER_SLAB = 64;
+constexpr int GN_MAX_GROUPS = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// part[b][slab][g][2] = (sum, sumsq) over GN_PIX_PER_SLAB pixels x channels-of-group.
+// Threads sweep (pixel, 8-channel chunk) pairs; a chunk may straddle groups, so elements are binned individually
+// into LDS accumulators with ds_add_f32 after a per-thread run-length merge.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
+                                                         int C2, int HW, int G, float* __restrict__ part, int nslab) {
+    __shared__ float acc[GN_MAX_GROUPS * 2];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int C = C1 + C2;
+    const int cpg = C / G;
+    const int nchunk = C / 8;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) acc[i] = 0.f;
+    __syncthreads();
+    const int p0 = slab * GN_PIX_PER_SLAB;
+    const int np = min(GN_PIX_PER_SLAB, HW - p0);
+    const int total = np * nchunk;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int pl = idx / nchunk;
+        int ch = idx - pl * nchunk;
+        int c = ch * 8;
+        size_t pix = (size_t)b * HW + p0 + pl;
+        uint4 raw = (c < C1) ? bc_ld16(x1 + pix * C1 + c) : bc_ld16(x2 + pix * C2 + (c - C1));
+        const h16* v = reinterpret_cast<const h16*>(&raw);
+        int gcur = c / cpg;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int gj = (c + j) / cpg;
+            if (gj != gcur) {
+                atomicAdd(&acc[2 * gcur], s);
+                atomicAdd(&acc[2 * gcur + 1], q);
+                s = 0.f; q = 0.f; gcur = gj;
+            }
+            float f = (float)v[j];
+            s += f;
+            q += f * f;
+        }
+        atomicAdd(&acc[2 * gcur], s);
+        atomicAdd(&acc[2 * gcur + 1], q);
+    }
+    __syncthreads();
+    float* dst = part + ((size_t)b * nslab + slab) * G * 2;
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) dst[i] = acc[i];
+}
+
+// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]).  One block per (b), threads over channels; each thread
+// re-reduces its group's slab partials (tiny: nslab <= 288 values per group).
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int nslab, int HW, int C, int G, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ ab) {
+    __shared__ float stat[GN_MAX_GROUPS * 2];
+    const int b = blockIdx.x;
+    const int cpg = C / G;
+    // wave w reduces groups w, w+nw, ...
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int g = wave; g < G; g += nw) {
+        double s = 0.0, q = 0.0;
+        for (int sl = lane; sl < nslab; sl += 64) {
+            const float* src = part + (((size_t)b * nslab + sl) * G + g) * 2;
+            s += src[0];
+            q += src[1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            q += __shfl_xor(q, o);
+        }
+        if (lane == 0) {
+            double n = (double)HW * cpg;
+            double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stat[2 * g] = (float)mean;
+            stat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        int g = c / cpg;
+        float a = stat[2 * g + 1] * gamma[c];
+        ab[((size_t)b * C + c) * 2] = a;
+        ab[((size_t)b * C + c) * 2 + 1] = beta[c] - stat[2 * g] * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
+                                                         int C2, int HW, long long total_chunks,
+                                                         const float* __restrict__ ab, int silu, h16* __restrict__ y) {
+    const int C = C1 + C2;
+    const int nchunk = C / 8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_chunks;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long pix = idx / nchunk;
+        int c = (int)(idx - pix * nchunk) * 8;
+        int b = (int)(pix / HW);
+        uint4 raw = (c < C1) ? bc_ld16(x1 + (size_t)pix * C1 + c) : bc_ld16(x2 + (size_t)pix * C2 + (c - C1));
+        const h16* v = reinterpret_cast<const h16*>(&raw);
+        const float4* abp = reinterpret_cast<const float4*>(ab + ((size_t)b * C + c) * 2);
+        uint4 outraw;
+        h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 t = abp[j];                       // (a0, b0, a1, b1)
+            float r0 = (float)v[2 * j] * t.x + t.y;
+            float r1 = (float)v[2 * j + 1] * t.z + t.w;
+            if (silu) { r0 = bc_silu_f(r0); r1 = bc_silu_f(r1); }
+            o[2 * j] = (h16)r0;
+            o[2 * j + 1] = (h16)r1;
+        }
+        bc_st16(y + (size_t)pix * C + c, outraw);
+    }
+}
+
+// LayerNorm: one wave per row; the row (C <= 64*8*MAXC elements) lives in registers, two-pass statistics.
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ x, int rows, int C, int ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, h16* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C / 8;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        int ch = lane + i * 64;
+        if (ch < nchunk) {
+            uint4 raw = bc_ld16(x + (size_t)row * ldx + ch * 8);
+            const h16* h = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)h[j]; s += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        int ch = lane + i * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        int ch = lane + i * 64;
+        if (ch < nchunk) {
+            uint4 outraw;
+            h16* o = reinterpret_cast<h16*>(&outraw);
+            const float4* gp = reinterpret_cast<const float4*>(gamma + ch * 8);
+            const float4* bp = reinterpret_cast<const float4*>(beta + ch * 8);
+            float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+            float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (h16)((v[i][j] - mean) * rstd * gg[j] + bb[j]);
+            bc_st16(y + (size_t)row * ldy + ch * 8, outraw);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bc_gn_stats(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW, int G, float* part,
+                           int nslab, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x2) C2 = 0;
+    int C = C1 + C2;
+    BC_CHECK_ARG(x1 && part && B > 0 && HW > 0, "bc_gn_stats: bad args");
+    BC_CHECK_ARG(C1 % 8 == 0 && C2 % 8 == 0 && G > 0 && G <= GN_MAX_GROUPS && C % G == 0,
+                 "bc_gn_stats: C1=%d C2=%d G=%d unsupported (channels %%8, groups<=%d)", C1, C2, G, GN_MAX_GROUPS);
+    BC_CHECK_ARG(nslab == bc_ceil_div(HW, GN_PIX_PER_SLAB), "bc_gn_stats: nslab must be ceil(HW/%d)", GN_PIX_PER_SLAB);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
+                       reinterpret_cast<const h16*>(x2), C2, HW, G, part, nslab);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_gn_finalize(const float* part, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
+                              const float* beta, float* ab, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(part && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0, "bc_gn_finalize: bad args");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part, nslab, HW, C, G, eps, gamma, beta, ab);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW, const float* ab,
+                           int silu, bc_half* y, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!x2) C2 = 0;
+    BC_CHECK_ARG(x1 && ab && y && C1 % 8 == 0 && C2 % 8 == 0, "bc_gn_apply: bad args");
+    long long total = (long long)B * HW * ((C1 + C2) / 8);
+    int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
+                       reinterpret_cast<const h16*>(x2), C2, HW, total, ab, silu, reinterpret_cast<h16*>(y));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_layernorm(const bc_half* x, int rows, int C, int ldx, const float* gamma, const float* beta,
+                            float eps, bc_half* y, int ldy, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(x && y && gamma && beta && rows > 0, "bc_layernorm: bad args");
+    BC_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 64 * 8 * 4, "bc_layernorm: C=%d unsupported (C%%8==0, C<=2048)", C);
+    dim3 grid(bc_ceil_div(rows, 4)), block(256);
+    const h16* xi = reinterpret_cast<const h16*>(x);
+    h16* yo = reinterpret_cast<h16*>(y);
+    if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
+    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
+    BC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,281 @@
+"""Static launch plans for the two trunks of the hot path: the patched SD-1.5 UNet and BlobNet.
+
+Host-side mirror of (paths relative to the reference root, D/ = diffusers/src/diffusers/):
+  * D/models/unets/unet_2d_condition.py:1039-1353  UNet2DConditionModel.forward with down/mid/up_block_add_samples
+  * blobctrl/models/blobnet.py:720-945             BlobNetModel.forward
+  * D/models/unets/unet_2d_blocks.py:1241-1323, 1378-1433, 860-899, 2514-2624, 2677-2765 (patched blocks)
+  * D/models/resnet.py:320-373, transformers/transformer_2d.py:479-527, attention.py:421-541
+re-expressed as a flat list of C-ABI launches over NHWC fp16 buffers (see launch.Recorder).  Fusions relative to
+the reference op list: channel-concat folded into the GroupNorm / shortcut loaders, nearest-upsample folded into the
+following conv's gather, bias / time-embedding / residual / BlobNet right-half add / conditioning scale / GEGLU folded
+into GEMM epilogues, V produced transposed by its projection GEMM, q|k projections fused, all 22 time_emb_proj fused.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .launch import Recorder
+from .weights import PackedTrunk, pad8
+
+
+@dataclass
+class TrunkConfig:
+    in_channels: int                      # real conv_in channels (5 for the UNet, 4+1+F for BlobNet)
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    num_heads: int = 8
+    norm_num_groups: int = 32
+    cross_attention_dim: Optional[int] = 768
+    out_channels: int = 4
+    is_blobnet: bool = False
+
+
+class Act:
+    """A token-major NHWC activation [B][H*W][C] (fp16)."""
+    __slots__ = ("t", "C", "H", "W")
+
+    def __init__(self, t, C, H, W):
+        self.t, self.C, self.H, self.W = t, C, H, W
+
+
+@dataclass
+class Residuals:
+    """BlobNet residual tensors in full-canvas token-major layout and how the UNet adds them
+    (unet_2d_blocks.py:1303-1307: whole tensor on a square canvas, right-hand square otherwise)."""
+    down: List[torch.Tensor]
+    mid: torch.Tensor
+    up: List[torch.Tensor]
+    bmod: int
+    xmin_of: callable = None
+
+
+class TrunkPlan:
+    """Records one forward of a trunk into the recorder's current segment."""
+
+    def __init__(self, rec: Recorder, pw: PackedTrunk, cfg: TrunkConfig, B: int, H: int, W: int):
+        self.rec, self.pw, self.cfg, self.B, self.H, self.W = rec, pw, cfg, B, H, W
+        self.G = cfg.norm_num_groups
+        self.heads = cfg.num_heads
+
+    # ------------------------------------------------------------------------------------------- helpers
+    def _r2(self, res_t, H, W):
+        """kwargs for the BlobNet residual add on an H x W output."""
+        if res_t is None:
+            return {}
+        xmin = 0 if W == H else W - H
+        return dict(R2=res_t, ldr2=res_t.shape[-1], r2_xmin=xmin, r2_bmod=self.res_bmod, out_w=W)
+
+    def conv3x3(self, x: Act, wname, Cout, stride=1, up_to=None, rowvec=None, R=None, r2=None, out_f32=False,
+                kind="conv3x3"):
+        rec, pw = self.rec, self.pw
+        Hv, Wv = up_to if up_to is not None else (x.H, x.W)
+        Hout, Wout = (Hv + 2 - 3) // stride + 1, (Wv + 2 - 3) // stride + 1
+        M = self.B * Hout * Wout
+        out = rec.empty(self.B, Hout * Wout, Cout, dtype=torch.float32 if out_f32 else torch.float16)
+        kw = {}
+        if rowvec is not None:
+            kw.update(rowvec=rowvec[0], ld_rowvec=rowvec[1])
+        if R is not None:
+            kw.update(R=R.t, ldr=R.C)
+        kw.update(self._r2(r2, Hout, Wout))
+        rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * x.C, out=out,
+                 out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,
+                 conv=dict(Cin=x.C, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
+                 bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, **kw)
+        return Act(out, Cout, Hout, Wout)
+
+    def dense(self, x_t, M, K, wname, N, bias=True, out=None, kind="linear", wkey=None, **kw):
+        rec, pw = self.rec, self.pw
+        act = kw.get("act", _lib.ACT_NONE)
+        n_out = N // 2 if act == _lib.ACT_GEGLU else N
+        if out is None:
+            out = rec.empty(M, n_out)
+        rec.gemm(A=x_t, W=pw.h[wkey or (wname + ".weight")], M=M, N=N, K=K, out=out,
+                 bias=pw.f[wname + ".bias"] if bias else None, kind=kind, **kw)
+        return out
+
+    def groupnorm(self, x: Act, x2: Optional[Act], name, eps, silu):
+        pw = self.pw
+        C2 = x2.C if x2 is not None else 0
+        out = self.rec.groupnorm(x.t, x.C, x2.t if x2 is not None else None, C2, self.B, x.H * x.W, self.G, eps,
+                                 pw.f[name + ".weight"], pw.f[name + ".bias"], silu)
+        return Act(out, x.C + C2, x.H, x.W)
+
+    # ------------------------------------------------------------------------------------------- blocks
+    def resnet(self, p, x: Act, skip: Optional[Act], Cout, r2=None):
+        """resnet.py:320-373 on (x [, skip]) = torch.cat([x, skip], 1)."""
+        pw = self.pw
+        Cin = x.C + (skip.C if skip is not None else 0)
+        off, n = pw.temb_slices[p]
+        assert n == Cout
+        rowvec = (self.tproj.data_ptr() + off * 2, pw.temb_total)
+        h = self.groupnorm(x, skip, p + "norm1", 1e-5, True)
+        h = self.conv3x3(h, p + "conv1", Cout, rowvec=rowvec)
+        h = self.groupnorm(h, None, p + "norm2", 1e-5, True)
+        M = self.B * x.H * x.W
+        if (p + "conv_shortcut.weight") in pw.h:
+            kw = {}
+            if skip is not None:
+                kw.update(A2=skip.t, C1=x.C, lda=x.C, lda2=skip.C)
+            sc = Act(self.dense(x.t, M, Cin, p + "conv_shortcut", Cout, kind="conv1x1", **kw), Cout, x.H, x.W)
+        else:
+            assert skip is None and Cin == Cout
+            sc = x
+        return self.conv3x3(h, p + "conv2", Cout, R=sc, r2=r2)
+
+    def transformer(self, p, x: Act, r2=None):
+        """transformer_2d.py:479-527 + attention.py:421-541 (one BasicTransformerBlock)."""
+        rec, pw, B = self.rec, self.pw, self.B
+        Cc, HW = x.C, x.H * x.W
+        M = B * HW
+        d = Cc // self.heads
+        scale = d ** -0.5
+        bp = p + "transformer_blocks.0."
+        n = self.groupnorm(x, None, p + "norm", 1e-6, False)
+        h = self.dense(n.t, M, Cc, p + "proj_in", Cc, kind="conv1x1")
+        # --- self attention
+        ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm1.weight"], pw.f[bp + "norm1.bias"], 1e-5)
+        qk = self.dense(ln, M, Cc, None, 2 * Cc, bias=False, wkey=bp + "attn1.to_qk.weight", kind="qkv")
+        ldvt = (HW + 63) // 64 * 64
+        vt = rec.zeros(B, Cc, ldvt)
+        self.dense(ln, M, Cc, None, Cc, bias=False, wkey=bp + "attn1.to_v.weight", out=vt, out_mode=_lib.OUT_F16_T,
+                   ldc=ldvt, rows_per_batch=HW, kind="qkv")
+        a = rec.empty(M, Cc)
+        rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc,
+                      Cc * ldvt, HW * Cc, scale, q_off=0, k_off=Cc)
+        h = self.dense(a, M, Cc, bp + "attn1.to_out.0", Cc, R=h, ldr=Cc, kind="attn_out")
+        # --- cross attention (UNet only)
+        if pw.has_cross:
+            ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm2.weight"], pw.f[bp + "norm2.bias"], 1e-5)
+            q = self.dense(ln, M, Cc, None, Cc, bias=False, wkey=bp + "attn2.to_q.weight", kind="qkv")
+            ck, cvt, T, ldc_vt = self.ctx_kv[bp]
+            a = rec.empty(M, Cc)
+            rec.attention(q, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt,
+                          HW * Cc, scale)
+            h = self.dense(a, M, Cc, bp + "attn2.to_out.0", Cc, R=h, ldr=Cc, kind="attn_out")
+        # --- GEGLU feed-forward
+        ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm3.weight"], pw.f[bp + "norm3.bias"], 1e-5)
+        g = self.dense(ln, M, Cc, bp + "ff.net.0.proj", 8 * Cc, act=_lib.ACT_GEGLU, kind="ff")
+        h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
+        # --- proj_out + residual (+ BlobNet residual)
+        out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW,
+                         **self._r2(r2, x.H, x.W))
+        return Act(out, Cc, x.H, x.W)
+
+    # ------------------------------------------------------------------------------------------- prologue
+    def record_context(self, ctx: torch.Tensor, T: int):
+        """Cross-attention K / V^T of the (step-invariant) prompt embeddings, once per edit
+        (attention.py:504-510; SURVEY Appendix A 'step-invariant => precompute once per edit')."""
+        rec, pw, B = self.rec, self.pw, self.B
+        self.ctx_kv = {}
+        Dc = ctx.shape[-1]
+        ldvt = (T + 63) // 64 * 64
+        for k in [k for k in pw.h if k.endswith("attn2.to_k.weight")]:
+            bp = k[: -len("attn2.to_k.weight")]
+            Cc = pw.h[k].shape[0]
+            ck = rec.empty(B * T, Cc)
+            rec.gemm(A=ctx, W=pw.h[k], M=B * T, N=Cc, K=Dc, out=ck, kind="ctx_kv")
+            cvt = rec.zeros(B, Cc, ldvt)
+            rec.gemm(A=ctx, W=pw.h[bp + "attn2.to_v.weight"], M=B * T, N=Cc, K=Dc, out=cvt, out_mode=_lib.OUT_F16_T,
+                     ldc=ldvt, rows_per_batch=T, kind="ctx_kv")
+            self.ctx_kv[bp] = (ck, cvt, T, ldvt)
+
+    # ------------------------------------------------------------------------------------------- time embedding
+    def record_time(self, t_table, t_idx, t_value=0.0):
+        """embeddings.py:27-78, 576-588 and the 22 `time_emb_proj(silu(emb))` of resnet.py:343-350 as three GEMMs."""
+        rec, pw, B = self.rec, self.pw, self.B
+        c0 = self.cfg.block_out_channels[0]
+        te = c0 * 4
+        sin = rec.empty(B, c0)
+        rec.call("bc_timestep_embedding", _ptr(t_table), _ptr(t_idx), float(t_value), B, c0, sin.data_ptr(),
+                 kind="temb", keep=(t_table, t_idx, sin))
+        h = self.dense(sin, B, c0, "time_embedding.linear_1", te, act=_lib.ACT_SILU, kind="temb")
+        h = self.dense(h, B, te, "time_embedding.linear_2", te, act=_lib.ACT_SILU, kind="temb")   # silu(emb)
+        self.tproj = self.dense(h, B, te, "temb_all", pw.temb_total, kind="temb")
+
+    # ------------------------------------------------------------------------------------------- forward
+    def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None):
+        """x_in: [B, H*W, pad8(in_channels)] fp16.  UNet: returns eps fp32 [B, H*W, out_channels].
+        BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx))."""
+        cfg, pw = self.cfg, self.pw
+        boc = cfg.block_out_channels
+        nb = len(boc)
+        H, W = self.H, self.W
+        res_d = list(residuals.down) if residuals is not None else None
+        res_u = list(residuals.up) if residuals is not None else None
+        self.res_bmod = residuals.bmod if residuals is not None else 1
+        pop = (lambda lst: lst.pop(0)) if residuals is not None else (lambda lst: None)
+        feats_d, feats_u = [], []
+
+        x = Act(x_in, pad8(cfg.in_channels), H, W)
+        if residuals is not None and W == H:
+            # square canvas: `sample = sample + r` rebinds, skip #0 stays WITHOUT the residual (unet_2d_condition.py:1213-1217)
+            skip0 = self.conv3x3(x, "conv_in", boc[0], kind="conv_in")
+            h = self.conv3x3(x, "conv_in", boc[0], r2=pop(res_d), kind="conv_in")
+        else:
+            # wide canvas: in-place slice add aliases the tuple element => skip #0 carries the residual (:1219)
+            h = self.conv3x3(x, "conv_in", boc[0], r2=pop(res_d), kind="conv_in")
+            skip0 = h
+        skips = [skip0]
+        feats_d.append(h)
+        for i in range(nb):
+            has_attn = i < nb - 1
+            for j in range(cfg.layers_per_block):
+                r = pop(res_d)
+                h = self.resnet(f"down_blocks.{i}.resnets.{j}.", h, None, boc[i], r2=None if has_attn else r)
+                if has_attn:
+                    h = self.transformer(f"down_blocks.{i}.attentions.{j}.", h, r2=r)
+                skips.append(h)
+                feats_d.append(h)
+            if i < nb - 1:
+                h = self.conv3x3(h, f"down_blocks.{i}.downsamplers.0.conv", boc[i], stride=2, r2=pop(res_d),
+                                 kind="downsample")
+                skips.append(h)
+                feats_d.append(h)
+        # mid (unet_2d_blocks.py:860-899) ; residual after the block (unet_2d_condition.py:1292-1296)
+        h = self.resnet("mid_block.resnets.0.", h, None, boc[-1])
+        h = self.transformer("mid_block.attentions.0.", h)
+        h = self.resnet("mid_block.resnets.1.", h, None, boc[-1], r2=residuals.mid if residuals is not None else None)
+        feat_mid = h
+        rev = list(reversed(boc))
+        for i in range(nb):
+            has_attn = i > 0
+            n_res = cfg.layers_per_block + 1
+            res = skips[-n_res:]
+            del skips[-n_res:]
+            for j in range(n_res):
+                r = pop(res_u)
+                sk = res.pop()
+                h = self.resnet(f"up_blocks.{i}.resnets.{j}.", h, sk, rev[i], r2=None if has_attn else r)
+                if has_attn:
+                    h = self.transformer(f"up_blocks.{i}.attentions.{j}.", h, r2=r)
+                feats_u.append(h)
+            if i < nb - 1:
+                size = (skips[-1].H, skips[-1].W)
+                h = self.conv3x3(h, f"up_blocks.{i}.upsamplers.0.conv", rev[i], up_to=size, r2=pop(res_u),
+                                 kind="upsample")
+                feats_u.append(h)
+        if not cfg.is_blobnet:
+            n = self.groupnorm(h, None, "conv_norm_out", 1e-5, True)
+            eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out")
+            return eps.t
+        # BlobNet: zero-convs (bn:860-864, 881, 921-924) scaled by conditioning_scale (bn:936-938)
+        alpha, alpha_dev, alpha_idx = zero_scale if zero_scale is not None else (1.0, None, None)
+
+        def zc(name, f: Act):
+            M = self.B * f.H * f.W
+            return self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
+                              alpha_idx=alpha_idx).view(self.B, f.H * f.W, f.C)
+
+        down = [zc(f"blobnet_down_blocks.{k}", f) for k, f in enumerate(feats_d)]
+        mid = zc("blobnet_mid_block", feat_mid)
+        up = [zc(f"blobnet_up_blocks.{k}", f) for k, f in enumerate(feats_u)]
+        self.feat_shapes = ([(f.C, f.H, f.W) for f in feats_d], (feat_mid.C, feat_mid.H, feat_mid.W),
+                            [(f.C, f.H, f.W) for f in feats_u])
+        return Residuals(down, mid, up, bmod=self.B)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,229 @@
+"""Launch recorder: turns the hot path into a STATIC list of C-ABI kernel launches over pre-allocated device buffers.
+
+Every method allocates its output once (PyTorch is only the device allocator here), builds the ctypes argument block
+once, and appends a zero-argument-ish launch closure `fn(stream)` to the current segment.  Running a segment is a flat
+loop over closures; because buffers and argument blocks never change, a segment can be captured into a hipGraph
+(`Segment.capture`) and replayed with one `hipGraphLaunch`.
+"""
+import ctypes as C
+from typing import Callable, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import BcGemm
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Segment:
+    """An ordered list of launches; replayable eagerly or as a hipGraph."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.calls: List[Callable] = []
+        self.graph = None
+        self.flops = 0          # algorithmic 2*MAC of the GEMM / attention launches recorded here
+        self.kinds = {}
+
+    def run(self, stream: int):
+        if self.graph is not None:
+            _lib.check(_lib.load().bc_graph_launch(self.graph, stream), "bc_graph_launch")
+            return
+        for fn in self.calls:
+            fn(stream)
+
+    def capture(self, stream: int):
+        """Capture this segment into a hipGraph on `stream` (a non-default stream)."""
+        lib = _lib.load()
+        _lib.check(lib.bc_graph_begin(stream), "bc_graph_begin")
+        try:
+            for fn in self.calls:
+                fn(stream)
+        finally:
+            g = C.c_void_p()
+            rc = lib.bc_graph_end(stream, C.byref(g))
+        _lib.check(rc, "bc_graph_end")
+        self.graph = g
+
+    def release(self):
+        if self.graph is not None:
+            _lib.load().bc_graph_destroy(self.graph)
+            self.graph = None
+
+
+class Recorder:
+    def __init__(self, device: torch.device):
+        self.lib = _lib.load()
+        self.device = device
+        self.seg: Optional[Segment] = None
+        self.keep = []                      # keeps ctypes blocks / tensors alive
+        self._slab = None
+        self._slab_elems = 0
+        info = (C.c_int * 4)()
+        _lib.check(self.lib.bc_device_info(info), "bc_device_info")
+        self.num_cu = info[0]
+        self.bytes_allocated = 0
+
+    # ------------------------------------------------------------------ buffers
+    def empty(self, *shape, dtype=torch.float16):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self.bytes_allocated += t.numel() * t.element_size()
+        return t
+
+    def zeros(self, *shape, dtype=torch.float16):
+        t = torch.zeros(*shape, dtype=dtype, device=self.device)
+        self.bytes_allocated += t.numel() * t.element_size()
+        return t
+
+    def begin(self, name: str) -> Segment:
+        self.seg = Segment(name)
+        return self.seg
+
+    def _push(self, fn, kind, flops=0):
+        self.seg.calls.append(fn)
+        self.seg.flops += flops
+        self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
+
+    def slab(self, elems: int):
+        """Shared split-K scratch: consumed by the reduce kernel that immediately follows on the same stream."""
+        if elems > self._slab_elems:
+            raise RuntimeError("split-K slab requested after planning froze its size")
+        return self._slab
+
+    def reserve_slab(self, elems: int):
+        if elems > self._slab_elems:
+            self._slab = torch.empty(elems, dtype=torch.float32, device=self.device)
+            self._slab_elems = elems
+
+    # ------------------------------------------------------------------ GEMM family
+    def choose_splitk(self, M, N, K):
+        bm, bn = (256, 64) if (((N + 127) // 128) * 128) / N > 1.10 else (128, 128)
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        nk = (K + 63) // 64
+        if tiles >= int(0.75 * self.num_cu) or nk < 8:
+            return 1
+        want = (2 * self.num_cu + tiles - 1) // tiles
+        return max(1, min(want, nk // 4, 16))
+
+    def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
+             conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
+             alpha=1.0, alpha_dev=None, alpha_idx=None, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
+             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0):
+        """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
+        Pointer offsets are in ELEMENTS of the respective tensor."""
+        n_out = N // 2 if act == _lib.ACT_GEGLU else N
+        g = BcGemm()
+        g.A = A.data_ptr() + a_offset * A.element_size()
+        g.A2 = ptr(A2)
+        g.a_mode = _lib.A_CONV3X3 if conv else _lib.A_DENSE
+        g.M, g.N, g.K = M, N, K
+        g.lda = lda if lda is not None else K
+        g.lda2, g.C1 = lda2, C1
+        if conv:
+            g.Cin, g.Hin, g.Win = conv["Cin"], conv["Hin"], conv["Win"]
+            g.Hv, g.Wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
+            g.Hout, g.Wout, g.stride = conv["Hout"], conv["Wout"], conv.get("stride", 1)
+        g.W = W.data_ptr() + w_offset * W.element_size()
+        g.ldw = K
+        g.bias = ptr(bias)
+        g.rowvec = ptr(rowvec) if not isinstance(rowvec, int) else rowvec
+        g.ld_rowvec, g.rows_per_batch = ld_rowvec, rows_per_batch
+        g.act = act
+        g.colscale = ptr(colscale)
+        g.alpha = alpha
+        g.alpha_dev, g.alpha_idx = ptr(alpha_dev), ptr(alpha_idx)
+        g.R, g.ldr = (ptr(R) if not isinstance(R, int) else R), ldr
+        g.R2, g.ldr2, g.r2_xmin, g.r2_bmod, g.out_w = ptr(R2), ldr2, r2_xmin, r2_bmod, out_w
+        g.out_mode = out_mode
+        g.C = out.data_ptr() + out_offset * out.element_size()
+        g.ldc = ldc if ldc is not None else n_out
+        sk = splitk if splitk is not None else self.choose_splitk(M, N, K)
+        g.splitk = sk
+        if sk > 1:
+            self.reserve_slab(sk * M * N)
+        rec = self
+
+        def fn(stream, g=g, lib=self.lib):
+            if g.splitk > 1:
+                g.slab = rec._slab.data_ptr()
+            rc = lib.bc_gemm(C.byref(g), stream)
+            if rc:
+                _lib.check(rc, "bc_gemm")
+
+        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx))
+        self._push(fn, kind, 2 * M * N * K)
+        return out
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out=None):
+        lib = self.lib
+        Cc = C1 + (C2 if x2 is not None else 0)
+        nslab = (HW + 63) // 64
+        part = self.empty(B, nslab, G, 2, dtype=torch.float32)
+        ab = self.empty(B, Cc, 2, dtype=torch.float32)
+        if out is None:
+            out = self.empty(B, HW, Cc)
+        p1, p2, pp, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(part), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
+        c2 = C2 if x2 is not None else 0
+
+        def fn(stream):
+            rc = lib.bc_gn_stats(p1, C1, p2, c2, B, HW, G, pp, nslab, stream)
+            rc = rc or lib.bc_gn_finalize(pp, nslab, B, HW, Cc, G, eps, pg, pb, pab, stream)
+            rc = rc or lib.bc_gn_apply(p1, C1, p2, c2, B, HW, pab, 1 if silu else 0, po, stream)
+            if rc:
+                _lib.check(rc, "groupnorm")
+
+        self.keep.append((x1, x2, part, ab, gamma, beta, out))
+        self._push(fn, "groupnorm")
+        return out
+
+    def layernorm(self, x, rows, Cc, gamma, beta, eps, out=None, ldx=None, ldy=None):
+        lib = self.lib
+        if out is None:
+            out = self.empty(rows, Cc)
+        px, pg, pb, po = ptr(x), ptr(gamma), ptr(beta), ptr(out)
+        ldx = ldx or Cc
+        ldy = ldy or Cc
+
+        def fn(stream):
+            rc = lib.bc_layernorm(px, rows, Cc, ldx, pg, pb, eps, po, ldy, stream)
+            if rc:
+                _lib.check(rc, "bc_layernorm")
+
+        self.keep.append((x, gamma, beta, out))
+        self._push(fn, "layernorm")
+        return out
+
+    # ------------------------------------------------------------------ attention
+    def attention(self, Q, K, Vt, out, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale,
+                  q_off=0, k_off=0):
+        lib = self.lib
+        pq = Q.data_ptr() + q_off * 2
+        pk = K.data_ptr() + k_off * 2
+        pv, po = ptr(Vt), ptr(out)
+
+        def fn(stream):
+            rc = lib.bc_attention(pq, pk, pv, po, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale,
+                                  stream)
+            if rc:
+                _lib.check(rc, "bc_attention")
+
+        self.keep.append((Q, K, Vt, out))
+        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d)
+        return out
+
+    # ------------------------------------------------------------------ glue
+    def call(self, name, *args, kind=None, keep=()):
+        """Record a generic `bc_<name>(*args, stream)` launch with pre-marshalled arguments."""
+        f = getattr(self.lib, name)
+
+        def fn(stream):
+            rc = f(*args, stream)
+            if rc:
+                _lib.check(rc, name)
+
+        self.keep.append(keep)
+        self._push(fn, kind or name)

@@ -1,0 +1,228 @@
+"""The blob-conditioned denoising loop on MI355X: host-side mirror of StableDiffusionBlobNetPipeline.__call__.
+
+Mirrors blobctrl/pipelines/pipeline_blobnet.py:743-1166 for the hot-path part:
+same keyword names and meaning (`num_inference_steps`, `guidance_scale`, `generator`, `latents`,
+`blobnet_conditioning_scale` (must be a Python float, pipe:395-396), `blobnet_control_guidance_start/end`,
+`output_type="latent"`), same error behaviour for bad arguments.  VAE encode/decode and the CLIP text encoder sit on
+either side of the loop and are out of scope this round: callers pass image latents and prompt embeddings.
+
+Execution model: one static launch plan per (batch, canvas, steps) configuration -
+    prologue (once per edit): cross-attention K/V of the prompt embeddings
+    step A (BlobNet active):  assemble BlobNet input -> BlobNet (batch B, CFG halves share it) -> assemble UNet input
+                              -> UNet (batch 2B, BlobNet residuals added in GEMM epilogues) -> crop + CFG + scheduler step
+    step I (BlobNet inactive, cond_scale * keep[i] == 0): UNet only
+each captured once into a hipGraph and replayed per step; per-step scalars (timestep, scheduler coefficients,
+conditioning scale) live in device tables indexed by a device-side step counter.
+"""
+from typing import List, Optional, Union
+
+import torch
+
+from . import _lib
+from .engine import TrunkConfig, TrunkPlan
+from .launch import Recorder
+from .schedulers import DDIMTable, UniPCTable
+from .weights import PackedTrunk, pad8
+
+
+def blobnet_keep(num_steps, start, end):
+    """pipe:1006-1012."""
+    return [1.0 - float(i / num_steps < start or (i + 1) / num_steps > end) for i in range(num_steps)]
+
+
+class StableDiffusionBlobNetPipeline:
+    """MI355X engine with the reference pipeline's call surface for the denoising hot path."""
+
+    def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
+                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.BlobCtrlHipError("blobctrl_amd runs on MI355X only (device must be cuda:N); there is no CPU fallback")
+        torch.cuda.set_device(self.device)
+        _lib.load()
+        self.unet_cfg, self.blob_cfg = unet_config, blobnet_config
+        self.unet_w = PackedTrunk(unet_state_dict, self.device, unet_config.block_out_channels)
+        self.blob_w = PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
+        self.scheduler_kind = scheduler
+        self.use_graphs = use_graphs
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._plans = {}
+        self.feat_dim = blobnet_config.in_channels - 5
+
+    # ------------------------------------------------------------------------------------------------ planning
+    def _plan(self, B, h, w, T, ctx_dim, nsteps):
+        key = (B, h, w, T, ctx_dim, nsteps)
+        if key in self._plans:
+            return self._plans[key]
+        dev = self.device
+        rec = Recorder(dev)
+        P = type("Plan", (), {})()
+        P.rec = rec
+        H, W = h, 2 * w
+        F = self.feat_dim
+        f32 = torch.float32
+        P.latents = rec.zeros(B, 4, h, w, dtype=f32)
+        P.fg_lat = rec.zeros(1, 4, h, w, dtype=f32)
+        P.bg_lat = rec.zeros(1, 4, h, w, dtype=f32)
+        P.fg_score = rec.zeros(1, h, w, dtype=f32)
+        P.bg_score = rec.zeros(1, h, w, dtype=f32)
+        P.feat = rec.zeros(1, max(F, 1), dtype=f32)
+        P.ctx = rec.zeros(2 * B, T, ctx_dim)
+        P.step_idx = rec.zeros(1, dtype=torch.int32)
+        P.t_table = rec.zeros(nsteps, dtype=f32)
+        P.coef = rec.zeros(nsteps, 16, dtype=f32)
+        P.scale_table = rec.zeros(nsteps, dtype=f32)
+        P.hist = rec.zeros(3, B * 4 * h * w, dtype=f32)
+        P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32)
+        P.guidance = [7.5]
+
+        unet_cin, blob_cin = pad8(self.unet_cfg.in_channels), pad8(self.blob_cfg.in_channels)
+        P.blob_in = rec.zeros(B, H * W, blob_cin)
+        P.unet_in = rec.zeros(2 * B, H * W, unet_cin)
+
+        # ---- prologue: prompt K/V
+        P.prologue = rec.begin("prologue")
+        unet_a = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
+        unet_a.record_context(P.ctx, T)
+
+        def record_unet(plan, residuals):
+            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, 1, 0,
+                     2 * B, h, w, unet_cin, P.unet_in.data_ptr(), kind="assemble")
+            plan.record_time(P.t_table, P.step_idx)
+            eps = plan.record_forward(P.unet_in, residuals)
+            P.eps = eps
+            g = P.guidance
+
+            def step_fn(stream, lib=rec.lib):
+                rc = lib.bc_cfg_scheduler_step(eps.data_ptr(), P.latents.data_ptr(), P.coef.data_ptr(),
+                                               P.step_idx.data_ptr(), P.hist.data_ptr(), g[0], B, h, w,
+                                               P.eps_guided.data_ptr(), 1, stream)
+                if rc:
+                    _lib.check(rc, "bc_cfg_scheduler_step")
+            rec._push(step_fn, "cfg_step")
+
+        # ---- step A: BlobNet + UNet
+        P.step_active = rec.begin("step_active")
+        rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
+                 P.feat.data_ptr() if F > 0 else None, 1, F, B, h, w, blob_cin, P.blob_in.data_ptr(), kind="assemble")
+        blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
+        blob.record_time(P.t_table, P.step_idx)
+        residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx))
+        P.residuals = residuals
+        record_unet(unet_a, residuals)
+        P.eps_active = P.eps
+
+        # ---- step I: UNet only (cond_scale == 0: BlobNet output is multiplied by 0, bn:936-938)
+        P.step_inactive = rec.begin("step_inactive")
+        unet_i = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
+        unet_i.ctx_kv = unet_a.ctx_kv
+        record_unet(unet_i, None)
+        P.eps_inactive = P.eps
+        P.captured = False
+        self._plans[key] = P
+        return P
+
+    def _capture(self, P):
+        if P.captured or not self.use_graphs:
+            return
+        s = self.stream.cuda_stream
+        # warm-up run outside capture (module loading, attribute setting) then capture each segment once
+        torch.cuda.synchronize(self.device)
+        for seg in (P.step_active, P.step_inactive):
+            seg.run(s)
+        self.stream.synchronize()
+        for seg in (P.step_active, P.step_inactive):
+            seg.capture(s)
+        self.stream.synchronize()
+        P.captured = True
+
+    # ------------------------------------------------------------------------------------------------ call
+    def check_inputs(self, blobnet_conditioning_scale, start, end, num_inference_steps):
+        if not isinstance(blobnet_conditioning_scale, float):                       # pipe:395-396
+            raise TypeError("For single blobnet: `blobnet_conditioning_scale` must be type `float`.")
+        if start >= end:                                                            # pipe:424-427
+            raise ValueError(f"control guidance start: {start} cannot be larger or equal to control guidance end: {end}.")
+        if start < 0.0:
+            raise ValueError(f"control guidance start: {start} can't be smaller than 0.")
+        if end > 1.0:
+            raise ValueError(f"control guidance end: {end} can't be larger than 1.0.")
+        if num_inference_steps < 1:
+            raise ValueError("num_inference_steps must be >= 1")
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds: torch.Tensor, fg_image_latents: torch.Tensor, bg_image_latents: torch.Tensor,
+                 gs_score: torch.Tensor, dino_feats: Optional[torch.Tensor] = None, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None,
+                 latents: Optional[torch.Tensor] = None, blobnet_conditioning_scale: float = 1.0,
+                 blobnet_control_guidance_start: float = 0.0, blobnet_control_guidance_end: float = 1.0,
+                 output_type: str = "latent", callback_on_step_end=None, trace: Optional[list] = None,
+                 teacher_latents: Optional[List[torch.Tensor]] = None):
+        """prompt_embeds [2B, T, D] = cat(negative, positive) (pipe:937-949); fg/bg_image_latents [1,4,h,w] already scaled
+        by 0.18215 (pipe:300-309); gs_score [1,2,h,w] = (bg, fg) scores (pipe:974); dino_feats [1,1,F] (pipe:982).
+        Returns the final latents [B,4,h,w] fp32 (`output_type="latent"`, pipe:1132,1143)."""
+        if output_type != "latent":
+            raise NotImplementedError("VAE decode is outside the hot path (SURVEY 8f): use output_type='latent'")
+        self.check_inputs(blobnet_conditioning_scale, blobnet_control_guidance_start, blobnet_control_guidance_end,
+                          num_inference_steps)
+        B2, T, Dc = prompt_embeds.shape
+        if B2 % 2:
+            raise ValueError("prompt_embeds must hold the negative and positive halves (classifier-free guidance)")
+        B = B2 // 2
+        h, w = fg_image_latents.shape[-2:]
+        n = num_inference_steps
+        P = self._plan(B, h, w, T, Dc, n)
+        dev = self.device
+        sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
+        sched.set_timesteps(n)
+        self.timesteps = sched.timesteps
+        if latents is None:                                                          # pipe:438-453
+            latents = torch.randn((B, 4, h, w), generator=generator, device=generator.device if generator else "cpu",
+                                  dtype=torch.float32)
+        keep = blobnet_keep(n, blobnet_control_guidance_start, blobnet_control_guidance_end)
+        scales = [blobnet_conditioning_scale * k for k in keep]
+        bg, fg = gs_score.unbind(dim=1)                                              # pipe:974
+        with torch.cuda.stream(self.stream):
+            P.latents.copy_(latents.to(dev, torch.float32) * sched.init_noise_sigma)
+            P.fg_lat.copy_(fg_image_latents.to(dev, torch.float32).reshape(1, 4, h, w))
+            P.bg_lat.copy_(bg_image_latents.to(dev, torch.float32).reshape(1, 4, h, w))
+            P.fg_score.copy_(fg.to(dev, torch.float32).reshape(1, h, w))
+            P.bg_score.copy_(bg.to(dev, torch.float32).reshape(1, h, w))
+            if self.feat_dim > 0:
+                if dino_feats is None:
+                    raise ValueError("dino_feats is required (BlobNet conditioning channels)")
+                P.feat.copy_(dino_feats.to(dev, torch.float32).reshape(1, self.feat_dim))
+            P.ctx.copy_(prompt_embeds.to(dev, torch.float16))
+            P.t_table.copy_(sched.timesteps.to(torch.float32))
+            P.coef.copy_(sched.table())
+            P.scale_table.copy_(torch.tensor(scales, dtype=torch.float32))
+            P.step_idx.zero_()
+            P.hist.zero_()
+        P.guidance[0] = float(guidance_scale)
+        s = self.stream.cuda_stream
+        self.stream.synchronize()
+        if teacher_latents is None and callback_on_step_end is None and trace is None:
+            self._capture(P)
+            # captured segments left the step counter advanced by the warm-up runs: reset per-edit state
+            with torch.cuda.stream(self.stream):
+                P.latents.copy_(latents.to(dev, torch.float32) * sched.init_noise_sigma)
+                P.step_idx.zero_()
+                P.hist.zero_()
+        P.prologue.run(s)
+        for i in range(n):
+            if teacher_latents is not None:
+                with torch.cuda.stream(self.stream):
+                    P.latents.copy_(teacher_latents[i].to(dev, torch.float32))
+            seg = P.step_active if scales[i] != 0.0 else P.step_inactive
+            seg.run(s)
+            if trace is not None:
+                self.stream.synchronize()
+                trace.append((P.eps_guided.clone(), P.latents.clone()))
+            if callback_on_step_end is not None:
+                self.stream.synchronize()
+                callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
+        self.stream.synchronize()
+        return P.latents.clone()
+
+    # convenience for bench / tests ------------------------------------------------------------------
+    def plan_for(self, B, h, w, T, ctx_dim, nsteps):
+        return self._plan(B, h, w, T, ctx_dim, nsteps)

@@ -1,0 +1,114 @@
+"""Weight pipeline: reference-schema state_dict (fp32, CPU) -> LoRA merge -> packed fp16 device layouts.
+
+Layouts (all K-contiguous so that both MFMA operands are read with ds_read_b128):
+  * conv3x3  [Co, Ci, 3, 3]  ->  [Co, 9 * Ci_pad]  with k = (ky*3 + kx) * Ci_pad + ci     (NHWC implicit-GEMM order)
+  * conv1x1 / Linear [Co, Ci] ->  [Co, Ci_pad]
+  * GEGLU proj [8C, C] (first half value, second half gate: D/models/activations.py:117-123) -> rows interleaved in
+    groups of 64 = 32 value rows | 32 gate rows so that one wavefront holds matching value/gate accumulators.
+  * to_q | to_k concatenated along N (one GEMM), to_v separate (its epilogue writes V transposed for the attention kernel).
+  * all ResnetBlock2D.time_emb_proj of a net concatenated along N (one GEMM per step for the 22 projections).
+  * biases, norm scales and shifts stay fp32.
+
+LoRA (reference: D/loaders/unet.py:271-340, peft semantics W + (alpha / r) * B @ A; peft itself is absent from the
+reference tree, so this merge is pinned only against the closed form - "LoRA parity unpinned").
+"""
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], alphas: Optional[Dict[str, float]] = None,
+               adapter_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Return a copy of `sd` with every `<module>.lora_A.weight` / `<module>.lora_B.weight` pair merged into
+    `<module>.weight`.  Rank r = lora_B.shape[1]; scale = alpha / r with alpha defaulting to r (D/loaders/unet.py:314-340)."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for key in list(lora.keys()):
+        if not key.endswith(".lora_A.weight"):
+            continue
+        mod = key[: -len(".lora_A.weight")]
+        a = lora[key].float()
+        b = lora[mod + ".lora_B.weight"].float()
+        r = b.shape[1]
+        alpha = float(alphas.get(mod, r)) if alphas else float(r)
+        w = out[mod + ".weight"]
+        delta = (b.flatten(1) @ a.flatten(1)).reshape(w.shape)
+        out[mod + ".weight"] = w + (adapter_scale * alpha / r) * delta
+    return out
+
+
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    co, ci = w.shape[:2]
+    cip = pad8(ci)
+    p = torch.zeros(co, 3, 3, cip, dtype=torch.float32)
+    p[..., :ci] = w.permute(0, 2, 3, 1)
+    return p.reshape(co, 9 * cip)
+
+
+def pack_matrix(w: torch.Tensor) -> torch.Tensor:
+    w = w.reshape(w.shape[0], -1)
+    co, ci = w.shape
+    cip = pad8(ci)
+    if cip == ci:
+        return w.contiguous()
+    p = torch.zeros(co, cip, dtype=torch.float32)
+    p[:, :ci] = w
+    return p
+
+
+def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
+    """[8C, C] / [8C] -> rows ordered (32 value, 32 gate) per group."""
+    n = w.shape[0] // 2
+    assert n % 32 == 0, "GEGLU inner dim must be a multiple of 32"
+    wv, wg = w[:n].reshape(n // 32, 32, -1), w[n:].reshape(n // 32, 32, -1)
+    bv, bg = b[:n].reshape(n // 32, 32), b[n:].reshape(n // 32, 32)
+    return torch.cat([wv, wg], dim=1).reshape(2 * n, -1).contiguous(), torch.cat([bv, bg], dim=1).reshape(2 * n).contiguous()
+
+
+class PackedTrunk:
+    """Device-resident packed weights of one trunk (UNet or BlobNet)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, block_out_channels, layers_per_block=2):
+        self.device = device
+        self.h: Dict[str, torch.Tensor] = {}       # fp16 matrices
+        self.f: Dict[str, torch.Tensor] = {}       # fp32 vectors
+        self.boc = tuple(block_out_channels)
+        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.has_cross = any(".attn2." in k for k in sd)
+        temb_w, temb_b, self.temb_slices = [], [], {}
+        off = 0
+        for k, v in sd.items():
+            if k.endswith(".bias") or (v.ndim == 1):
+                if ".time_emb_proj." in k or ".ff.net.0.proj." in k:
+                    continue
+                self.f[k] = v.to(device)
+                continue
+            if ".time_emb_proj.weight" in k:
+                p = k[: -len("time_emb_proj.weight")]
+                temb_w.append(v)
+                temb_b.append(sd[p + "time_emb_proj.bias"])
+                self.temb_slices[p] = (off, v.shape[0])
+                off += v.shape[0]
+            elif ".ff.net.0.proj.weight" in k:
+                w, b = interleave_geglu(v, sd[k[:-6] + "bias"])
+                self.h[k] = w.half().to(device)
+                self.f[k[:-6] + "bias"] = b.to(device)
+            elif k.endswith("attn1.to_q.weight"):
+                p = k[: -len("to_q.weight")]
+                self.h[p + "to_qk.weight"] = torch.cat([v, sd[p + "to_k.weight"]], 0).half().to(device)
+            elif k.endswith("attn1.to_k.weight"):
+                continue
+            elif v.ndim == 4 and v.shape[-1] == 3:
+                self.h[k] = pack_conv3x3(v).half().to(device)
+            else:
+                self.h[k] = pack_matrix(v).half().to(device)
+        self.temb_total = off
+        self.h["temb_all.weight"] = torch.cat(temb_w, 0).half().to(device)
+        self.f["temb_all.bias"] = torch.cat(temb_b, 0).to(device)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in list(self.h.values()) + list(self.f.values()))

@@ -1,0 +1,185 @@
+/*
+ * blobctrl_hip.h  --  C ABI of libblobctrl_hip.so, the MI355X (gfx950) kernels for the BlobCtrl denoising hot path.
+ *
+ * Boundary contract: the reference has no FFI layer, its hot path is a chain of ATen calls made from
+ * Python nn.Modules.  This library replaces those ATen calls one for one; every entry point below cites the reference
+ * call site(s) it stands in for (paths relative to the reference root, D/ = diffusers/src/diffusers/).
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless marked host; sizes are ints; no torch / C++ types.
+ *   - activations are fp16 ("bc_half" = IEEE binary16) in NHWC / token-major layout [B][H*W][C]; accumulation,
+ *     normalisation statistics, softmax and the scheduler state are fp32.
+ *   - every K-contiguous dimension (channels, head_dim) is a multiple of 8 elements (16 bytes); callers pad.
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no internal threads, no allocation, no
+ *     synchronisation: every launch function is hipGraph-capturable.  The caller owns all buffers.
+ *   - return value: 0 on success, non-zero on error; bc_last_error() returns a thread-local message.
+ */
+#ifndef BLOBCTRL_HIP_H
+#define BLOBCTRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t bc_half;          /* IEEE fp16 bit pattern */
+typedef void*    bc_stream;        /* hipStream_t */
+
+const char* bc_last_error(void);
+int bc_version(void);
+/* Device properties of the current device: [0]=multiProcessorCount, [1]=warpSize, [2]=sharedMemPerBlock(KiB), [3]=gcn major*100+minor */
+int bc_device_info(int* out4);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16):   C[M][N] = epilogue( A[M][K] . W[N][K]^T )
+ * Replaces: F.conv2d 3x3 / 1x1 (D/models/resnet.py:341,366,368; downsampling.py:147; upsampling.py:180;
+ *           transformer_2d.py:484,521; unet_2d_condition.py:1172,1344; blobnet.py:840,862-864,881,922-924),
+ *           F.linear (attention_processor.py:2191-2224; attention.py:1165-1167; activations.py:117-123;
+ *           embeddings.py:576-588; resnet.py:343-350) and the patched right-half residual add
+ *           (unet_2d_blocks.py:1303-1307 et al.).
+ * --------------------------------------------------------------------------------------------------------------- */
+enum { BC_A_DENSE = 0, BC_A_CONV3X3 = 1 };
+enum { BC_ACT_NONE = 0, BC_ACT_GELU = 1, BC_ACT_GEGLU = 2, BC_ACT_SILU = 3 };
+enum { BC_OUT_F16 = 0, BC_OUT_F16_T = 1, BC_OUT_F32 = 2 };
+
+typedef struct BcGemm {
+    /* ---- A operand ---- */
+    const bc_half* A;        /* DENSE: [M][lda] rows; CONV3X3: NHWC image [B][Hin][Win][Cin] */
+    const bc_half* A2;       /* DENSE only, optional second source: columns k >= C1 come from A2[m][k - C1] (channel concat) */
+    int a_mode;              /* BC_A_* */
+    int M, N, K;             /* GEMM dims; CONV3X3: M = B*Hout*Wout, K = 9*Cin; weights are [N][ky][kx][Cin] */
+    int lda, lda2;           /* DENSE row strides (elements) */
+    int C1;                  /* DENSE with A2: split point (multiple of 8); else ignored */
+    int Cin;                 /* CONV3X3: input channels (multiple of 8) */
+    int Hin, Win;            /* CONV3X3: stored input image size */
+    int Hv, Wv;              /* CONV3X3: virtual (nearest-upsampled) input size the 3x3 window slides over; = Hin,Win when no upsample */
+    int Hout, Wout;          /* CONV3X3: output size */
+    int stride;              /* CONV3X3: 1 or 2 (pad is always 1) */
+    /* ---- B operand ---- */
+    const bc_half* W;        /* [N][ldw], K contiguous */
+    int ldw;
+    /* ---- epilogue:  v = acc (+bias[n]) (+rowvec[m / rows_per_batch][n]) ; v = act(v) ; v *= colscale[n] ; v *= alpha ;
+     *                 v += R[m][n] ; v += R2[(b % r2_bmod, pixel)][n] if x(m) >= r2_xmin ---- */
+    const float*   bias;     /* [N] fp32 or NULL (GEGLU: [N] in the interleaved order of W) */
+    const bc_half* rowvec;   /* per-batch row vector [B][ld_rowvec] (time-embedding projection) or NULL */
+    int ld_rowvec;
+    int rows_per_batch;      /* H*W of the output (for rowvec / R2 / transposed-output indexing); 0 => M */
+    int act;                 /* BC_ACT_* ; GEGLU: columns come in groups of 64 = 32 value | 32 gate, output has N/2 columns */
+    const float*   colscale; /* [N] or NULL (DINOv2 LayerScale) */
+    float alpha;             /* scalar multiplier (1.0f default) */
+    const float*   alpha_dev;/* optional device scalar table: alpha *= alpha_dev[*alpha_idx] (BlobNet conditioning_scale*keep[i]) */
+    const int*     alpha_idx;
+    const bc_half* R;        /* residual [M][ldr] or NULL */
+    int ldr;
+    const bc_half* R2;       /* BlobNet residual, token-major [r2_bmod][rows_per_batch][ldr2], added where x >= r2_xmin */
+    int ldr2, r2_xmin, r2_bmod, out_w;   /* out_w = Wout (x = m % out_w) */
+    /* ---- output ---- */
+    int out_mode;            /* BC_OUT_F16: C[m*ldc + n]; BC_OUT_F16_T: C[(b*N + n)*ldc + (m % rows_per_batch)]; BC_OUT_F32: float C */
+    void* C;
+    int ldc;
+    /* ---- split-K ---- */
+    int splitk;              /* >=1 ; >1 needs `slab` of splitk*M*N floats */
+    float* slab;
+} BcGemm;
+
+int bc_gemm(const BcGemm* p, bc_stream stream);
+int bc_sizeof_gemm(void);            /* sizeof(BcGemm), lets FFI bindings verify their struct mirror */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
+ * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
+ * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
+ *   bc_gn_stats    : partial sums   part[B][nslab][G][2]
+ *   bc_gn_finalize : per-channel affine  ab[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma)
+ *   bc_gn_apply    : y[B][HW][C] = silu?( x*ab.x + ab.y )   (x = concat(x1, x2))
+ * --------------------------------------------------------------------------------------------------------------- */
+int bc_gn_stats(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW, int G,
+                float* part, int nslab, bc_stream stream);
+int bc_gn_finalize(const float* part, int nslab, int B, int HW, int C, int G, float eps,
+                   const float* gamma, const float* beta, float* ab, bc_stream stream);
+int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW,
+                const float* ab, int silu, bc_half* y, bc_stream stream);
+
+/* LayerNorm over the last dim of [rows][C]  (attention.py:447,491,517; transformers Dinov2Layer norm1/norm2/layernorm). */
+int bc_layernorm(const bc_half* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
+                 bc_half* y, int ldy, bc_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Flash attention forward, one launch per (self|cross) attention layer.
+ * Replaces F.scaled_dot_product_attention (attention_processor.py:2216-2218) and the DINOv2 eager attention.
+ *   Q  [B][Nq ][ldq] , head h at columns h*d .. h*d+d-1
+ *   K  [B][Nkv][ldk]
+ *   Vt [B][heads*d][ldvt]  (V TRANSPOSED: key index contiguous; ldvt >= Nkv rounded up to 64, padding zero)
+ *   O  [B][Nq ][ldo]
+ * softmax(scale * Q K^T) V with fp32 online softmax.  d in {8,16,32,40,64,80,160}.
+ * --------------------------------------------------------------------------------------------------------------- */
+int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O,
+                 int B, int heads, int d, int Nq, int Nkv,
+                 int ldq, int ldk, int ldvt, int ldo,
+                 long long q_bstride, long long k_bstride, long long vt_bstride, long long o_bstride,
+                 float scale, bc_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Blob maths and loop glue
+ * --------------------------------------------------------------------------------------------------------------- */
+/* Gaussian-blob splat rasteriser: blobctrl/utils/utils.py:145-194 (tuple score_size branch, return_d_score=True).
+ * params (HOST doubles, 8 per blob image): xs, ys, cov00, cov01, cov10, cov11, size, unused.
+ * out: DEVICE double [n][2][h][w]  (channel 0 = background, 1 = foreground), computed in fp64 like the reference. */
+int bc_splat_scores(const double* params_host, int n, int h, int w, double* out, bc_stream stream);
+
+/* Input assembly: pipeline_blobnet.py:724-739 (construct_blobnet_input) fused with NCHW->NHWC, fp16 cast, channel padding
+ * and the rank-1 feature splat (pipeline_blobnet.py:706-721).  Writes X[Bout][h][2w][Cpad]:
+ *   left half  = (img_lat[bi][4], score[bi], score*feat[bi][0..F))   right half = (latents[b % Blat][4], score, score*feat)
+ * with bi = b % Bimg.  latents fp32 [Blat][4][h][w] (NCHW), img_lat fp32 [Bimg][4][h][w], score fp32 [Bimg][h][w],
+ * feat fp32 [Bimg][F] or NULL (F = 0). */
+int bc_assemble_input(const float* latents, int Blat, const float* img_lat, const float* score, const float* feat,
+                      int Bimg, int F, int Bout, int h, int w, int Cpad, bc_half* X, bc_stream stream);
+
+/* Sinusoidal timestep embedding (embeddings.py:27-78, flip_sin_to_cos=True, shift 0) for `rows` identical rows.
+ * t = t_table[*t_idx] when t_table != NULL else t_value.  out [rows][dim] fp16. */
+int bc_timestep_embedding(const float* t_table, const int* t_idx, float t_value, int rows, int dim, bc_half* out,
+                          bc_stream stream);
+
+/* SiLU elementwise on fp16 (resnet.py:345 nonlinearity(temb)). */
+int bc_silu(const bc_half* x, bc_half* y, long long n, bc_stream stream);
+
+/* Crop (right half) + classifier-free guidance + scheduler step, all fp32 state
+ * (pipeline_blobnet.py:1092-1102; scheduling_unipc_multistep.py:822-901 / scheduling_ddim.py:342-468 as linear
+ * combinations with per-step host-precomputed coefficients).
+ *   eps      : UNet output, fp32 token-major [2B][h][2w][4]  (uncond batch first, then cond)
+ *   latents  : fp32 [B][4][h][w] NCHW, updated in place
+ *   coef     : device table [nsteps][16] (layout in blobctrl_amd/schedulers.py), row = *step_idx
+ *   hist     : fp32 [3][B*4*h*w] scheduler history (x0_prev, x0_prevprev, last_sample)
+ *   eps_out  : optional fp32 [B][4][h][w] guided epsilon (for parity tracing) or NULL
+ * Increments *step_idx when advance != 0. */
+int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, int* step_idx, float* hist,
+                          float guidance_scale, int B, int h, int w, float* eps_out, int advance, bc_stream stream);
+
+/* Layout helpers at the nn.Module boundary (NCHW <-> token-major NHWC, fp32/fp16). */
+int bc_nchw_to_nhwc_f16(const void* src, int src_is_f32, int B, int C, int HW, int Cpad, bc_half* dst, bc_stream stream);
+int bc_nhwc_to_nchw(const bc_half* src, int B, int C, int HW, int ldsrc, void* dst, int dst_is_f32, bc_stream stream);
+/* Concatenate a learned token in front of patch tokens and add position embeddings (DINOv2 embeddings). */
+int bc_add_cls_pos(const bc_half* patches, const float* cls, const float* pos, int B, int T, int D, bc_half* out,
+                   bc_stream stream);
+/* im2col for the DINOv2 14x14/s14 patch embedding: pixels fp32 [B][3][H][W] -> [B*gh*gw][Kpad] fp16 (c,ky,kx order). */
+int bc_patchify(const float* pixels, int B, int H, int W, int patch, int Kpad, bc_half* out, bc_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * hipGraph helpers: capture everything enqueued on `stream` between begin/end, replay with bc_graph_launch.
+ * --------------------------------------------------------------------------------------------------------------- */
+int bc_graph_begin(bc_stream stream);
+int bc_graph_end(bc_stream stream, void** graph_exec_out);
+int bc_graph_launch(void* graph_exec, bc_stream stream);
+int bc_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on an arbitrary stream (torch.cuda.Event only sees torch's current stream). */
+int bc_event_create(void** ev);
+int bc_event_record(void* ev, bc_stream stream);
+int bc_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int bc_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

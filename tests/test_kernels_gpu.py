@@ -1,0 +1,360 @@
+"""Kernel-level parity on MI355X: every C-ABI entry point against a plain PyTorch fp32 statement of the same op
+(computed on CPU from the SAME fp16-rounded inputs).  Tolerances: fp16 output rounding (rel 1e-3) + fp32 accumulation
+order; attention 2e-3 abs on O(1) outputs."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import g  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rec():
+    from blobctrl_amd.launch import Recorder
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    r = Recorder(torch.device("cuda:0"))
+    return r
+
+
+def run(rec, fn):
+    seg = rec.begin("test")
+    out = fn()
+    seg.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out
+
+
+def h(x):
+    return x.half().cuda()
+
+
+def close(a, b, rtol=2e-3, atol=None, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    if atol is None:
+        atol = 2e-3 * max(1.0, float(b.abs().max()))
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4e} (atol {atol:.2e})"
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 320, 320), (154, 320, 768), (2, 1280, 320), (4096, 640, 640),
+                                    (33, 8, 8), (130, 72, 200)])
+def test_gemm_dense_bias(rec, M, N, K):
+    from blobctrl_amd import _lib
+    A, W, b = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N)
+    out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda()))
+    ref = A.half().float() @ W.half().float().t() + b
+    close(out, ref, what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu"])
+def test_gemm_act_residual_colscale_alpha(rec, act):
+    from blobctrl_amd import _lib
+    M, N, K = 300, 192, 128
+    A, W, b, R, cs = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N), g(4, M, N), g(5, N)
+    tab = torch.tensor([0.0, 0.7, 1.3]).cuda()
+    idx = torch.tensor([1], dtype=torch.int32).cuda()
+    out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(),
+                                    act=_lib.ACT_GELU if act == "gelu" else _lib.ACT_SILU, colscale=cs.cuda(), alpha=0.5,
+                                    alpha_dev=tab, alpha_idx=idx, R=h(R), ldr=N))
+    v = A.half().float() @ W.half().float().t() + b
+    v = F.gelu(v) if act == "gelu" else F.silu(v)
+    ref = v * cs * 0.5 * 0.7 + R.half().float()
+    close(out, ref, what="epilogue chain")
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(256, 1280, 11520, 6), (128, 320, 1280, 4), (70, 64, 640, 3)])
+def test_gemm_splitk(rec, M, N, K, sk):
+    A, W, b, R = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N), g(4, M, N)
+    out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), R=h(R), ldr=N,
+                                    splitk=sk))
+    ref = A.half().float() @ W.half().float().t() + b + R.half().float()
+    close(out, ref, what="splitk")
+
+
+@pytest.mark.parametrize("C1,C2,N", [(8, 16, 24), (320, 640, 320), (72, 56, 100)])
+def test_gemm_concat_sources(rec, C1, C2, N):
+    M = 260
+    A1, A2, W = g(1, M, C1), g(2, M, C2), g(3, N, C1 + C2) / math.sqrt(C1 + C2)
+    out = run(rec, lambda: rec.gemm(A=h(A1), A2=h(A2), C1=C1, lda=C1, lda2=C2, W=h(W), M=M, N=N, K=C1 + C2,
+                                    out=rec.empty(M, N)))
+    ref = torch.cat([A1, A2], 1).half().float() @ W.half().float().t()
+    close(out, ref, what="concat")
+
+
+def test_gemm_transposed_and_f32_out(rec):
+    from blobctrl_amd import _lib
+    B, T, N, K = 2, 77, 80, 64
+    A, W = g(1, B * T, K), g(2, N, K) / math.sqrt(K)
+    ldvt = 128
+    vt = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=B * T, N=N, K=K, out=rec.zeros(B, N, ldvt), out_mode=_lib.OUT_F16_T,
+                                   ldc=ldvt, rows_per_batch=T))
+    ref = (A.half().float() @ W.half().float().t()).view(B, T, N).transpose(1, 2)
+    close(vt[:, :, :T], ref, what="transposed")
+    assert float(vt[:, :, T:].abs().max()) == 0.0
+    o32 = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=B * T, N=N, K=K, out=rec.empty(B * T, N, dtype=torch.float32),
+                                    out_mode=_lib.OUT_F32))
+    assert o32.dtype == torch.float32
+    close(o32, A.half().float() @ W.half().float().t(), rtol=1e-4, atol=1e-4, what="f32 out")
+
+
+@pytest.mark.parametrize("C", [8, 40, 320])
+def test_gemm_geglu(rec, C):
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import interleave_geglu
+    M = 200
+    A, W, b = g(1, M, C), g(2, 8 * C, C) / math.sqrt(C), g(3, 8 * C)
+    wi, bi = interleave_geglu(W, b)
+    out = run(rec, lambda: rec.gemm(A=h(A), W=h(wi), M=M, N=8 * C, K=C, out=rec.empty(M, 4 * C), bias=bi.cuda(),
+                                    act=_lib.ACT_GEGLU))
+    hg = A.half().float() @ W.half().float().t() + b
+    val, gate = hg.chunk(2, -1)
+    close(out, val * F.gelu(gate), what="geglu")
+    out2 = run(rec, lambda: rec.gemm(A=h(A), W=h(wi), M=M, N=8 * C, K=C, out=rec.empty(M, 4 * C), bias=bi.cuda(),
+                                     act=_lib.ACT_GEGLU, splitk=2)) if C >= 128 else out
+    close(out2, val * F.gelu(gate), what="geglu splitk")
+
+
+# ---------------------------------------------------------------------------------------------------- conv
+def nhwc(x):      # NCHW fp32 -> token-major fp16 on device
+    B, Cc, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B, H * W, Cc).half().cuda().contiguous()
+
+
+def from_nhwc(t, B, H, W):
+    return t.float().cpu().view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", [(2, 8, 16, 8, 16, 1), (1, 64, 320, 16, 32, 1), (2, 320, 320, 16, 32, 2),
+                                                   (1, 24, 40, 7, 9, 1), (1, 24, 40, 7, 9, 2), (2, 128, 4, 8, 16, 1)])
+def test_conv3x3(rec, B, Cin, Cout, H, W, stride):
+    from blobctrl_amd.weights import pack_conv3x3
+    x, w, b = g(1, B, Cin, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=B * Ho * Wo, N=Cout, K=9 * Cin,
+                                    out=rec.empty(B, Ho * Wo, Cout), bias=b.cuda(),
+                                    conv=dict(Cin=Cin, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride)))
+    ref = F.conv2d(x.half().float(), w.half().float(), b, stride=stride, padding=1)
+    close(from_nhwc(out, B, Ho, Wo), ref, what="conv3x3")
+
+
+def test_conv3x3_padded_input_channels(rec):
+    """conv_in: 5 real channels padded to 8 (UNet) - padded lanes carry zeros on both operands."""
+    from blobctrl_amd.weights import pack_conv3x3
+    B, Cin, Cout, H, W = 2, 5, 32, 8, 16
+    x, w, b = g(1, B, Cin, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(45), g(3, Cout)
+    xp = torch.zeros(B, 8, H, W)
+    xp[:, :Cin] = x
+    out = run(rec, lambda: rec.gemm(A=nhwc(xp), W=h(pack_conv3x3(w)), M=B * H * W, N=Cout, K=72,
+                                    out=rec.empty(B, H * W, Cout), bias=b.cuda(),
+                                    conv=dict(Cin=8, Hin=H, Win=W, Hout=H, Wout=W)))
+    close(from_nhwc(out, B, H, W), F.conv2d(x.half().float(), w.half().float(), b, padding=1), what="conv_in")
+
+
+@pytest.mark.parametrize("size", [None, (9, 13)])
+def test_conv3x3_fused_upsample(rec, size):
+    from blobctrl_amd.weights import pack_conv3x3
+    B, Cc, H, W = 2, 64, 4, 8
+    x, w, b = g(1, B, Cc, H, W), g(2, Cc, Cc, 3, 3) / math.sqrt(9 * Cc), g(3, Cc)
+    Hv, Wv = size if size else (2 * H, 2 * W)
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=B * Hv * Wv, N=Cc, K=9 * Cc,
+                                    out=rec.empty(B, Hv * Wv, Cc), bias=b.cuda(),
+                                    conv=dict(Cin=Cc, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hv, Wout=Wv)))
+    up = F.interpolate(x.half().float(), size=(Hv, Wv), mode="nearest")
+    close(from_nhwc(out, B, Hv, Wv), F.conv2d(up, w.half().float(), b, padding=1), what="upsample conv")
+
+
+@pytest.mark.parametrize("H,W", [(8, 16), (8, 8)])
+def test_conv_rowvec_residual_and_blobnet_right_half(rec, H, W):
+    """conv1 (+time embedding row vector) and conv2 (+shortcut residual, + BlobNet residual on the right square, broadcast
+    over the CFG halves: unet_2d_blocks.py:1303-1307 with `b % Bblob`)."""
+    from blobctrl_amd.weights import pack_conv3x3
+    B, Bb, Cc = 4, 2, 64
+    x, w, b = g(1, B, Cc, H, W), g(2, Cc, Cc, 3, 3) / math.sqrt(9 * Cc), g(3, Cc)
+    temb, R, R2 = g(4, B, 3 * Cc), g(5, B, Cc, H, W), g(6, Bb, Cc, H, W)
+    xmin = 0 if H == W else W - H
+    dtemb = h(temb)
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=B * H * W, N=Cc, K=9 * Cc,
+                                    out=rec.empty(B, H * W, Cc), bias=b.cuda(),
+                                    conv=dict(Cin=Cc, Hin=H, Win=W, Hout=H, Wout=W),
+                                    rowvec=dtemb.data_ptr() + Cc * 2, ld_rowvec=3 * Cc, R=nhwc(R), ldr=Cc,
+                                    R2=nhwc(R2), ldr2=Cc, r2_xmin=xmin, r2_bmod=Bb, out_w=W))
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=1) + temb.half().float()[:, Cc:2 * Cc, None, None]
+    ref = ref + R.half().float()
+    add = R2.half().float().repeat(2, 1, 1, 1)
+    ref[..., xmin:] = ref[..., xmin:] + add[..., xmin:]
+    close(from_nhwc(out, B, H, W), ref, what="conv epilogue")
+
+
+# ---------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,C1,C2,HW,G,eps,silu", [(2, 320, 0, 512, 32, 1e-5, True), (2, 1280, 640, 128, 32, 1e-5, True),
+                                                   (1, 16, 0, 100, 4, 1e-6, False), (2, 32, 16, 37, 4, 1e-5, True),
+                                                   (1, 640, 320, 2048, 32, 1e-5, True)])
+def test_groupnorm(rec, B, C1, C2, HW, G, eps, silu):
+    Cc = C1 + C2
+    x = g(1, B, HW, Cc) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * g(2, Cc), 0.1 * g(3, Cc)
+    x1 = x[..., :C1].contiguous()
+    x2 = x[..., C1:].contiguous() if C2 else None
+    out = run(rec, lambda: rec.groupnorm(h(x1), C1, h(x2) if C2 else None, C2, B, HW, G, eps, gamma.cuda(), beta.cuda(), silu))
+    xr = x.half().float().permute(0, 2, 1)
+    ref = F.group_norm(xr, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    close(out, ref.permute(0, 2, 1), what="groupnorm")
+
+
+@pytest.mark.parametrize("rows,Cc", [(100, 320), (77, 640), (513, 1280), (9, 64), (5, 16)])
+def test_layernorm(rec, rows, Cc):
+    x, gamma, beta = g(1, rows, Cc) * 3 + 1, 1 + 0.1 * g(2, Cc), 0.1 * g(3, Cc)
+    out = run(rec, lambda: rec.layernorm(h(x), rows, Cc, gamma.cuda(), beta.cuda(), 1e-5))
+    close(out, F.layer_norm(x.half().float(), (Cc,), gamma, beta, 1e-5), what="layernorm")
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,heads,d,Nq,Nkv", [(2, 8, 40, 512, 512), (1, 8, 80, 256, 256), (2, 8, 160, 128, 128),
+                                              (2, 8, 40, 300, 77), (1, 8, 160, 128, 77), (2, 4, 64, 257, 257),
+                                              (2, 2, 8, 128, 128), (1, 2, 16, 32, 7), (1, 2, 32, 8, 8), (1, 8, 80, 200, 77)])
+def test_attention(rec, B, heads, d, Nq, Nkv):
+    Cc = heads * d
+    q, k, v = g(1, B, Nq, Cc), g(2, B, Nkv, Cc), g(3, B, Nkv, Cc)
+    ldvt = (Nkv + 63) // 64 * 64
+    vt = torch.zeros(B, Cc, ldvt, dtype=torch.float16)
+    vt[:, :, :Nkv] = v.half().transpose(1, 2)
+    scale = d ** -0.5
+    out = run(rec, lambda: rec.attention(h(q), h(k), vt.cuda(), rec.empty(B, Nq, Cc), B, heads, d, Nq, Nkv, Cc, Cc, ldvt, Cc,
+                                         Nq * Cc, Nkv * Cc, Cc * ldvt, Nq * Cc, scale))
+    qf = q.half().float().view(B, Nq, heads, d).transpose(1, 2)
+    kf = k.half().float().view(B, Nkv, heads, d).transpose(1, 2)
+    vf = v.half().float().view(B, Nkv, heads, d).transpose(1, 2)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf
+    ref = ref.transpose(1, 2).reshape(B, Nq, Cc)
+    close(out, ref, rtol=2e-3, atol=3e-3, what=f"attention d={d} Nq={Nq} Nkv={Nkv}")
+
+
+def test_attention_online_softmax_rescale(rec):
+    """Force the running-max rescale: a late key tile carries a much larger score than the early ones."""
+    B, heads, d, N = 1, 2, 40, 256
+    Cc = heads * d
+    q, k, v = g(1, B, N, Cc), g(2, B, N, Cc), g(3, B, N, Cc)
+    k[:, 200] = q[:, 10] * 4.0          # spike: query 10 suddenly matches key 200 (third tile)
+    ldvt = N
+    vt = v.half().transpose(1, 2).contiguous()
+    out = run(rec, lambda: rec.attention(h(q), h(k), vt.cuda(), rec.empty(B, N, Cc), B, heads, d, N, N, Cc, Cc, ldvt, Cc,
+                                         N * Cc, N * Cc, Cc * ldvt, N * Cc, d ** -0.5))
+    qf = q.half().float().view(B, N, heads, d).transpose(1, 2)
+    kf = k.half().float().view(B, N, heads, d).transpose(1, 2)
+    vf = v.half().float().view(B, N, heads, d).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, N, Cc)
+    close(out, ref, rtol=2e-3, atol=3e-3, what="attention rescale")
+
+
+# ---------------------------------------------------------------------------------------------------- blob maths / glue
+def test_splat_against_reference_fixtures(golden_dir):
+    from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
+    z = np.load(os.path.join(golden_dir, "splat.npz"))
+    meta = json.loads(str(z["meta"]))
+    for i, m in enumerate(meta):
+        blob = blob_dict_from_ellipse(m["ellipse"], m["W"], m["H"])
+        s = splat_features(**blob, score_size=(m["h"], m["w"]), return_d_score=True).cpu().numpy()
+        assert s.dtype == np.float64 and s.shape == z[f"score_{i}"].shape
+        np.testing.assert_allclose(s, z[f"score_{i}"], rtol=1e-9, atol=1e-12)
+    blob = blob_dict_from_ellipse(meta[0]["ellipse"], 512, 512)
+    blob["sizes"] = torch.tensor([[0.2]])
+    s = splat_features(**blob, score_size=(64, 64), return_d_score=True).cpu().numpy()
+    np.testing.assert_allclose(s, z["score_absent"], rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        splat_features(**blob, score_size=64, return_d_score=True)
+
+
+def test_assemble_matches_construct_blobnet_input(rec):
+    from oracle.pipeline import construct_input
+    B, hh, ww, Fd = 2, 8, 8, 9
+    lat, img, sc, feat = g(1, B, 4, hh, ww), g(2, 1, 4, hh, ww), g(3, 1, 1, hh, ww).abs(), g(4, 1, 1, Fd)
+    Cpad = 16
+    X = rec.zeros(2 * B, hh * 2 * ww, Cpad)
+    dl, di, ds, df = lat.cuda(), img.cuda(), sc.cuda(), feat.cuda()
+    run(rec, lambda: rec.call("bc_assemble_input", dl.data_ptr(), B, di.data_ptr(), ds.data_ptr(), df.data_ptr(), 1, Fd,
+                              2 * B, hh, ww, Cpad, X.data_ptr()))
+    lmi = torch.cat([lat] * 2)
+    feats = torch.einsum("nmhw,nmc->nchw", sc.repeat(2 * B, 1, 1, 1), feat.repeat(2 * B, 1, 1))
+    ref = construct_input(lmi, sc.repeat(2 * B, 1, 1, 1), img.repeat(2 * B, 1, 1, 1), feats)
+    got = from_nhwc(X, 2 * B, hh, 2 * ww)
+    close(got[:, :4 + 1 + Fd], ref, rtol=1e-3, atol=2e-3, what="assemble")
+    assert float(got[:, 4 + 1 + Fd:].abs().max()) == 0.0
+
+
+def test_timestep_embedding(rec):
+    from oracle.nets import timestep_embedding
+    for t in (999.0, 981.0, 500.0, 1.0):
+        out = rec.empty(2, 320)
+        run(rec, lambda: rec.call("bc_timestep_embedding", None, None, t, 2, 320, out.data_ptr()))
+        ref = timestep_embedding(torch.tensor([t, t]), 320)
+        close(out, ref, rtol=0, atol=2e-3, what=f"temb t={t}")
+
+
+@pytest.mark.parametrize("kind,n", [("unipc", 6), ("ddim", 5)])
+def test_cfg_scheduler_step_matches_reference_trajectory(rec, golden_dir, kind, n):
+    from blobctrl_amd.schedulers import DDIMTable, UniPCTable
+    from oracle.schedulers import DDIMOracle, UniPCOracle
+    B, hh, ww = 1, 8, 8
+    tab = (UniPCTable() if kind == "unipc" else DDIMTable()).set_timesteps(n)
+    orc = UniPCOracle() if kind == "unipc" else DDIMOracle()
+    orc.set_timesteps(n)
+    x = g(21, B, 4, hh, ww)
+    lat = x.clone().cuda()
+    coef = tab.table().cuda()
+    idx = torch.zeros(1, dtype=torch.int32).cuda()
+    hist = torch.zeros(3, B * 4 * hh * ww).cuda()
+    eg = torch.zeros(B, 4, hh, ww).cuda()
+    lib = rec.lib
+    for i in range(n):
+        eu, ec = g(200 + i, B, 4, hh, ww), g(300 + i, B, 4, hh, ww)
+        full = torch.zeros(2 * B, hh, 2 * ww, 4)
+        full[:B, :, ww:, :] = eu.permute(0, 2, 3, 1)
+        full[B:, :, ww:, :] = ec.permute(0, 2, 3, 1)
+        full[:, :, :ww, :] = 123.0                                    # left half must be ignored (pipe:1092-1093)
+        fd = full.cuda()
+        rc = lib.bc_cfg_scheduler_step(fd.data_ptr(), lat.data_ptr(), coef.data_ptr(), idx.data_ptr(), hist.data_ptr(), 7.5,
+                                       B, hh, ww, eg.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        e = eu + 7.5 * (ec - eu)
+        x = orc.step(e, x)
+        torch.cuda.synchronize()
+        close(eg, e, rtol=1e-5, atol=1e-5, what="cfg")
+        close(lat, x, rtol=2e-5, atol=2e-5 * float(x.abs().max()), what=f"{kind} step {i}")
+    assert int(idx.item()) == n
+
+
+def test_layout_roundtrip(rec):
+    B, Cc, HW = 2, 5, 24
+    x = g(1, B, Cc, HW)
+    lib = rec.lib
+    s = torch.cuda.current_stream().cuda_stream
+    xd = x.cuda()
+    t = torch.empty(B, HW, 8, dtype=torch.float16, device="cuda")
+    assert lib.bc_nchw_to_nhwc_f16(xd.data_ptr(), 1, B, Cc, HW, 8, t.data_ptr(), s) == 0
+    back = torch.empty(B, Cc, HW, dtype=torch.float32, device="cuda")
+    assert lib.bc_nhwc_to_nchw(t.data_ptr(), B, Cc, HW, 8, back.data_ptr(), 1, s) == 0
+    torch.cuda.synchronize()
+    close(back, x.half().float(), rtol=0, atol=0, what="layout roundtrip")
+    assert float(t[..., Cc:].abs().max()) == 0.0
+
+
+def test_bad_arguments_fail_loudly(rec):
+    from blobctrl_amd import _lib
+    with pytest.raises(_lib.BlobCtrlHipError):
+        run(rec, lambda: rec.gemm(A=h(g(1, 8, 12)), W=h(g(2, 8, 12)), M=8, N=8, K=12, out=rec.empty(8, 8)))   # K % 8
+    with pytest.raises(_lib.BlobCtrlHipError):
+        run(rec, lambda: rec.attention(h(g(1, 1, 8, 24)), h(g(2, 1, 8, 24)), h(g(3, 1, 24, 64)), rec.empty(1, 8, 24), 1, 2, 12,
+                                       8, 8, 24, 24, 64, 24, 192, 192, 24 * 64, 192, 1.0))                       # d = 12
