@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the BlobCtrl denoising hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+One bench "step" = ONE complete 512x512 edit of BASELINE.json configs[1]: batch 1, 50 scheduler steps, each step =
+BlobNet (batch 1) + patched UNet (CFG batch 2) + crop/CFG/scheduler update, hipGraph-replayed, inputs resident in HBM.
+metric = edits/s over all ranks (weak scaling: every rank runs its own K edits, no data-path collective).
+Also emits `roofline` for the dominant kernel (HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle,
+one denoise step of the same workload on the host cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def full_configs():
+    from blobctrl_amd.engine import TrunkConfig
+    u = TrunkConfig(in_channels=5, block_out_channels=(320, 640, 1280, 1280), num_heads=8, norm_num_groups=32,
+                    cross_attention_dim=768, out_channels=4, is_blobnet=False)
+    b = TrunkConfig(in_channels=1029, block_out_channels=(320, 640, 1280, 1280), num_heads=8, norm_num_groups=32,
+                    cross_attention_dim=None, out_channels=0, is_blobnet=True)
+    return u, b
+
+
+def synth_weights():
+    from blobctrl_amd import synth
+    us = synth.trunk_param_shapes(5, (320, 640, 1280, 1280), 2, 768, 4, blobnet=False)
+    bs = synth.trunk_param_shapes(1029, (320, 640, 1280, 1280), 2, None, None, blobnet=True)
+    return synth.synth_state_dict(us, 1234), synth.synth_state_dict(bs, 1235)
+
+
+def synth_inputs(h, w, T=77, ctx=768, feat=1024):
+    """SURVEY 8d synthetic inputs: seeded latents / prompt embeddings / DINO vector, move_hat blob scaled to the canvas."""
+    import numpy as np
+    from blobctrl_amd.splat import blob_dict_from_ellipse
+
+    def g(seed, *shape):
+        return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
+    s = (8 * w) / 512.0
+    ell = [[361.1067 * s, 367.8526 * s], [85.4812 * s, 103.6543 * s], 87.3739]
+    return dict(fg=g(1, 1, 4, h, w) * 0.18215 * 5, bg=g(2, 1, 4, h, w) * 0.18215 * 5, prompt=g(3, 2, T, ctx),
+                dino=g(4, 1, 1, feat), latents=g(1248464818 % (2 ** 31), 1, 4, h, w),
+                blob=blob_dict_from_ellipse(ell, 8 * w, 8 * h))
+
+
+def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler):
+    """The CPU oracle (oracle/, kind 'port') on ONE denoise step of the same workload, all host cores."""
+    from oracle import blob_splat, pipeline as o_pipe
+    from oracle.nets import NetConfig
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ucfg = NetConfig(in_channels=5, cross_attention_dim=768)
+    bcfg = NetConfig(in_channels=1029, cross_attention_dim=None)
+    b = inp["blob"]
+    score = torch.from_numpy(blob_splat.splat_scores(float(b["xs"]), float(b["ys"]), b["covs"][0, 0].numpy(), 1.0, h, w)).float()
+    B2 = 2
+    fg, bg = inp["fg"].repeat(B2, 1, 1, 1), inp["bg"].repeat(B2, 1, 1, 1)
+    bg_s, fg_s = score.unbind(dim=1)
+    bg_s, fg_s = bg_s.unsqueeze(1).repeat(B2, 1, 1, 1), fg_s.unsqueeze(1).repeat(B2, 1, 1, 1)
+    feats = torch.einsum("nmhw,nmc->nchw", fg_s, inp["dino"].repeat(B2, 1, 1)).contiguous()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        eps = o_pipe.noise_pred_step(usd, ucfg, bsd, bcfg, inp["latents"], torch.tensor(999), inp["prompt"], fg, bg, fg_s, bg_s,
+                                     feats, 1.0, 7.5)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / (dt * steps), unit="edits/s", cores=cores, kind="port",
+                sample=f"1 of {steps} denoise steps (BlobNet + UNet, CFG batch 2, fp32, {8*h}x{8*w}) = {dt:.2f} s, "
+                       f"extrapolated x{steps}"), eps
+
+
+def roofline(pipe, plan):
+    """HIP-event time every launch of one BlobNet-active step on the launch stream; report the dominant kernel."""
+    s = pipe.stream.cuda_stream
+    with torch.cuda.stream(pipe.stream):
+        plan.step_idx.zero_()
+    g = plan.step_active.graph
+    plan.step_active.graph = None
+    try:
+        plan.step_active.run(s)                  # warm (eager)
+        with torch.cuda.stream(pipe.stream):
+            plan.step_idx.zero_()
+        timed = plan.step_active.run_timed(s)
+    finally:
+        plan.step_active.graph = g
+    pipe.stream.synchronize()
+    by = {}
+    for m, ms in timed:
+        v = m["variant"] or m["kind"]
+        a = by.setdefault(v, dict(ms=0.0, flops=0, n=0))
+        a["ms"] += ms
+        a["flops"] += m["flops"]
+        a["n"] += 1
+    total_ms = sum(a["ms"] for a in by.values())
+    cand = {k: a for k, a in by.items() if a["flops"] > 0 and "+splitk" not in k}
+    dom = max(cand, key=lambda k: cand[k]["ms"])
+    a = cand[dom]
+    achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
+             for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
+    return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=None, launches_per_step=a["n"],
+                avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
+                step_ms_event_sum=round(total_ms, 3)), table
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed edits per rank (one edit = 50 denoise steps)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--scheduler", default="ddim", choices=["ddim", "unipc"])
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
+    args = ap.parse_args()
+
+    from blobctrl_amd import dist as bdist
+    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.splat import splat_features
+    from blobctrl_amd.weights import PackedTrunk
+    import torch.distributed as tdist
+
+    rank, world, local = bdist.init_from_env()
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    ucfg, bcfg = full_configs()
+    h = w = args.res // 8
+    state = {}
+
+    def build_unet():
+        state["usd"], state["bsd"] = synth_weights()
+        return PackedTrunk(state["usd"], dev, ucfg.block_out_channels)
+
+    def build_blob():
+        return PackedTrunk(state["bsd"], dev, bcfg.block_out_channels)
+
+    t0 = time.perf_counter()
+    pw_u = bdist.broadcast_packed(build_unet, dev)          # rank 0 packs, RCCL broadcast over xGMI to the others
+    pw_b = bdist.broadcast_packed(build_blob, dev)
+    t_weights = time.perf_counter() - t0
+    pipe = StableDiffusionBlobNetPipeline(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=args.scheduler)
+    inp = synth_inputs(h, w)
+    inp_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}     # inputs resident in HBM
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device=str(dev))   # HIP rasteriser
+
+    def one_edit(seed_off=0):
+        lat = inp_dev["latents"] if seed_off == 0 else torch.roll(inp_dev["latents"], seed_off, -1)
+        return pipe(inp_dev["prompt"], inp_dev["fg"], inp_dev["bg"], score, inp_dev["dino"], num_inference_steps=args.denoise_steps,
+                    guidance_scale=7.5, latents=lat, blobnet_conditioning_scale=1.0,
+                    blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0)
+
+    for i in range(max(1, args.warmup)):
+        out = one_edit(i)
+    assert torch.isfinite(out).all(), "non-finite latents"
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_edit(rank * 1000 + i + 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    dt = bdist.barrier_max_seconds(time.perf_counter() - t0, dev)
+
+    plan = pipe.plan_for(1, h, w, 77, 768, args.denoise_steps)
+    line = {
+        "metric": "512x512_50step_blobctrl_edits_per_sec" if args.res == 512 else f"{args.res}x{args.res}_edits_per_sec",
+        "value": world * args.steps / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: single {args.res}x{args.res} edit, batch 1 (CFG batch 2 for the UNet, "
+                               f"BlobNet shared across CFG halves), {args.denoise_steps} {args.scheduler.upper()} steps, "
+                               "guidance window [0,1], fp16 activations / fp32 accumulate, LoRA pre-merged, hipGraph-replayed steps",
+                   "edits_per_rank": args.steps, "denoise_steps": args.denoise_steps,
+                   "denoise_step_ms": dt / args.steps / args.denoise_steps * 1e3,
+                   "algorithmic_tflop_per_edit": plan.step_active.flops * args.denoise_steps / 1e12,
+                   "weights_s": round(t_weights, 2)},
+    }
+    if rank == 0 and not args.no_roofline:
+        rl, table = roofline(pipe, plan)
+        line["roofline"] = rl
+        if args.table:
+            print(json.dumps(table, indent=1), file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, _ = cpu_baseline(state["usd"], state["bsd"], inp, h, w, args.denoise_steps, args.scheduler)
+        line["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

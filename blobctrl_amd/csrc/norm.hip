@@ -17,64 +17,59 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// part[b][slab][g][2] = (sum, sumsq) over GN_PIX_PER_SLAB pixels x channels-of-group.
-// Threads sweep (pixel, 8-channel chunk) pairs; a chunk may straddle groups, so elements are binned individually
-// into LDS accumulators with ds_add_f32 after a per-thread run-length merge.
+// part[b][slab][c][2] = per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab.  No atomics: every
+// partial is produced by exactly one thread in a fixed order, so GroupNorm (and everything downstream) is bit-reproducible.
+// Lane l owns 8-channel chunk(s) l, l + blockDim, ...; adjacent lanes read adjacent 16-byte chunks (coalesced rows).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
-                                                         int C2, int HW, int G, float* __restrict__ part, int nslab) {
-    __shared__ float acc[GN_MAX_GROUPS * 2];
+                                                         int C2, int HW, float* __restrict__ part, int nslab) {
     const int b = blockIdx.y, slab = blockIdx.x;
     const int C = C1 + C2;
-    const int cpg = C / G;
     const int nchunk = C / 8;
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) acc[i] = 0.f;
-    __syncthreads();
     const int p0 = slab * GN_PIX_PER_SLAB;
     const int np = min(GN_PIX_PER_SLAB, HW - p0);
-    const int total = np * nchunk;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        int pl = idx / nchunk;
-        int ch = idx - pl * nchunk;
-        int c = ch * 8;
-        size_t pix = (size_t)b * HW + p0 + pl;
-        uint4 raw = (c < C1) ? bc_ld16(x1 + pix * C1 + c) : bc_ld16(x2 + pix * C2 + (c - C1));
-        const h16* v = reinterpret_cast<const h16*>(&raw);
-        int gcur = c / cpg;
-        float s = 0.f, q = 0.f;
+    float* dst = part + ((size_t)b * nslab + slab) * C * 2;
+    for (int ch = threadIdx.x; ch < nchunk; ch += blockDim.x) {
+        const int c = ch * 8;
+        const bool first = c < C1;
+        const h16* src = first ? x1 + ((size_t)b * HW + p0) * C1 + c : x2 + ((size_t)b * HW + p0) * C2 + (c - C1);
+        const int stride = first ? C1 : C2;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+#pragma unroll 4
+        for (int pl = 0; pl < np; ++pl) {
+            uint4 raw = bc_ld16(src + (size_t)pl * stride);
+            const h16* v = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j];
+                s[j] += f;
+                q[j] += f * f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int gj = (c + j) / cpg;
-            if (gj != gcur) {
-                atomicAdd(&acc[2 * gcur], s);
-                atomicAdd(&acc[2 * gcur + 1], q);
-                s = 0.f; q = 0.f; gcur = gj;
-            }
-            float f = (float)v[j];
-            s += f;
-            q += f * f;
+            dst[(c + j) * 2] = s[j];
+            dst[(c + j) * 2 + 1] = q[j];
         }
-        atomicAdd(&acc[2 * gcur], s);
-        atomicAdd(&acc[2 * gcur + 1], q);
     }
-    __syncthreads();
-    float* dst = part + ((size_t)b * nslab + slab) * G * 2;
-    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) dst[i] = acc[i];
 }
 
-// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]).  One block per (b), threads over channels; each thread
-// re-reduces its group's slab partials (tiny: nslab <= 288 values per group).
+// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]).  One block per batch image; wave w reduces groups
+// w, w + nw, ... over (slab, channel-in-group) pairs in a fixed order with fp64 accumulation.
 __global__ void gn_finalize_kernel(const float* __restrict__ part, int nslab, int HW, int C, int G, float eps,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ ab) {
     __shared__ float stat[GN_MAX_GROUPS * 2];
     const int b = blockIdx.x;
     const int cpg = C / G;
-    // wave w reduces groups w, w+nw, ...
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int g = wave; g < G; g += nw) {
         double s = 0.0, q = 0.0;
-        for (int sl = lane; sl < nslab; sl += 64) {
-            const float* src = part + (((size_t)b * nslab + sl) * G + g) * 2;
+        const int items = nslab * cpg;
+        for (int it = lane; it < items; it += 64) {
+            int sl = it / cpg, cj = it - sl * cpg;
+            const float* src = part + (((size_t)b * nslab + sl) * C + g * cpg + cj) * 2;
             s += src[0];
             q += src[1];
         }
@@ -193,8 +188,9 @@ extern "C" int bc_gn_stats(const bc_half* x1, int C1, const bc_half* x2, int C2,
     BC_CHECK_ARG(C1 % 8 == 0 && C2 % 8 == 0 && G > 0 && G <= GN_MAX_GROUPS && C % G == 0,
                  "bc_gn_stats: C1=%d C2=%d G=%d unsupported (channels %%8, groups<=%d)", C1, C2, G, GN_MAX_GROUPS);
     BC_CHECK_ARG(nslab == bc_ceil_div(HW, GN_PIX_PER_SLAB), "bc_gn_stats: nslab must be ceil(HW/%d)", GN_PIX_PER_SLAB);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
-                       reinterpret_cast<const h16*>(x2), C2, HW, G, part, nslab);
+    int threads = std::min(256, ((C / 8 + 63) / 64) * 64);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(threads), 0, stream, reinterpret_cast<const h16*>(x1), C1,
+                       reinterpret_cast<const h16*>(x2), C2, HW, part, nslab);
     BC_CHECK_LAUNCH();
     return 0;
 }

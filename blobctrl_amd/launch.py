@@ -27,6 +27,7 @@ class Segment:
         self.graph = None
         self.flops = 0          # algorithmic 2*MAC of the GEMM / attention launches recorded here
         self.kinds = {}
+        self.meta = []          # per call: dict(kind, flops, variant)
 
     def run(self, stream: int):
         if self.graph is not None:
@@ -47,6 +48,28 @@ class Segment:
             rc = lib.bc_graph_end(stream, C.byref(g))
         _lib.check(rc, "bc_graph_end")
         self.graph = g
+
+    def run_timed(self, stream: int):
+        """Eager replay with a HIP event pair around every launch (events are recorded on `stream`, the stream the
+        kernels run on).  Returns a list of (meta, milliseconds)."""
+        lib = _lib.load()
+        evs = []
+        for fn in self.calls:
+            a, b = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.bc_event_create(C.byref(a)), "bc_event_create")
+            _lib.check(lib.bc_event_create(C.byref(b)), "bc_event_create")
+            _lib.check(lib.bc_event_record(a, stream), "bc_event_record")
+            fn(stream)
+            _lib.check(lib.bc_event_record(b, stream), "bc_event_record")
+            evs.append((a, b))
+        out = []
+        for (a, b), m in zip(evs, self.meta):
+            ms = C.c_float()
+            _lib.check(lib.bc_event_elapsed_ms(a, b, C.byref(ms)), "bc_event_elapsed_ms")
+            out.append((m, ms.value))
+            lib.bc_event_destroy(a)
+            lib.bc_event_destroy(b)
+        return out
 
     def release(self):
         if self.graph is not None:
@@ -82,10 +105,11 @@ class Recorder:
         self.seg = Segment(name)
         return self.seg
 
-    def _push(self, fn, kind, flops=0):
+    def _push(self, fn, kind, flops=0, variant=""):
         self.seg.calls.append(fn)
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
+        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant))
 
     def slab(self, elems: int):
         """Shared split-K scratch: consumed by the reduce kernel that immediately follows on the same stream."""
@@ -103,10 +127,10 @@ class Recorder:
         bm, bn = (256, 64) if (((N + 127) // 128) * 128) / N > 1.10 else (128, 128)
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         nk = (K + 63) // 64
-        if tiles >= int(0.75 * self.num_cu) or nk < 8:
+        if tiles >= int(0.6 * self.num_cu) or nk < 8:
             return 1
-        want = (2 * self.num_cu + tiles - 1) // tiles
-        return max(1, min(want, nk // 4, 16))
+        want = (self.num_cu + tiles - 1) // tiles
+        return max(1, min(want, nk // 4, 8))
 
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
@@ -154,7 +178,9 @@ class Recorder:
                 _lib.check(rc, "bc_gemm")
 
         self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx))
-        self._push(fn, kind, 2 * M * N * K)
+        narrow = (((N + 127) // 128) * 128) / N > 1.10
+        variant = ("gemm_kernel<256,64,4,1>" if narrow else "gemm_kernel<128,128,2,2>") + ("+splitk" if sk > 1 else "")
+        self._push(fn, kind, 2 * M * N * K, variant)
         return out
 
     # ------------------------------------------------------------------ norms
@@ -162,7 +188,7 @@ class Recorder:
         lib = self.lib
         Cc = C1 + (C2 if x2 is not None else 0)
         nslab = (HW + 63) // 64
-        part = self.empty(B, nslab, G, 2, dtype=torch.float32)
+        part = self.empty(B, nslab, Cc, 2, dtype=torch.float32)
         ab = self.empty(B, Cc, 2, dtype=torch.float32)
         if out is None:
             out = self.empty(B, HW, Cc)
@@ -212,7 +238,7 @@ class Recorder:
                 _lib.check(rc, "bc_attention")
 
         self.keep.append((Q, K, Vt, out))
-        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d)
+        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d, f"attn_fwd_kernel<{d}>")
         return out
 
     # ------------------------------------------------------------------ glue

@@ -41,8 +41,11 @@ class StableDiffusionBlobNetPipeline:
         torch.cuda.set_device(self.device)
         _lib.load()
         self.unet_cfg, self.blob_cfg = unet_config, blobnet_config
-        self.unet_w = PackedTrunk(unet_state_dict, self.device, unet_config.block_out_channels)
-        self.blob_w = PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
+        # either reference-schema state dicts (packed here) or already-packed / broadcast replicas (dist.broadcast_packed)
+        self.unet_w = unet_state_dict if isinstance(unet_state_dict, PackedTrunk) else \
+            PackedTrunk(unet_state_dict, self.device, unet_config.block_out_channels)
+        self.blob_w = blobnet_state_dict if isinstance(blobnet_state_dict, PackedTrunk) else \
+            PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
         self.scheduler_kind = scheduler
         self.use_graphs = use_graphs
         self.stream = torch.cuda.Stream(device=self.device)
@@ -129,6 +132,8 @@ class StableDiffusionBlobNetPipeline:
         # warm-up run outside capture (module loading, attribute setting) then capture each segment once
         torch.cuda.synchronize(self.device)
         for seg in (P.step_active, P.step_inactive):
+            with torch.cuda.stream(self.stream):
+                P.step_idx.zero_()
             seg.run(s)
         self.stream.synchronize()
         for seg in (P.step_active, P.step_inactive):

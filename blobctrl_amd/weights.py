@@ -109,6 +109,61 @@ class PackedTrunk:
         self.temb_total = off
         self.h["temb_all.weight"] = torch.cat(temb_w, 0).half().to(device)
         self.f["temb_all.bias"] = torch.cat(temb_b, 0).to(device)
+        self._to_arenas()
+
+    # ---- arenas: all fp16 matrices live in ONE contiguous buffer, all fp32 vectors in another, so that a replica is
+    # ---- two RCCL broadcasts (blobctrl_amd/dist.py) and one allocation each; views are 256-byte aligned.
+    @staticmethod
+    def _layout(tensors, align_elems):
+        layout, off = [], 0
+        for k, t in tensors.items():
+            layout.append((k, tuple(t.shape), off))
+            off += (t.numel() + align_elems - 1) // align_elems * align_elems
+        return layout, off
+
+    def _to_arenas(self):
+        self.h_layout, hn = self._layout(self.h, 128)
+        self.f_layout, fn = self._layout(self.f, 64)
+        self.h_arena = torch.zeros(hn, dtype=torch.float16, device=self.device)
+        self.f_arena = torch.zeros(fn, dtype=torch.float32, device=self.device)
+        self._view(copy_from=(self.h, self.f))
+
+    def _view(self, copy_from=None):
+        h, f = {}, {}
+        for (k, shape, off) in self.h_layout:
+            n = 1
+            for d in shape:
+                n *= d
+            h[k] = self.h_arena[off:off + n].view(shape)
+            if copy_from is not None:
+                h[k].copy_(copy_from[0][k])
+        for (k, shape, off) in self.f_layout:
+            n = 1
+            for d in shape:
+                n *= d
+            f[k] = self.f_arena[off:off + n].view(shape)
+            if copy_from is not None:
+                f[k].copy_(copy_from[1][k])
+        self.h, self.f = h, f
+
+    def meta(self):
+        """Everything a replica needs besides the two arenas (small, picklable)."""
+        return dict(h_layout=self.h_layout, f_layout=self.f_layout, temb_slices=self.temb_slices,
+                    temb_total=self.temb_total, has_cross=self.has_cross, boc=self.boc,
+                    h_elems=self.h_arena.numel(), f_elems=self.f_arena.numel())
+
+    @classmethod
+    def from_meta(cls, meta, device):
+        """An EMPTY replica with the same layout (filled by an RCCL broadcast of the arenas)."""
+        self = cls.__new__(cls)
+        self.device = device
+        self.h_layout, self.f_layout = meta["h_layout"], meta["f_layout"]
+        self.temb_slices, self.temb_total = meta["temb_slices"], meta["temb_total"]
+        self.has_cross, self.boc = meta["has_cross"], meta["boc"]
+        self.h_arena = torch.zeros(meta["h_elems"], dtype=torch.float16, device=device)
+        self.f_arena = torch.zeros(meta["f_elems"], dtype=torch.float32, device=device)
+        self._view()
+        return self
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in list(self.h.values()) + list(self.f.values()))
+        return self.h_arena.numel() * 2 + self.f_arena.numel() * 4

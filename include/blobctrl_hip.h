@@ -90,7 +90,7 @@ int bc_sizeof_gemm(void);            /* sizeof(BcGemm), lets FFI bindings verify
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
  * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
  * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
- *   bc_gn_stats    : partial sums   part[B][nslab][G][2]
+ *   bc_gn_stats    : per-channel partial sums  part[B][nslab][C1+C2][2], nslab = ceil(HW/64)  (no atomics: bit-reproducible)
  *   bc_gn_finalize : per-channel affine  ab[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma)
  *   bc_gn_apply    : y[B][HW][C] = silu?( x*ab.x + ab.y )   (x = concat(x1, x2))
  * --------------------------------------------------------------------------------------------------------------- */
