@@ -99,6 +99,16 @@ def roofline(pipe, plan):
         a["flops"] += m["flops"]
         a["n"] += 1
     total_ms = sum(a["ms"] for a in by.values())
+    shapes = {}
+    for m, ms in timed:
+        key = (m["kind"], m["variant"], m["shape"])
+        a = shapes.setdefault(key, dict(ms=0.0, n=0, flops=0))
+        a["ms"] += ms
+        a["n"] += 1
+        a["flops"] += m["flops"]
+    detail = [dict(kind=k[0], variant=k[1], shape=k[2], launches=v["n"], ms=round(v["ms"], 4),
+                   tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
+              for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])][:40]
     cand = {k: a for k, a in by.items() if a["flops"] > 0 and "+splitk" not in k}
     dom = max(cand, key=lambda k: cand[k]["ms"])
     a = cand[dom]
@@ -108,7 +118,7 @@ def roofline(pipe, plan):
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=None, launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
-                step_ms_event_sum=round(total_ms, 3)), table
+                step_ms_event_sum=round(total_ms, 3)), dict(by_kernel=table, top_shapes=detail)
 
 
 def main():

@@ -29,7 +29,7 @@ class BcGemm(C.Structure):
         ("R", C.c_void_p), ("ldr", C.c_int),
         ("R2", C.c_void_p), ("ldr2", C.c_int), ("r2_xmin", C.c_int), ("r2_bmod", C.c_int), ("out_w", C.c_int),
         ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
-        ("splitk", C.c_int), ("slab", C.c_void_p),
+        ("splitk", C.c_int), ("slab", C.c_void_p), ("gn_part", C.c_void_p),
     ]
 
 
@@ -39,10 +39,10 @@ _SIGNATURES = {
     "bc_device_info": (C.c_int, [C.POINTER(C.c_int)]),
     "bc_gemm": (C.c_int, [C.POINTER(BcGemm), C.c_void_p]),
     "bc_sizeof_gemm": (C.c_int, []),
-    "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                              C.c_void_p]),
-    "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bc_gemm_tile_rows": (C.c_int, [C.c_int]),
+    "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bc_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p]),
     "bc_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,

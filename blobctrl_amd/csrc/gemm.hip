@@ -11,85 +11,11 @@
 //   * split-K writes fp32 slabs; bc_splitk_reduce applies the same epilogue.
 //
 // Reference call sites replaced: see include/blobctrl_hip.h (BcGemm).
-#include "bc_common.h"
+#include <stdlib.h>
+#include "gemm_common.h"
 
+using namespace bcg;
 namespace {
-
-constexpr int BK = 64;   // K-tile (elements); 128-byte LDS rows
-
-struct FastDiv {          // exact floor(n / d) for 0 <= n < 2^31
-    unsigned mul, shift, d;
-};
-
-inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    if (d == 0) d = 1;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;
-    f.mul = (unsigned)m;
-    f.shift = 31 + l;
-    f.d = d;
-    return f;
-}
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
-}
-
-struct GemmArgs {
-    BcGemm p;
-    FastDiv div_rpb;     // rows_per_batch
-    FastDiv div_outw;    // out_w
-    FastDiv div_wout;    // conv Wout
-    int nk;              // number of K tiles
-    int kt_per_split;
-    int n_out;           // output columns (N, or N/2 for GEGLU)
-    int fast_k;          // conv: Cin % BK == 0 ; dense: (C1 % BK == 0 or no A2)
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// One output element: everything after the accumulator (+bias +rowvec, activation) has been applied by the caller.
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, float v, int m, int n, float alpha) {
-    const BcGemm& p = g.p;
-    if (p.colscale) v *= p.colscale[n];
-    v *= alpha;
-    if (p.R) v += (float)reinterpret_cast<const h16*>(p.R)[(size_t)m * p.ldr + n];
-    int b = 0, pix = m;
-    if (p.R2 || p.out_mode == BC_OUT_F16_T) {
-        b = (int)fdiv((unsigned)m, g.div_rpb);
-        pix = m - b * (int)g.div_rpb.d;
-    }
-    if (p.R2) {
-        int y = (int)fdiv((unsigned)pix, g.div_outw);
-        int x = pix - y * (int)g.div_outw.d;
-        if (x >= p.r2_xmin) {
-            int bb = b % p.r2_bmod;
-            v += (float)reinterpret_cast<const h16*>(p.R2)[((size_t)bb * g.div_rpb.d + pix) * p.ldr2 + n];
-        }
-    }
-    if (p.out_mode == BC_OUT_F16) {
-        reinterpret_cast<h16*>(p.C)[(size_t)m * p.ldc + n] = (h16)v;
-    } else if (p.out_mode == BC_OUT_F32) {
-        reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
-    } else {
-        reinterpret_cast<h16*>(p.C)[((size_t)b * g.n_out + n) * p.ldc + pix] = (h16)v;
-    }
-}
-
-__device__ __forceinline__ float pre_act(const GemmArgs& g, float acc, int m, int ncol) {
-    const BcGemm& p = g.p;
-    float v = acc;
-    if (p.bias) v += p.bias[ncol];
-    if (p.rowvec) {
-        int b = (int)fdiv((unsigned)m, g.div_rpb);
-        v += (float)reinterpret_cast<const h16*>(p.rowvec)[(size_t)b * p.ld_rowvec + ncol];
-    }
-    return v;
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
@@ -264,70 +190,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
 
     // ------------------------------------------------------------------------------------------------ epilogue
-    // C layout of v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    const int wave_m0 = m0 + wm * (BM / WM);
-    const int wave_n0 = n0 + wn * (BN / WN);
-
-    if (p.splitk > 1) {
-        float* slab = p.slab + (size_t)split * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int n = wave_n0 + j * 32 + frow;
-                if (n >= p.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    if (m < p.M) slab[(size_t)m * p.N + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
-
-    if (p.act == BC_ACT_GEGLU) {
-        // wave spans 64 GEMM columns = [32 value | 32 gate]; TN == 2 by construction
-        static_assert(TN == 2 || true, "");
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j + 1 < TN; j += 2) {
-                int nv = wave_n0 + j * 32 + frow;          // value column (GEMM index)
-                int ng = nv + 32;                          // gate column
-                if (ng >= p.N) continue;
-                int nout = (nv >> 6) * 32 + frow;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    if (m >= p.M) continue;
-                    float v = pre_act(g, acc[i][j][r], m, nv);
-                    float gt = pre_act(g, acc[i][j + 1][r], m, ng);
-                    epilogue_store(g, v * bc_gelu_f(gt), m, nout, alpha);
-                }
-            }
-        }
-        return;
-    }
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = wave_n0 + j * 32 + frow;
-            if (n >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (m >= p.M) continue;
-                float v = pre_act(g, acc[i][j][r], m, n);
-                if (p.act == BC_ACT_GELU) v = bc_gelu_f(v);
-                else if (p.act == BC_ACT_SILU) v = bc_silu_f(v);
-                epilogue_store(g, v, m, n, alpha);
-            }
-        }
+    __syncthreads();                                   // operand stages are dead: reuse LDS as the fp32 output tile
+    float* tile = reinterpret_cast<float*>(smem);
+    acc_to_tile<TM, TN>(tile, BN, acc, wm * (BM / WM), wn * (BN / WN), frow, fhalf);
+    __syncthreads();
+    tile_epilogue_scalar<BM, BN, NT>(g, tile, m0, n0, split, tid);
 }
 
 // Sum split-K slabs and apply the epilogue.  One thread per output element, n fastest (coalesced slab reads).
@@ -378,6 +245,11 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int bc_gemm_tile_rows(int N) {
+    int n128 = bc_ceil_div(N, 128) * 128;
+    return ((double)n128 / N > 1.10) ? 256 : 128;
+}
 
 extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -441,9 +313,23 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
 
     // tile choice: 128x128 unless N would be padded by >10 % (N = 320 -> 5 x 64 columns)
     int n128 = bc_ceil_div(p.N, 128) * 128;
-    bool narrow = (double)n128 / p.N > 1.10;
-    int rc = narrow ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
-    if (rc) return rc;
+    g.narrow = (double)n128 / p.N > 1.10;
+    auto aligned16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    g.vec_epilogue = p.out_mode == BC_OUT_F16 && g.n_out % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
+                     (!p.R || (p.ldr % 8 == 0 && aligned16(p.R))) && (!p.R2 || (p.ldr2 % 8 == 0 && aligned16(p.R2)));
+    if (p.gn_part) {
+        int bm = g.narrow ? 256 : 128;
+        BC_CHECK_ARG(p.splitk == 1 && g.vec_epilogue && p.K % BK == 0 && p.rows_per_batch % bm == 0 && p.M % p.rows_per_batch == 0,
+                     "bc_gemm: fused GroupNorm partials need splitk==1, fp16 row-major output, K%%64==0 and rows_per_batch%%%d==0", bm);
+    }
+    static const bool force_generic = getenv("BC_GEMM_GENERIC") != nullptr;
+    int rc = force_generic ? -1 : bc_gemm_fast_try(g, stream);
+    if (rc > 0) return rc;
+    if (rc < 0) {
+        BC_CHECK_ARG(!p.gn_part, "bc_gemm: fused GroupNorm partials are only produced by the fast path");
+        rc = g.narrow ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
+        if (rc) return rc;
+    }
     if (p.splitk > 1) {
         long long total = (long long)p.M * g.n_out;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(bc_ceil_div(total, 256)), dim3(256), 0, stream, g);

@@ -1,0 +1,148 @@
+// Shared host/device pieces of the implicit-GEMM kernels (gemm.hip = generic kernel + dispatch, gemm_fast.hip = LDS-DMA kernel).
+#pragma once
+#include "bc_common.h"
+
+namespace bcg {
+
+
+constexpr int BK = 64;   // K-tile (elements); 128-byte LDS rows
+
+struct FastDiv {          // exact floor(n / d) for 0 <= n < 2^31
+    unsigned mul, shift, d;
+};
+
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    if (d == 0) d = 1;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;
+    f.mul = (unsigned)m;
+    f.shift = 31 + l;
+    f.d = d;
+    return f;
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
+}
+
+struct GemmArgs {
+    BcGemm p;
+    FastDiv div_rpb;     // rows_per_batch
+    FastDiv div_outw;    // out_w
+    FastDiv div_wout;    // conv Wout
+    int nk;              // number of K tiles
+    int kt_per_split;
+    int n_out;           // output columns (N, or N/2 for GEGLU)
+    int fast_k;          // conv: Cin % BK == 0 ; dense: (C1 % BK == 0 or no A2)
+    int narrow;          // 1: 256x64 tile (N padded by > 10 % on a 128-wide tile), 0: 128x128
+    int vec_epilogue;    // 1: LDS-staged 16-byte epilogue is legal (fp16 row-major output, widths % 8 == 0)
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// One output element: everything after the accumulator (+bias +rowvec, activation) has been applied by the caller.
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, float v, int m, int n, float alpha) {
+    const BcGemm& p = g.p;
+    if (p.colscale) v *= p.colscale[n];
+    v *= alpha;
+    if (p.R) v += (float)reinterpret_cast<const h16*>(p.R)[(size_t)m * p.ldr + n];
+    int b = 0, pix = m;
+    if (p.R2 || p.out_mode == BC_OUT_F16_T) {
+        b = (int)fdiv((unsigned)m, g.div_rpb);
+        pix = m - b * (int)g.div_rpb.d;
+    }
+    if (p.R2) {
+        int y = (int)fdiv((unsigned)pix, g.div_outw);
+        int x = pix - y * (int)g.div_outw.d;
+        if (x >= p.r2_xmin) {
+            int bb = b % p.r2_bmod;
+            v += (float)reinterpret_cast<const h16*>(p.R2)[((size_t)bb * g.div_rpb.d + pix) * p.ldr2 + n];
+        }
+    }
+    if (p.out_mode == BC_OUT_F16) {
+        reinterpret_cast<h16*>(p.C)[(size_t)m * p.ldc + n] = (h16)v;
+    } else if (p.out_mode == BC_OUT_F32) {
+        reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = v;
+    } else {
+        reinterpret_cast<h16*>(p.C)[((size_t)b * g.n_out + n) * p.ldc + pix] = (h16)v;
+    }
+}
+
+__device__ __forceinline__ float pre_act(const GemmArgs& g, float acc, int m, int ncol) {
+    const BcGemm& p = g.p;
+    float v = acc;
+    if (p.bias) v += p.bias[ncol];
+    if (p.rowvec) {
+        int b = (int)fdiv((unsigned)m, g.div_rpb);
+        v += (float)reinterpret_cast<const h16*>(p.rowvec)[(size_t)b * p.ld_rowvec + ncol];
+    }
+    return v;
+}
+
+
+// ---- epilogue helpers shared by both kernels -----------------------------------------------------------------
+// Accumulators are first parked RAW in LDS with compile-time register indices only (anything fancier inside the
+// unrolled register loops makes hipcc give up unrolling and demote the accumulator array to scratch memory), then a
+// plain per-element / per-chunk loop applies the epilogue with runtime indices.
+template <int TM, int TN>
+__device__ __forceinline__ void acc_to_tile(float* tile, int ts, const f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0,
+                                            int frow, int fhalf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * ts + wave_n0 + j * 32 + frow] = acc[i][j][r];
+}
+
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void tile_epilogue_scalar(const GemmArgs& g, const float* tile, int m0, int n0, int split,
+                                                     int tid) {
+    const BcGemm& p = g.p;
+    if (p.splitk > 1) {
+        float* slab = p.slab + (size_t)split * p.M * p.N;
+        for (int idx = tid; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.N) slab[(size_t)m * p.N + n] = tile[idx];
+        }
+        return;
+    }
+    float alpha = p.alpha;
+    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    if (p.act == BC_ACT_GEGLU) {
+        constexpr int BNO = BN / 2;
+        for (int idx = tid; idx < BM * BNO; idx += NT) {
+            const int row = idx / BNO, c = idx - row * BNO;
+            const int m = m0 + row;
+            const int cv = (c >> 5) * 64 + (c & 31);           // tile column of the value; gate is 32 further
+            const int nv = n0 + cv, ng = nv + 32;
+            if (m < p.M && ng < p.N) {
+                const float v = pre_act(g, tile[row * BN + cv], m, nv);
+                const float gt = pre_act(g, tile[row * BN + cv + 32], m, ng);
+                epilogue_store(g, v * bc_gelu_f(gt), m, n0 / 2 + c, alpha);
+            }
+        }
+        return;
+    }
+    for (int idx = tid; idx < BM * BN; idx += NT) {
+        const int row = idx / BN, col = idx - row * BN;
+        const int m = m0 + row, n = n0 + col;
+        if (m < p.M && n < p.N) {
+            float v = pre_act(g, tile[idx], m, n);
+            if (p.act == BC_ACT_GELU) v = bc_gelu_f(v);
+            else if (p.act == BC_ACT_SILU) v = bc_silu_f(v);
+            epilogue_store(g, v, m, n, alpha);
+        }
+    }
+}
+
+}  // namespace bcg
+
+// gemm_fast.hip: returns 0 when it launched the GEMM, -1 when the problem is outside its fast path, >0 on error.
+int bc_gemm_fast_try(const bcg::GemmArgs& g, hipStream_t stream);

@@ -20,25 +20,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 // part[b][slab][c][2] = per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab.  No atomics: every
 // partial is produced by exactly one thread in a fixed order, so GroupNorm (and everything downstream) is bit-reproducible.
 // Lane l owns 8-channel chunk(s) l, l + blockDim, ...; adjacent lanes read adjacent 16-byte chunks (coalesced rows).
-__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
-                                                         int C2, int HW, float* __restrict__ part, int nslab) {
+// (Only used for tensors whose producer could not emit the partials itself - see BcGemm.gn_part.)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x, int C, int HW, float* __restrict__ part,
+                                                         int nslab) {
     const int b = blockIdx.y, slab = blockIdx.x;
-    const int C = C1 + C2;
     const int nchunk = C / 8;
     const int p0 = slab * GN_PIX_PER_SLAB;
     const int np = min(GN_PIX_PER_SLAB, HW - p0);
     float* dst = part + ((size_t)b * nslab + slab) * C * 2;
     for (int ch = threadIdx.x; ch < nchunk; ch += blockDim.x) {
         const int c = ch * 8;
-        const bool first = c < C1;
-        const h16* src = first ? x1 + ((size_t)b * HW + p0) * C1 + c : x2 + ((size_t)b * HW + p0) * C2 + (c - C1);
-        const int stride = first ? C1 : C2;
+        const h16* src = x + ((size_t)b * HW + p0) * C + c;
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-#pragma unroll 4
+#pragma unroll 8
         for (int pl = 0; pl < np; ++pl) {
-            uint4 raw = bc_ld16(src + (size_t)pl * stride);
+            uint4 raw = bc_ld16(src + (size_t)pl * C);
             const h16* v = reinterpret_cast<const h16*>(&raw);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -55,23 +53,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x
     }
 }
 
-// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]).  One block per batch image; wave w reduces groups
-// w, w + nw, ... over (slab, channel-in-group) pairs in a fixed order with fp64 accumulation.
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int nslab, int HW, int C, int G, float eps,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ ab) {
+// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]) for the channel-concat of two sources, each with its own
+// per-channel partial buffer part_i[B][nslab_i][C_i][2].  One block per batch image; wave w reduces groups w, w + nw, ...
+// over (slab, channel-in-group) pairs in a fixed order with fp64 accumulation (deterministic).
+__global__ void gn_finalize_kernel(const float* __restrict__ part1, int nslab1, int C1, const float* __restrict__ part2,
+                                   int nslab2, int C2, int HW, int G, float eps, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ ab) {
     __shared__ float stat[GN_MAX_GROUPS * 2];
     const int b = blockIdx.x;
+    const int C = C1 + C2;
     const int cpg = C / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int g = wave; g < G; g += nw) {
         double s = 0.0, q = 0.0;
-        const int items = nslab * cpg;
-        for (int it = lane; it < items; it += 64) {
-            int sl = it / cpg, cj = it - sl * cpg;
-            const float* src = part + (((size_t)b * nslab + sl) * C + g * cpg + cj) * 2;
-            s += src[0];
-            q += src[1];
+        for (int cj = 0; cj < cpg; ++cj) {
+            const int c = g * cpg + cj;
+            const bool first = c < C1;
+            const float* base = first ? part1 + ((size_t)b * nslab1 * C1 + c) * 2 : part2 + ((size_t)b * nslab2 * C2 + (c - C1)) * 2;
+            const int ns = first ? nslab1 : nslab2;
+            const size_t stride = (size_t)(first ? C1 : C2) * 2;
+            for (int sl = lane; sl < ns; sl += 64) {
+                s += base[sl * stride];
+                q += base[sl * stride + 1];
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -96,17 +100,18 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nslab, in
     }
 }
 
+// y = silu?(x * a + b) over the concat of two sources; grid (chunks of one image, batch), 32-bit index maths only.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
-                                                         int C2, int HW, long long total_chunks,
+                                                         int C2, int HW, int nchunk, unsigned div_mul, unsigned div_shift,
                                                          const float* __restrict__ ab, int silu, h16* __restrict__ y) {
     const int C = C1 + C2;
-    const int nchunk = C / 8;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_chunks;
-         idx += (long long)gridDim.x * blockDim.x) {
-        long long pix = idx / nchunk;
-        int c = (int)(idx - pix * nchunk) * 8;
-        int b = (int)(pix / HW);
-        uint4 raw = (c < C1) ? bc_ld16(x1 + (size_t)pix * C1 + c) : bc_ld16(x2 + (size_t)pix * C2 + (c - C1));
+    const int b = blockIdx.y;
+    const unsigned total = (unsigned)HW * nchunk;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned pl = (unsigned)(((unsigned long long)idx * div_mul) >> div_shift);     // idx / nchunk
+        const int c = (int)(idx - pl * nchunk) * 8;
+        const size_t pix = (size_t)b * HW + pl;
+        uint4 raw = (c < C1) ? bc_ld16(x1 + pix * C1 + c) : bc_ld16(x2 + pix * C2 + (c - C1));
         const h16* v = reinterpret_cast<const h16*>(&raw);
         const float4* abp = reinterpret_cast<const float4*>(ab + ((size_t)b * C + c) * 2);
         uint4 outraw;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x
             o[2 * j] = (h16)r0;
             o[2 * j + 1] = (h16)r1;
         }
-        bc_st16(y + (size_t)pix * C + c, outraw);
+        bc_st16(y + pix * C + c, outraw);
     }
 }
 
@@ -179,27 +184,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ 
 
 }  // namespace
 
-extern "C" int bc_gn_stats(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW, int G, float* part,
-                           int nslab, bc_stream stream_) {
+extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, int nslab, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!x2) C2 = 0;
-    int C = C1 + C2;
-    BC_CHECK_ARG(x1 && part && B > 0 && HW > 0, "bc_gn_stats: bad args");
-    BC_CHECK_ARG(C1 % 8 == 0 && C2 % 8 == 0 && G > 0 && G <= GN_MAX_GROUPS && C % G == 0,
-                 "bc_gn_stats: C1=%d C2=%d G=%d unsupported (channels %%8, groups<=%d)", C1, C2, G, GN_MAX_GROUPS);
+    BC_CHECK_ARG(x && part && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "bc_gn_stats: bad args (C %% 8 == 0)");
     BC_CHECK_ARG(nslab == bc_ceil_div(HW, GN_PIX_PER_SLAB), "bc_gn_stats: nslab must be ceil(HW/%d)", GN_PIX_PER_SLAB);
     int threads = std::min(256, ((C / 8 + 63) / 64) * 64);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(threads), 0, stream, reinterpret_cast<const h16*>(x1), C1,
-                       reinterpret_cast<const h16*>(x2), C2, HW, part, nslab);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(threads), 0, stream, reinterpret_cast<const h16*>(x), C, HW, part,
+                       nslab);
     BC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bc_gn_finalize(const float* part, int nslab, int B, int HW, int C, int G, float eps, const float* gamma,
-                              const float* beta, float* ab, bc_stream stream_) {
+extern "C" int bc_gn_finalize(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2, int B, int HW,
+                              int G, float eps, const float* gamma, const float* beta, float* ab, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    BC_CHECK_ARG(part && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0, "bc_gn_finalize: bad args");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part, nslab, HW, C, G, eps, gamma, beta, ab);
+    if (!part2) { C2 = 0; nslab2 = 0; }
+    int C = C1 + C2;
+    BC_CHECK_ARG(part1 && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0 && nslab1 > 0,
+                 "bc_gn_finalize: bad args (groups <= %d, C %% G == 0)", GN_MAX_GROUPS);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
+                       gamma, beta, ab);
     BC_CHECK_LAUNCH();
     return 0;
 }
@@ -209,10 +213,16 @@ extern "C" int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2,
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!x2) C2 = 0;
     BC_CHECK_ARG(x1 && ab && y && C1 % 8 == 0 && C2 % 8 == 0, "bc_gn_apply: bad args");
-    long long total = (long long)B * HW * ((C1 + C2) / 8);
-    int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
-                       reinterpret_cast<const h16*>(x2), C2, HW, total, ab, silu, reinterpret_cast<h16*>(y));
+    int nchunk = (C1 + C2) / 8;
+    long long per_img = (long long)HW * nchunk;
+    BC_CHECK_ARG(per_img < (1ll << 31), "bc_gn_apply: image too large");
+    unsigned l = 0;
+    while ((1ull << l) < (unsigned)nchunk) ++l;
+    unsigned long long mul = ((1ull << (31 + l)) + nchunk - 1) / nchunk;
+    int blocks = (int)std::min<long long>((per_img + 255) / 256, 2048);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
+                       reinterpret_cast<const h16*>(x2), C2, HW, nchunk, (unsigned)mul, 31 + l, ab, silu,
+                       reinterpret_cast<h16*>(y));
     BC_CHECK_LAUNCH();
     return 0;
 }

@@ -83,7 +83,7 @@ class TrunkPlan:
         rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * x.C, out=out,
                  out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,
                  conv=dict(Cin=x.C, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
-                 bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, **kw)
+                 bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, want_gn=not out_f32, **kw)
         return Act(out, Cout, Hout, Wout)
 
     def dense(self, x_t, M, K, wname, N, bias=True, out=None, kind="linear", wkey=None, **kw):
@@ -160,7 +160,7 @@ class TrunkPlan:
         g = self.dense(ln, M, Cc, bp + "ff.net.0.proj", 8 * Cc, act=_lib.ACT_GEGLU, kind="ff")
         h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
         # --- proj_out + residual (+ BlobNet residual)
-        out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW,
+        out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True,
                          **self._r2(r2, x.H, x.W))
         return Act(out, Cc, x.H, x.W)
 

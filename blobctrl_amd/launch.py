@@ -89,6 +89,7 @@ class Recorder:
         _lib.check(self.lib.bc_device_info(info), "bc_device_info")
         self.num_cu = info[0]
         self.bytes_allocated = 0
+        self.parts = {}                     # data_ptr of a GEMM output -> (per-channel GroupNorm partials, nslab)
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float16):
@@ -105,11 +106,11 @@ class Recorder:
         self.seg = Segment(name)
         return self.seg
 
-    def _push(self, fn, kind, flops=0, variant=""):
+    def _push(self, fn, kind, flops=0, variant="", shape=None):
         self.seg.calls.append(fn)
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
-        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant))
+        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape))
 
     def slab(self, elems: int):
         """Shared split-K scratch: consumed by the reduce kernel that immediately follows on the same stream."""
@@ -135,7 +136,7 @@ class Recorder:
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
-             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0):
+             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -169,6 +170,26 @@ class Recorder:
         if sk > 1:
             self.reserve_slab(sk * M * N)
         rec = self
+        part = None
+        if want_gn:
+            # mirror of the C-side eligibility (bc_gemm: fused GroupNorm partials come from the LDS-DMA fast path only)
+            rpb = rows_per_batch if rows_per_batch > 0 else (conv["Hout"] * conv["Wout"] if conv else M)
+            tile_rows = self.lib.bc_gemm_tile_rows(N)
+            fast = K % 64 == 0
+            if conv:
+                hv, wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
+                ups = (hv, wv) != (conv["Hin"], conv["Win"])
+                fast = fast and conv["Cin"] % 64 == 0 and (not ups or ((hv, wv) == (2 * conv["Hin"], 2 * conv["Win"])
+                                                                      and conv.get("stride", 1) == 1))
+            elif A2 is not None:
+                fast = fast and C1 % 64 == 0
+            vec = out_mode == _lib.OUT_F16 and n_out % 8 == 0 and g.ldc % 8 == 0 and (R is None or ldr % 8 == 0) and \
+                (R2 is None or ldr2 % 8 == 0)
+            if fast and vec and sk == 1 and rpb % tile_rows == 0 and M % rpb == 0:
+                nslab = rpb // tile_rows
+                part = self.empty(M // rpb, nslab, n_out, 2, dtype=torch.float32)
+                g.gn_part = part.data_ptr()
+                self.parts[g.C] = (part, nslab)
 
         def fn(stream, g=g, lib=self.lib):
             if g.splitk > 1:
@@ -177,33 +198,51 @@ class Recorder:
             if rc:
                 _lib.check(rc, "bc_gemm")
 
-        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx))
+        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part))
         narrow = (((N + 127) // 128) * 128) / N > 1.10
         variant = ("gemm_kernel<256,64,4,1>" if narrow else "gemm_kernel<128,128,2,2>") + ("+splitk" if sk > 1 else "")
-        self._push(fn, kind, 2 * M * N * K, variant)
+        self._push(fn, kind, 2 * M * N * K, variant, (M, N, K, sk))
         return out
 
     # ------------------------------------------------------------------ norms
     def groupnorm(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out=None):
+        """GroupNorm(+SiLU) of the channel-concat (x1 | x2).  Per-channel partial statistics are taken from the producing
+        GEMM's epilogue when it emitted them (self.parts), otherwise a standalone bc_gn_stats pass is recorded."""
         lib = self.lib
-        Cc = C1 + (C2 if x2 is not None else 0)
-        nslab = (HW + 63) // 64
-        part = self.empty(B, nslab, Cc, 2, dtype=torch.float32)
+        c2 = C2 if x2 is not None else 0
+        Cc = C1 + c2
         ab = self.empty(B, Cc, 2, dtype=torch.float32)
         if out is None:
             out = self.empty(B, HW, Cc)
-        p1, p2, pp, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(part), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
-        c2 = C2 if x2 is not None else 0
+        stats_calls = []
+        srcs = []
+        for x, c in ((x1, C1), (x2, c2)):
+            if x is None:
+                srcs.append((None, 0))
+                continue
+            hit = self.parts.get(x.data_ptr())
+            if hit is not None and hit[0].shape[2] == c:
+                srcs.append((hit[0], hit[1]))
+            else:
+                nslab = (HW + 63) // 64
+                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
+                stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
+                srcs.append((part, nslab))
+        (pa1, ns1), (pa2, ns2) = srcs
+        p1, p2, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
+        pp1, pp2 = ptr(pa1), ptr(pa2)
 
         def fn(stream):
-            rc = lib.bc_gn_stats(p1, C1, p2, c2, B, HW, G, pp, nslab, stream)
-            rc = rc or lib.bc_gn_finalize(pp, nslab, B, HW, Cc, G, eps, pg, pb, pab, stream)
+            rc = 0
+            for (px, c, pp, ns) in stats_calls:
+                rc = rc or lib.bc_gn_stats(px, c, B, HW, pp, ns, stream)
+            rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
             rc = rc or lib.bc_gn_apply(p1, C1, p2, c2, B, HW, pab, 1 if silu else 0, po, stream)
             if rc:
                 _lib.check(rc, "groupnorm")
 
-        self.keep.append((x1, x2, part, ab, gamma, beta, out))
-        self._push(fn, "groupnorm")
+        self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta, out))
+        self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"))
         return out
 
     def layernorm(self, x, rows, Cc, gamma, beta, eps, out=None, ldx=None, ldy=None):
@@ -238,7 +277,7 @@ class Recorder:
                 _lib.check(rc, "bc_attention")
 
         self.keep.append((Q, K, Vt, out))
-        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d, f"attn_fwd_kernel<{d}>")
+        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d, f"attn_fwd_kernel<{d}>", (B, heads, d, Nq, Nkv))
         return out
 
     # ------------------------------------------------------------------ glue

@@ -81,23 +81,29 @@ typedef struct BcGemm {
     /* ---- split-K ---- */
     int splitk;              /* >=1 ; >1 needs `slab` of splitk*M*N floats */
     float* slab;
+    /* ---- optional fused GroupNorm statistics of the (fp16-rounded) OUTPUT: per-channel (sum, sumsq) partials
+     *      gn_part[B][rows_per_batch / bc_gemm_tile_rows(N, act)][n_out][2]; needs splitk == 1, BC_OUT_F16, K % 64 == 0,
+     *      rows_per_batch % tile_rows == 0.  Consumed by bc_gn_finalize (replaces the bc_gn_stats pass). ---- */
+    float* gn_part;
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);
 int bc_sizeof_gemm(void);            /* sizeof(BcGemm), lets FFI bindings verify their struct mirror */
+int bc_gemm_tile_rows(int N);        /* rows of one output tile for an N-column GEMM (256 or 128): slab height of gn_part */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
  * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
  * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
- *   bc_gn_stats    : per-channel partial sums  part[B][nslab][C1+C2][2], nslab = ceil(HW/64)  (no atomics: bit-reproducible)
- *   bc_gn_finalize : per-channel affine  ab[B][C][2] = (rstd*gamma, beta - mean*rstd*gamma)
- *   bc_gn_apply    : y[B][HW][C] = silu?( x*ab.x + ab.y )   (x = concat(x1, x2))
+ *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/64)][C][2] (no atomics: bit-reproducible).
+ *                    Only needed when the producing GEMM did not emit them itself (BcGemm.gn_part).
+ *   bc_gn_finalize : per-channel affine of the concat (x1 | x2): ab[B][C1+C2][2] = (rstd*gamma, beta - mean*rstd*gamma),
+ *                    from part_i[B][nslab_i][C_i][2] (part2 may be NULL)
+ *   bc_gn_apply    : y[B][HW][C1+C2] = silu?( x*ab.x + ab.y )   (x = concat(x1, x2))
  * --------------------------------------------------------------------------------------------------------------- */
-int bc_gn_stats(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW, int G,
-                float* part, int nslab, bc_stream stream);
-int bc_gn_finalize(const float* part, int nslab, int B, int HW, int C, int G, float eps,
-                   const float* gamma, const float* beta, float* ab, bc_stream stream);
+int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, int nslab, bc_stream stream);
+int bc_gn_finalize(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2, int B, int HW, int G,
+                   float eps, const float* gamma, const float* beta, float* ab, bc_stream stream);
 int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW,
                 const float* ab, int silu, bc_half* y, bc_stream stream);
 

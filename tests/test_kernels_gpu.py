@@ -214,6 +214,33 @@ def test_groupnorm(rec, B, C1, C2, HW, G, eps, silu):
     close(out, ref.permute(0, 2, 1), what="groupnorm")
 
 
+@pytest.mark.parametrize("B,HW,K,N,G", [(2, 256, 128, 320, 32), (2, 512, 64, 128, 32), (1, 1024, 192, 640, 32)])
+def test_groupnorm_with_stats_fused_into_gemm_epilogue(rec, B, HW, K, N, G):
+    """The producing GEMM emits per-channel (sum, sumsq) partials of its fp16 output; GroupNorm consumes them without
+    re-reading the tensor.  Also covers the concat of a fused-stats tensor with a plain one."""
+    M = B * HW
+    A, W, b, R = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N), g(4, M, N)
+    gamma, beta = 1 + 0.1 * g(5, N), 0.1 * g(6, N)
+
+    def fn():
+        y = rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), R=h(R), ldr=N, rows_per_batch=HW,
+                     want_gn=True)
+        assert y.data_ptr() in rec.parts, "GEMM did not take the fused-statistics path"
+        return y, rec.groupnorm(y, N, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda(), True)
+    y, out = run(rec, fn)
+    assert rec.seg.kinds.get("groupnorm_fused_stats") == 1
+    yref = A.half().float() @ W.half().float().t() + b + R.half().float()
+    close(y, yref, what="gemm out")
+    ref = F.silu(F.group_norm(y.float().cpu().view(B, HW, N).permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1)
+    close(out, ref, what="groupnorm fused stats")
+    # concat with a tensor that has no partials (stand-alone statistics pass for that source only)
+    x2 = g(7, B, HW, 64)
+    g2, b2 = 1 + 0.1 * g(8, N + 64), 0.1 * g(9, N + 64)
+    out2 = run(rec, lambda: rec.groupnorm(y, N, h(x2), 64, B, HW, G, 1e-5, g2.cuda(), b2.cuda(), False))
+    cat = torch.cat([y.float().cpu().view(B, HW, N), x2.half().float()], -1).permute(0, 2, 1)
+    close(out2, F.group_norm(cat, G, g2, b2, 1e-5).permute(0, 2, 1), what="groupnorm concat mixed stats")
+
+
 @pytest.mark.parametrize("rows,Cc", [(100, 320), (77, 640), (513, 1280), (9, 64), (5, 16)])
 def test_layernorm(rec, rows, Cc):
     x, gamma, beta = g(1, rows, Cc) * 3 + 1, 1 + 0.1 * g(2, Cc), 0.1 * g(3, Cc)
