@@ -246,9 +246,90 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int bc_gemm_tile_rows(int N) {
-    int n128 = bc_ceil_div(N, 128) * 128;
-    return ((double)n128 / N > 1.10) ? 256 : 128;
+namespace {
+
+struct TileCfg { int bm, bn, threads, ns, lds; };
+// index = BC_TILE_*
+const TileCfg kTiles[BC_TILE_COUNT] = {
+    {0, 0, 0, 0, 0},
+    {256, 128, 512, 3, 3 * (256 + 128) * 128},
+    {128, 128, 256, 3, 3 * (128 + 128) * 128},
+    {128, 128, 256, 2, 2 * (128 + 128) * 128},
+    {256, 64, 256, 2, 2 * (256 + 64) * 128},
+    {256, 64, 256, 3, 3 * (256 + 64) * 128},
+    {128, 64, 256, 3, 3 * (128 + 64) * 128},
+    {64, 64, 256, 4, 4 * (64 + 64) * 128},
+};
+
+int g_num_cu = 0;
+
+int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+// Cost model (microseconds).  Operand staging is bounded by the per-CU L2->LDS rate (~70 GB/s measured for LDS-DMA
+// gathers, MI355X_MICROARCH.md "Indexed rows: gather into LDS") and, when few bytes are in flight per CU, by latency
+// (~1 us per dependent tile); MFMA at ~9.8 TFLOP/s per CU.  Split-K adds the fp32 slab round trip and a second launch.
+double model_us(const TileCfg& t, int M, int N, int K, int sk) {
+    const int cus = num_cu();
+    const long long nblk = (long long)bc_ceil_div(M, t.bm) * bc_ceil_div(N, t.bn) * sk;
+    const int nkb = bc_ceil_div(bc_ceil_div(K, BK), sk);
+    const double stage = (double)(t.bm + t.bn) * 128.0;
+    const int by_lds = std::max(1, (160 * 1024) / std::max(t.lds, t.bm * t.bn * 4));
+    const int resident = (int)std::min<long long>(std::min(by_lds, 2048 / t.threads), (nblk + cus - 1) / cus);
+    const double inflight = resident * (t.ns - 1) * stage;                 // bytes in flight per CU
+    const double bw = std::min(70e3, inflight / 1.0);                      // bytes per microsecond per CU
+    const double per_cu_blocks = (double)((nblk + cus - 1) / cus);
+    const double t_load = per_cu_blocks * nkb * stage / bw;
+    const double t_mfma = per_cu_blocks * nkb * (2.0 * t.bm * t.bn * BK) / (9.8e6 * 0.8);
+    double us = std::max(t_load, t_mfma) + 3.0 + per_cu_blocks * (t.bm * t.bn) / 16384.0 * 1.0;   // + epilogue per block
+    if (sk > 1) us += 3.0 + 2.0 * sk * (double)M * N * 4.0 / 3.0e6;
+    return us;
+}
+
+}  // namespace
+
+extern "C" int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int* bm, int* bn) {
+    BC_CHECK_ARG(tile_cfg && splitk && bm && bn && M > 0 && N > 0 && K > 0, "bc_gemm_plan: bad args");
+    const int nk = bc_ceil_div(K, BK);
+    int cfg = *tile_cfg, sk = *splitk;
+    if (!fast) {
+        // generic kernel: 128x128, or 256x64 when N would be padded by > 10 % on a 128-wide tile
+        int n128 = bc_ceil_div(N, 128) * 128;
+        cfg = ((double)n128 / N > 1.10) ? BC_TILE_256x64_S2 : BC_TILE_128x128_S2;
+        if (sk <= 0) {
+            long long tiles = (long long)bc_ceil_div(M, kTiles[cfg].bm) * bc_ceil_div(N, kTiles[cfg].bn);
+            sk = 1;
+            if (tiles < num_cu() * 6 / 10 && nk >= 8) sk = (int)std::max<long long>(1, std::min<long long>(std::min<long long>((num_cu() + tiles - 1) / tiles, nk / 4), 8));
+        }
+    } else if (cfg <= BC_TILE_AUTO || cfg >= BC_TILE_COUNT || sk <= 0) {
+        double best = 1e30;
+        int best_cfg = BC_TILE_128x128_S2, best_sk = 1;
+        const int sks[] = {1, 2, 3, 4, 6, 8, 12};
+        for (int c = 1; c < BC_TILE_COUNT; ++c) {
+            if (cfg > BC_TILE_AUTO && cfg < BC_TILE_COUNT && c != cfg) continue;
+            for (int s : sks) {
+                if (sk > 0 && s != sk) continue;
+                if (s > 1 && nk / s < 4) continue;
+                double us = model_us(kTiles[c], M, N, K, s);
+                if (us < best) { best = us; best_cfg = c; best_sk = s; }
+            }
+        }
+        cfg = best_cfg;
+        if (sk <= 0) sk = best_sk;
+    }
+    if (sk > nk) sk = nk;
+    *tile_cfg = cfg;
+    *splitk = sk;
+    *bm = kTiles[cfg].bm;
+    *bn = kTiles[cfg].bn;
+    return 0;
 }
 
 extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
@@ -311,23 +392,36 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     g.div_outw = make_fastdiv((unsigned)p.out_w);
     g.div_wout = make_fastdiv((unsigned)(p.a_mode == BC_A_CONV3X3 ? p.Wout : 1));
 
-    // tile choice: 128x128 unless N would be padded by >10 % (N = 320 -> 5 x 64 columns)
-    int n128 = bc_ceil_div(p.N, 128) * 128;
-    g.narrow = (double)n128 / p.N > 1.10;
+    // ---- resolve tile configuration (explicit from the caller's plan, or heuristic) ----
+    bool fast_ok = (p.K % BK == 0);
+    if (p.a_mode == BC_A_CONV3X3) {
+        bool ups = (p.Hv != p.Hin) || (p.Wv != p.Win);
+        fast_ok = fast_ok && (p.Cin % BK == 0) && (!ups || (p.Hv == 2 * p.Hin && p.Wv == 2 * p.Win && p.stride == 1));
+    } else if (p.A2) {
+        fast_ok = fast_ok && (p.C1 % BK == 0);
+    }
+    static const bool force_generic = getenv("BC_GEMM_GENERIC") != nullptr;
+    static const int force_tile = getenv("BC_GEMM_TILE") ? atoi(getenv("BC_GEMM_TILE")) : 0;
+    if (force_generic) fast_ok = false;
+    {
+        int cfg = (force_tile > 0 && force_tile < BC_TILE_COUNT) ? force_tile : p.tile_cfg;
+        int sk = p.splitk, bm = 0, bn = 0;
+        int rc0 = bc_gemm_plan(p.M, p.N, p.K, fast_ok ? 1 : 0, &cfg, &sk, &bm, &bn);
+        if (rc0) return rc0;
+        g.cfg = cfg; g.bm = bm; g.bn = bn;
+    }
     auto aligned16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     g.vec_epilogue = p.out_mode == BC_OUT_F16 && g.n_out % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                      (!p.R || (p.ldr % 8 == 0 && aligned16(p.R))) && (!p.R2 || (p.ldr2 % 8 == 0 && aligned16(p.R2)));
     if (p.gn_part) {
-        int bm = g.narrow ? 256 : 128;
-        BC_CHECK_ARG(p.splitk == 1 && g.vec_epilogue && p.K % BK == 0 && p.rows_per_batch % bm == 0 && p.M % p.rows_per_batch == 0,
-                     "bc_gemm: fused GroupNorm partials need splitk==1, fp16 row-major output, K%%64==0 and rows_per_batch%%%d==0", bm);
+        BC_CHECK_ARG(fast_ok && p.splitk == 1 && g.vec_epilogue && p.rows_per_batch % g.bm == 0 && p.M % p.rows_per_batch == 0,
+                     "bc_gemm: fused GroupNorm partials need the fast path, splitk==1, fp16 row-major output and rows_per_batch%%%d==0", g.bm);
     }
-    static const bool force_generic = getenv("BC_GEMM_GENERIC") != nullptr;
-    int rc = force_generic ? -1 : bc_gemm_fast_try(g, stream);
+    int rc = fast_ok ? bc_gemm_fast_try(g, stream) : -1;
     if (rc > 0) return rc;
     if (rc < 0) {
         BC_CHECK_ARG(!p.gn_part, "bc_gemm: fused GroupNorm partials are only produced by the fast path");
-        rc = g.narrow ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
+        rc = (g.bn == 64) ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
         if (rc) return rc;
     }
     if (p.splitk > 1) {

@@ -36,7 +36,8 @@ struct GemmArgs {
     int kt_per_split;
     int n_out;           // output columns (N, or N/2 for GEGLU)
     int fast_k;          // conv: Cin % BK == 0 ; dense: (C1 % BK == 0 or no A2)
-    int narrow;          // 1: 256x64 tile (N padded by > 10 % on a 128-wide tile), 0: 128x128
+    int cfg;             // resolved BC_TILE_* configuration
+    int bm, bn;          // its tile shape
     int vec_epilogue;    // 1: LDS-staged 16-byte epilogue is legal (fp16 row-major output, widths % 8 == 0)
 };
 

@@ -13,6 +13,7 @@
 //     parked as fp32 in the (now free) LDS tile, then re-read row-major so that the residual loads, the BlobNet
 //     right-half add and the fp16 stores are all 16-byte coalesced; the same pass optionally emits per-channel
 //     (sum, sumsq) partials of the fp16-rounded output for the consumer's GroupNorm (no extra pass over the tensor).
+#include <stdlib.h>
 #include "gemm_common.h"
 
 using namespace bcg;
@@ -28,7 +29,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool UPS>
+template <int BM, int BN, int WM, int WN, int NS, bool CONV, bool UPS>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs g) {
     constexpr int NT = 64 * WM * WN;
     constexpr int NW = WM * WN;
@@ -163,12 +164,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
     const int frow = lane & 31;
     const int fhalf = lane >> 5;
 
-    if (kt_begin < kt_end) issue(kt_begin, 0);
+    // NS-stage LDS ring, NS-1 tiles of LDS-DMA in flight.  Counted vmcnt + raw s_barrier: a __syncthreads() here would
+    // drain every outstanding LDS-DMA (cdna_hip_programming.md section 5 "Pipelining across barriers").
+    constexpr int L = A_LOADS + B_LOADS;              // LDS-DMA instructions per wave per tile
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (kt_begin + s < kt_end) issue(kt_begin + s, s);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of tile kt have landed
-        __syncthreads();                                      // everyone's have; everyone finished reading stage cur^1
-        if (kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+        const int remaining = kt_end - 1 - kt;        // tiles issued after tile kt
+        if (NS >= 4 && remaining >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+        else if (NS >= 3 && remaining >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; stage (kt-1)%NS is free again
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < kt_end) {
+            int nxt = cur + NS - 1;
+            if (nxt >= NS) nxt -= NS;
+            issue(kt + NS - 1, nxt);
+        }
         const char* la = smem + cur * STAGE;
         const char* lb = la + BM * 128;
 #pragma unroll
@@ -190,7 +204,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        cur ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS reads of this stage are done before I pass the next barrier
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
 
     // ------------------------------------------------------------------------------------------------ epilogue
@@ -332,21 +347,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool UPS>
+template <int BM, int BN, int WM, int WN, int NS, bool CONV, bool UPS>
 int launch_fast(const GemmArgs& g, hipStream_t stream) {
     const BcGemm& p = g.p;
     dim3 grid(bc_ceil_div(p.N, BN), bc_ceil_div(p.M, BM), p.splitk);
     dim3 block(64 * WM * WN);
-    size_t lds = 2 * (BM + BN) * 128;
+    size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BM * BN * 4);
     static bool attr_set = false;
     if (!attr_set) {
-        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, WM, WN, CONV, UPS>),
+        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, WN, CONV, UPS>), grid, block, lds, stream, g);
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>), grid, block, lds, stream, g);
     BC_CHECK_LAUNCH();
     return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_mode(const GemmArgs& g, bool conv, bool ups, hipStream_t stream) {
+    if (conv) return ups ? launch_fast<BM, BN, WM, WN, NS, true, true>(g, stream) : launch_fast<BM, BN, WM, WN, NS, true, false>(g, stream);
+    return launch_fast<BM, BN, WM, WN, NS, false, false>(g, stream);
 }
 
 }  // namespace
@@ -363,10 +384,14 @@ int bc_gemm_fast_try(const GemmArgs& g, hipStream_t stream) {
     } else if (p.A2 && (p.C1 % BK != 0)) {
         return -1;
     }
-    if (g.narrow) {
-        if (conv) return ups ? launch_fast<256, 64, 4, 1, true, true>(g, stream) : launch_fast<256, 64, 4, 1, true, false>(g, stream);
-        return launch_fast<256, 64, 4, 1, false, false>(g, stream);
+    switch (g.cfg) {
+        case BC_TILE_256x128:    return launch_mode<256, 128, 4, 2, 3>(g, conv, ups, stream);
+        case BC_TILE_128x128_S3: return launch_mode<128, 128, 2, 2, 3>(g, conv, ups, stream);
+        case BC_TILE_128x128_S2: return launch_mode<128, 128, 2, 2, 2>(g, conv, ups, stream);
+        case BC_TILE_256x64_S2:  return launch_mode<256, 64, 4, 1, 2>(g, conv, ups, stream);
+        case BC_TILE_256x64_S3:  return launch_mode<256, 64, 4, 1, 3>(g, conv, ups, stream);
+        case BC_TILE_128x64:     return launch_mode<128, 64, 2, 2, 3>(g, conv, ups, stream);
+        case BC_TILE_64x64:      return launch_mode<64, 64, 2, 2, 4>(g, conv, ups, stream);
+        default: return -1;
     }
-    if (conv) return ups ? launch_fast<128, 128, 2, 2, true, true>(g, stream) : launch_fast<128, 128, 2, 2, true, false>(g, stream);
-    return launch_fast<128, 128, 2, 2, false, false>(g, stream);
 }

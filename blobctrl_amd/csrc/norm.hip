@@ -54,49 +54,58 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x
 }
 
 // ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]) for the channel-concat of two sources, each with its own
-// per-channel partial buffer part_i[B][nslab_i][C_i][2].  One block per batch image; wave w reduces groups w, w + nw, ...
-// over (slab, channel-in-group) pairs in a fixed order with fp64 accumulation (deterministic).
-__global__ void gn_finalize_kernel(const float* __restrict__ part1, int nslab1, int C1, const float* __restrict__ part2,
-                                   int nslab2, int C2, int HW, int G, float eps, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ ab) {
-    __shared__ float stat[GN_MAX_GROUPS * 2];
-    const int b = blockIdx.x;
+// per-channel partial buffer part_i[B][nslab_i][C_i][2].  grid (ceil(G/4), B), one wave per group: its lanes sweep the
+// flattened (channel-in-group, slab) items of both sources (all loads independent -> one memory latency, not cpg of them),
+// fp64 accumulation in a fixed order => deterministic.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part1, int nslab1, int C1,
+                                                            const float* __restrict__ part2, int nslab2, int C2, int HW,
+                                                            int G, float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ab) {
+    const int b = blockIdx.y;
     const int C = C1 + C2;
     const int cpg = C / G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int g = wave; g < G; g += nw) {
-        double s = 0.0, q = 0.0;
-        for (int cj = 0; cj < cpg; ++cj) {
-            const int c = g * cpg + cj;
-            const bool first = c < C1;
-            const float* base = first ? part1 + ((size_t)b * nslab1 * C1 + c) * 2 : part2 + ((size_t)b * nslab2 * C2 + (c - C1)) * 2;
-            const int ns = first ? nslab1 : nslab2;
-            const size_t stride = (size_t)(first ? C1 : C2) * 2;
-            for (int sl = lane; sl < ns; sl += 64) {
-                s += base[sl * stride];
-                q += base[sl * stride + 1];
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o);
-            q += __shfl_xor(q, o);
-        }
-        if (lane == 0) {
-            double n = (double)HW * cpg;
-            double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            stat[2 * g] = (float)mean;
-            stat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int n1 = max(0, min(c_hi, C1) - c_lo);               // channels of this group living in source 1
+    const int n2 = cpg - n1;
+    double s = 0.0, q = 0.0;
+    {
+        const float* base = part1 + ((size_t)b * nslab1 * C1 + c_lo) * 2;
+        const int items = n1 * nslab1;
+        for (int it = lane; it < items; it += 64) {
+            const int sl = it / n1, cj = it - sl * n1;
+            const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C1 + cj) * 2);
+            s += v.x;
+            q += v.y;
         }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        int g = c / cpg;
-        float a = stat[2 * g + 1] * gamma[c];
+    if (n2 > 0) {
+        const int c2_lo = max(c_lo, C1) - C1;
+        const float* base = part2 + ((size_t)b * nslab2 * C2 + c2_lo) * 2;
+        const int items = n2 * nslab2;
+        for (int it = lane; it < items; it += 64) {
+            const int sl = it / n2, cj = it - sl * n2;
+            const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C2 + cj) * 2);
+            s += v.x;
+            q += v.y;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = c_lo + lane; c < c_hi; c += 64) {
+        const float a = rstd * gamma[c];
         ab[((size_t)b * C + c) * 2] = a;
-        ab[((size_t)b * C + c) * 2 + 1] = beta[c] - stat[2 * g] * a;
+        ab[((size_t)b * C + c) * 2 + 1] = beta[c] - meanf * a;
     }
 }
 
@@ -202,7 +211,7 @@ extern "C" int bc_gn_finalize(const float* part1, int nslab1, int C1, const floa
     int C = C1 + C2;
     BC_CHECK_ARG(part1 && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0 && nslab1 > 0,
                  "bc_gn_finalize: bad args (groups <= %d, C %% G == 0)", GN_MAX_GROUPS);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(bc_ceil_div(G, 4), B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
                        gamma, beta, ab);
     BC_CHECK_LAUNCH();
     return 0;

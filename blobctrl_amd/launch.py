@@ -6,12 +6,29 @@ loop over closures; because buffers and argument blocks never change, a segment 
 (`Segment.capture`) and replayed with one `hipGraphLaunch`.
 """
 import ctypes as C
+import json
+import os
 from typing import Callable, List, Optional
 
 import torch
 
 from . import _lib
 from ._lib import BcGemm
+
+
+_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
+_TUNING = None
+
+
+def tuning_table():
+    """Measured best (tile_cfg, splitk) per GEMM shape, written by tools/tune_gemm.py on an MI355X (optional)."""
+    global _TUNING
+    if _TUNING is None:
+        _TUNING = {}
+        if os.path.exists(_TUNING_PATH) and not os.environ.get("BC_NO_TUNING"):
+            with open(_TUNING_PATH) as f:
+                _TUNING = json.load(f).get("shapes", {})
+    return _TUNING
 
 
 def ptr(t: Optional[torch.Tensor]):
@@ -124,19 +141,22 @@ class Recorder:
             self._slab_elems = elems
 
     # ------------------------------------------------------------------ GEMM family
-    def choose_splitk(self, M, N, K):
-        bm, bn = (256, 64) if (((N + 127) // 128) * 128) / N > 1.10 else (128, 128)
-        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-        nk = (K + 63) // 64
-        if tiles >= int(0.6 * self.num_cu) or nk < 8:
-            return 1
-        want = (self.num_cu + tiles - 1) // tiles
-        return max(1, min(want, nk // 4, 8))
+    def plan_gemm(self, M, N, K, fast, mode, tile_cfg=0, splitk=None):
+        """(tile_cfg, splitk, bm, bn) for a GEMM: tuning table first, then the library's cost model (bc_gemm_plan)."""
+        sk = -1 if splitk is None else splitk
+        if tile_cfg == 0 and splitk is None and fast:
+            hit = tuning_table().get(f"{mode}|{M}|{N}|{K}")
+            if hit:
+                tile_cfg, sk = int(hit[0]), int(hit[1])
+        c, s_, bm, bn = C.c_int(tile_cfg), C.c_int(sk), C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.bc_gemm_plan(M, N, K, 1 if fast else 0, C.byref(c), C.byref(s_), C.byref(bm), C.byref(bn)),
+                   "bc_gemm_plan")
+        return c.value, s_.value, bm.value, bn.value
 
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
-             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False):
+             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -165,28 +185,32 @@ class Recorder:
         g.out_mode = out_mode
         g.C = out.data_ptr() + out_offset * out.element_size()
         g.ldc = ldc if ldc is not None else n_out
-        sk = splitk if splitk is not None else self.choose_splitk(M, N, K)
+        # mirror of the C-side fast-path eligibility (bc_gemm)
+        fast = K % 64 == 0
+        mode = "dense"
+        if conv:
+            hv, wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
+            ups = (hv, wv) != (conv["Hin"], conv["Win"])
+            fast = fast and conv["Cin"] % 64 == 0 and (not ups or ((hv, wv) == (2 * conv["Hin"], 2 * conv["Win"])
+                                                                  and conv.get("stride", 1) == 1))
+            mode = "ups" if ups else f"conv{conv.get('stride', 1)}"
+        elif A2 is not None:
+            fast = fast and C1 % 64 == 0
+        if os.environ.get("BC_GEMM_GENERIC"):
+            fast = False
+        cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
         g.splitk = sk
+        g.tile_cfg = cfg
         if sk > 1:
             self.reserve_slab(sk * M * N)
         rec = self
         part = None
         if want_gn:
-            # mirror of the C-side eligibility (bc_gemm: fused GroupNorm partials come from the LDS-DMA fast path only)
             rpb = rows_per_batch if rows_per_batch > 0 else (conv["Hout"] * conv["Wout"] if conv else M)
-            tile_rows = self.lib.bc_gemm_tile_rows(N)
-            fast = K % 64 == 0
-            if conv:
-                hv, wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
-                ups = (hv, wv) != (conv["Hin"], conv["Win"])
-                fast = fast and conv["Cin"] % 64 == 0 and (not ups or ((hv, wv) == (2 * conv["Hin"], 2 * conv["Win"])
-                                                                      and conv.get("stride", 1) == 1))
-            elif A2 is not None:
-                fast = fast and C1 % 64 == 0
             vec = out_mode == _lib.OUT_F16 and n_out % 8 == 0 and g.ldc % 8 == 0 and (R is None or ldr % 8 == 0) and \
                 (R2 is None or ldr2 % 8 == 0)
-            if fast and vec and sk == 1 and rpb % tile_rows == 0 and M % rpb == 0:
-                nslab = rpb // tile_rows
+            if fast and vec and sk == 1 and rpb % bm == 0 and M % rpb == 0 and not os.environ.get("BC_GEMM_TILE"):
+                nslab = rpb // bm
                 part = self.empty(M // rpb, nslab, n_out, 2, dtype=torch.float32)
                 g.gn_part = part.data_ptr()
                 self.parts[g.C] = (part, nslab)
@@ -199,9 +223,8 @@ class Recorder:
                 _lib.check(rc, "bc_gemm")
 
         self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part))
-        narrow = (((N + 127) // 128) * 128) / N > 1.10
-        variant = ("gemm_kernel<256,64,4,1>" if narrow else "gemm_kernel<128,128,2,2>") + ("+splitk" if sk > 1 else "")
-        self._push(fn, kind, 2 * M * N * K, variant, (M, N, K, sk))
+        variant = ("gemm_fast<" if fast else "gemm_generic<") + _lib.TILE_NAMES[cfg] + ">" + ("+splitk" if sk > 1 else "")
+        self._push(fn, kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out
 
     # ------------------------------------------------------------------ norms

@@ -82,14 +82,22 @@ typedef struct BcGemm {
     int splitk;              /* >=1 ; >1 needs `slab` of splitk*M*N floats */
     float* slab;
     /* ---- optional fused GroupNorm statistics of the (fp16-rounded) OUTPUT: per-channel (sum, sumsq) partials
-     *      gn_part[B][rows_per_batch / bc_gemm_tile_rows(N, act)][n_out][2]; needs splitk == 1, BC_OUT_F16, K % 64 == 0,
+     *      gn_part[B][rows_per_batch / bm (bm from bc_gemm_plan)][n_out][2]; needs splitk == 1, BC_OUT_F16, K % 64 == 0,
      *      rows_per_batch % tile_rows == 0.  Consumed by bc_gn_finalize (replaces the bc_gn_stats pass). ---- */
     float* gn_part;
+    /* ---- tile configuration: 0 = library heuristic, else one of BC_TILE_* (see bc_gemm_plan) ---- */
+    int tile_cfg;
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);
 int bc_sizeof_gemm(void);            /* sizeof(BcGemm), lets FFI bindings verify their struct mirror */
-int bc_gemm_tile_rows(int N);        /* rows of one output tile for an N-column GEMM (256 or 128): slab height of gn_part */
+/* Tile configurations of the LDS-DMA fast path (block tile BM x BN, waves, LDS stages). */
+enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_128x128_S2 = 3, BC_TILE_256x64_S2 = 4,
+       BC_TILE_256x64_S3 = 5, BC_TILE_128x64 = 6, BC_TILE_64x64 = 7, BC_TILE_COUNT = 8 };
+/* Resolve the plan for a GEMM: in/out *tile_cfg (AUTO -> heuristic choice), in/out *splitk (<= 0 -> heuristic), out *bm,
+ * *bn = tile shape (bm is the slab height of gn_part).  `fast` = 1 when the problem meets the fast-path conditions
+ * (K % 64 == 0, conv Cin % 64 == 0, concat split % 64 == 0); otherwise only 128x128 / 256x64 generic tiles exist. */
+int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int* bm, int* bn);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
