@@ -227,6 +227,78 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
     epilogue_store(g, v, m, n, alpha);
 }
 
+// Vectorised reducer: a workgroup owns SK_ROWS rows x 64 output columns (8 columns per thread), sums the slabs with
+// 16-byte loads, applies the shared 8-wide epilogue and (optionally) emits GroupNorm partials for its row block:
+// gn_part[B][rows_per_batch / SK_ROWS][n_out][2].
+constexpr int SK_ROWS = 32;
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g) {
+    __shared__ float scr[4 * 64 * 2];
+    const BcGemm& p = g.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col8 = tid & 7, row = tid >> 3;                 // 8 chunks x 32 rows
+    const int m = blockIdx.y * SK_ROWS + row;
+    const int n_first = blockIdx.x * 64 + col8 * 8;
+    const bool geglu = p.act == BC_ACT_GEGLU;
+    const int ncol_v = geglu ? (n_first >> 5) * 64 + (n_first & 31) : n_first;
+    float alpha = p.alpha;
+    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    Cols8 cols;
+    cols8_init(g, cols, n_first, ncol_v, geglu, alpha);
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    if (m < p.M && cols.nok) {
+        const size_t mn = (size_t)p.M * p.N;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splitk; ++z) {
+            const float* src = p.slab + z * mn + (size_t)m * p.N + ncol_v;
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+            if (geglu) {
+                const float4 glo = *reinterpret_cast<const float4*>(src + 32), ghi = *reinterpret_cast<const float4*>(src + 36);
+                gt[0] += glo.x; gt[1] += glo.y; gt[2] += glo.z; gt[3] += glo.w;
+                gt[4] += ghi.x; gt[5] += ghi.y; gt[6] += ghi.z; gt[7] += ghi.w;
+            }
+        }
+        epi8_store(g, cols, v, gt, m, gs, gq);
+    }
+    if (p.gn_part) {
+        for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gs[j] += __shfl_xor(gs[j], o);
+                gq[j] += __shfl_xor(gq[j], o);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                scr[(wave * 64 + col8 * 8 + j) * 2] = gs[j];
+                scr[(wave * 64 + col8 * 8 + j) * 2 + 1] = gq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int n = blockIdx.x * 64 + tid;
+            if (n < g.n_out) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s += scr[(w * 64 + tid) * 2];
+                    q += scr[(w * 64 + tid) * 2 + 1];
+                }
+                const int mb = blockIdx.y * SK_ROWS;
+                const int b = (int)fdiv((unsigned)mb, g.div_rpb);
+                const int slab = (mb - b * (int)g.div_rpb.d) / SK_ROWS;
+                const int nslab = (int)g.div_rpb.d / SK_ROWS;
+                float* dst = p.gn_part + (((size_t)b * nslab + slab) * g.n_out + n) * 2;
+                dst[0] = s;
+                dst[1] = q;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     const BcGemm& p = g.p;
@@ -414,19 +486,26 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     g.vec_epilogue = p.out_mode == BC_OUT_F16 && g.n_out % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                      (!p.R || (p.ldr % 8 == 0 && aligned16(p.R))) && (!p.R2 || (p.ldr2 % 8 == 0 && aligned16(p.R2)));
     if (p.gn_part) {
-        BC_CHECK_ARG(fast_ok && p.splitk == 1 && g.vec_epilogue && p.rows_per_batch % g.bm == 0 && p.M % p.rows_per_batch == 0,
-                     "bc_gemm: fused GroupNorm partials need the fast path, splitk==1, fp16 row-major output and rows_per_batch%%%d==0", g.bm);
+        const int slab_rows = p.splitk > 1 ? SK_ROWS : g.bm;
+        BC_CHECK_ARG((fast_ok || p.splitk > 1) && g.vec_epilogue && p.N % 4 == 0 && p.rows_per_batch % slab_rows == 0 &&
+                         p.M % p.rows_per_batch == 0,
+                     "bc_gemm: fused GroupNorm partials need the fast path or split-K, fp16 row-major output and rows_per_batch%%%d==0", slab_rows);
     }
     int rc = fast_ok ? bc_gemm_fast_try(g, stream) : -1;
     if (rc > 0) return rc;
     if (rc < 0) {
-        BC_CHECK_ARG(!p.gn_part, "bc_gemm: fused GroupNorm partials are only produced by the fast path");
+        BC_CHECK_ARG(!p.gn_part || p.splitk > 1, "bc_gemm: fused GroupNorm partials are only produced by the fast path or the split-K reducer");
         rc = (g.bn == 64) ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
         if (rc) return rc;
     }
     if (p.splitk > 1) {
-        long long total = (long long)p.M * g.n_out;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(bc_ceil_div(total, 256)), dim3(256), 0, stream, g);
+        if (g.vec_epilogue && p.N % 4 == 0) {
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(bc_ceil_div(g.n_out, 64), bc_ceil_div(p.M, SK_ROWS)), dim3(256), 0,
+                               stream, g);
+        } else {
+            long long total = (long long)p.M * g.n_out;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(bc_ceil_div(total, 256)), dim3(256), 0, stream, g);
+        }
         BC_CHECK_LAUNCH();
     }
     return 0;

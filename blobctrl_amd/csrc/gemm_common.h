@@ -143,6 +143,84 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmArgs& g, const fl
     }
 }
 
+// ---- vectorised (8 output columns) epilogue shared by the fast kernel's row-major pass and the split-K reducer ----
+struct Cols8 {
+    float bias_v[8], bias_g[8], cs[8];
+    int n_first;        // first OUTPUT column
+    bool nok;
+};
+
+__device__ __forceinline__ void cols8_init(const GemmArgs& g, Cols8& c, int n_first_out, int ncol_value, bool geglu, float alpha) {
+    const BcGemm& p = g.p;
+    c.n_first = n_first_out;
+    c.nok = n_first_out < g.n_out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        c.bias_v[j] = (p.bias && c.nok) ? p.bias[ncol_value + j] : 0.f;
+        c.bias_g[j] = (geglu && p.bias && c.nok) ? p.bias[ncol_value + 32 + j] : 0.f;
+        c.cs[j] = ((p.colscale && c.nok) ? p.colscale[n_first_out + j] : 1.f) * alpha;
+    }
+}
+
+// v[8] = raw accumulators of the (value) columns, gt = raw gate accumulators (GEGLU only).  Applies bias, row vector,
+// activation, LayerScale*alpha, residual, BlobNet right-half residual; stores 8 fp16; accumulates GroupNorm partials.
+__device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, float (&v)[8], const float (&gt)[8], int m,
+                                           float (&gs)[8], float (&gq)[8]) {
+    const BcGemm& p = g.p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += c.bias_v[j];
+    int b = 0, pix = m;
+    if (p.rowvec || p.R2) {
+        b = (int)fdiv((unsigned)m, g.div_rpb);
+        pix = m - b * (int)g.div_rpb.d;
+    }
+    if (p.rowvec) {
+        const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.rowvec) + (size_t)b * p.ld_rowvec + c.n_first);
+        const h16* rh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+    }
+    if (p.act == BC_ACT_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= bc_gelu_f(gt[j] + c.bias_g[j]);
+    } else if (p.act == BC_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
+    } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= c.cs[j];
+    if (p.R) {
+        const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)m * p.ldr + c.n_first);
+        const h16* rh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+    }
+    if (p.R2) {
+        const int y = (int)fdiv((unsigned)pix, g.div_outw);
+        const int x = pix - y * (int)g.div_outw.d;
+        if (x >= p.r2_xmin) {
+            const int bb = b % p.r2_bmod;
+            const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)bb * g.div_rpb.d + pix) * p.ldr2 + c.n_first);
+            const h16* rh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+        }
+    }
+    uint4 outraw;
+    h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        o[j] = (h16)v[j];
+        const float f = (float)o[j];
+        gs[j] += f;
+        gq[j] += f * f;
+    }
+    bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)m * p.ldc + c.n_first, outraw);
+}
+
 }  // namespace bcg
 
 // gemm_fast.hip: returns 0 when it launched the GEMM, -1 when the problem is outside its fast path, >0 on error.

@@ -231,81 +231,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
     const int n_first = (geglu ? n0 / 2 : n0) + c_out;
     const bool nok = n_first < g.n_out;
     const int cv = geglu ? (c_out >> 5) * 64 + (c_out & 31) : c_out;      // tile column of the (value) accumulators
-    float bias_v[8], bias_g[8], cs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bias_v[j] = (p.bias && nok) ? p.bias[n0 + cv + j] : 0.f;
-        bias_g[j] = (geglu && p.bias && nok) ? p.bias[n0 + cv + 32 + j] : 0.f;
-        cs[j] = ((p.colscale && nok) ? p.colscale[n_first + j] : 1.f) * alpha;
-    }
+    Cols8 cols;
+    cols8_init(g, cols, n_first, n0 + cv, geglu, alpha);
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
-    const h16* R = reinterpret_cast<const h16*>(p.R);
-    const h16* R2 = reinterpret_cast<const h16*>(p.R2);
-    const h16* RV = reinterpret_cast<const h16*>(p.rowvec);
-    h16* Cout = reinterpret_cast<h16*>(p.C);
     for (int row = tid / CPR; row < BM; row += rstep) {
         const int m = m0 + row;
         if (m < p.M && nok) {
             const float4 lo = *reinterpret_cast<const float4*>(tile + row * BN + cv);
             const float4 hi = *reinterpret_cast<const float4*>(tile + row * BN + cv + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias_v[j];
-            int b = 0, pix = m;
-            if (RV || R2) {
-                b = (int)fdiv((unsigned)m, g.div_rpb);
-                pix = m - b * (int)g.div_rpb.d;
-            }
-            if (RV) {
-                const uint4 raw = bc_ld16(RV + (size_t)b * p.ld_rowvec + n_first);
-                const h16* rh = reinterpret_cast<const h16*>(&raw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-            }
+            float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (geglu) {
                 const float4 glo = *reinterpret_cast<const float4*>(tile + row * BN + cv + 32);
                 const float4 ghi = *reinterpret_cast<const float4*>(tile + row * BN + cv + 36);
-                const float gt[8] = {glo.x, glo.y, glo.z, glo.w, ghi.x, ghi.y, ghi.z, ghi.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= bc_gelu_f(gt[j] + bias_g[j]);
-            } else if (p.act == BC_ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
-            } else if (p.act == BC_ACT_SILU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+                gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
+                gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= cs[j];
-            if (R) {
-                const uint4 raw = bc_ld16(R + (size_t)m * p.ldr + n_first);
-                const h16* rh = reinterpret_cast<const h16*>(&raw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-            }
-            if (R2) {
-                const int y = (int)fdiv((unsigned)pix, g.div_outw);
-                const int x = pix - y * (int)g.div_outw.d;
-                if (x >= p.r2_xmin) {
-                    const int bb = b % p.r2_bmod;
-                    const uint4 raw = bc_ld16(R2 + ((size_t)bb * g.div_rpb.d + pix) * p.ldr2 + n_first);
-                    const h16* rh = reinterpret_cast<const h16*>(&raw);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-                }
-            }
-            uint4 outraw;
-            h16* o = reinterpret_cast<h16*>(&outraw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                o[j] = (h16)v[j];
-                const float f = (float)o[j];
-                gs[j] += f;
-                gq[j] += f * f;
-            }
-            bc_st16(Cout + (size_t)m * p.ldc + n_first, outraw);
+            epi8_store(g, cols, v, gt, m, gs, gq);
         }
     }
     if (p.gn_part) {

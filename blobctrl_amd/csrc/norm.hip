@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int GN_PIX_PER_SLAB = 64;
+constexpr int GN_PIX_PER_SLAB = 16;     // stand-alone statistics pass: small slabs => enough workgroups for 256 CUs
 constexpr int GN_MAX_GROUPS = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -209,8 +209,10 @@ class Recorder:
             rpb = rows_per_batch if rows_per_batch > 0 else (conv["Hout"] * conv["Wout"] if conv else M)
             vec = out_mode == _lib.OUT_F16 and n_out % 8 == 0 and g.ldc % 8 == 0 and (R is None or ldr % 8 == 0) and \
                 (R2 is None or ldr2 % 8 == 0)
-            if fast and vec and sk == 1 and rpb % bm == 0 and M % rpb == 0 and not os.environ.get("BC_GEMM_TILE"):
-                nslab = rpb // bm
+            slab_rows = bm if sk == 1 else 32
+            if vec and (fast or sk > 1) and N % 4 == 0 and rpb % slab_rows == 0 and M % rpb == 0 and \
+                    not os.environ.get("BC_GEMM_TILE"):
+                nslab = rpb // slab_rows
                 part = self.empty(M // rpb, nslab, n_out, 2, dtype=torch.float32)
                 g.gn_part = part.data_ptr()
                 self.parts[g.C] = (part, nslab)
@@ -247,7 +249,7 @@ class Recorder:
             if hit is not None and hit[0].shape[2] == c:
                 srcs.append((hit[0], hit[1]))
             else:
-                nslab = (HW + 63) // 64
+                nslab = (HW + 15) // 16
                 part = self.empty(B, nslab, c, 2, dtype=torch.float32)
                 stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
                 srcs.append((part, nslab))

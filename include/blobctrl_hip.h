@@ -82,8 +82,9 @@ typedef struct BcGemm {
     int splitk;              /* >=1 ; >1 needs `slab` of splitk*M*N floats */
     float* slab;
     /* ---- optional fused GroupNorm statistics of the (fp16-rounded) OUTPUT: per-channel (sum, sumsq) partials
-     *      gn_part[B][rows_per_batch / bm (bm from bc_gemm_plan)][n_out][2]; needs splitk == 1, BC_OUT_F16, K % 64 == 0,
-     *      rows_per_batch % tile_rows == 0.  Consumed by bc_gn_finalize (replaces the bc_gn_stats pass). ---- */
+     *      gn_part[B][rows_per_batch / slab_rows][n_out][2], slab_rows = bm of bc_gemm_plan when splitk == 1 (fast path only)
+     *      or 32 when splitk > 1 (emitted by the split-K reducer).  Needs BC_OUT_F16, widths % 8 == 0 and
+     *      rows_per_batch % slab_rows == 0.  Consumed by bc_gn_finalize (replaces the bc_gn_stats pass). ---- */
     float* gn_part;
     /* ---- tile configuration: 0 = library heuristic, else one of BC_TILE_* (see bc_gemm_plan) ---- */
     int tile_cfg;
@@ -103,7 +104,7 @@ int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int*
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
  * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
  * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
- *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/64)][C][2] (no atomics: bit-reproducible).
+ *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/16)][C][2] (no atomics: bit-reproducible).
  *                    Only needed when the producing GEMM did not emit them itself (BcGemm.gn_part).
  *   bc_gn_finalize : per-channel affine of the concat (x1 | x2): ab[B][C1+C2][2] = (rstd*gamma, beta - mean*rstd*gamma),
  *                    from part_i[B][nslab_i][C_i][2] (part2 may be NULL)
