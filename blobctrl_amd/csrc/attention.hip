@@ -14,6 +14,7 @@
 //   V arrives TRANSPOSED from the to_v GEMM epilogue (BC_OUT_F16_T), so the V^T tile is a coalesced row copy.
 //   When D is not a multiple of 32 the padded V^T tile carries a row of ones, which makes the MFMA produce the softmax
 //   denominator for free (removes 32 v_add per tile from the VALU-bound D=40 case).
+#include <type_traits>
 #include "bc_common.h"
 
 namespace {
@@ -96,9 +97,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int ntiles = (Nkv + KVT - 1) / KVT;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int kbase = tile * KVT;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    union PFrag { h16x8 v; h16x2 p[4]; };
+
+    // one KV tile; MASKED = the tile holds keys >= Nkv (only ever the last one) -> kept out of the steady-state code path
+    auto process_tile = [&](const int kbase, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         __syncthreads();     // previous tile fully consumed (also orders the constant-part stores before first use)
         // ---- stage K tile: KVT keys x D (row copy, 16-byte chunks) ----
         {
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
             for (int i = tid; i < KVT * CH; i += 256) {
                 int key = i / CH, ch = i % CH;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (kbase + key < Nkv) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
+                if (!MASKED || kbase + key < Nkv) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
                 bc_st16(ldsK + key * C::K_STRIDE + ch * 8, v);
             }
         }
@@ -136,8 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kt], 0, 0, 0);
             }
         }
-        // mask keys beyond Nkv (last tile only)
-        if (kbase + KVT > Nkv) {
+        if (MASKED) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -155,29 +158,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         // m_new is finite as soon as one valid key was seen (every tile has >= 1 valid key)
-        const float alpha = exp2f(m_run - m_new);
+        const bool grew = m_new != m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
-        h16x8 pf[2][2];
+        PFrag pf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float pv = exp2f(sacc[kt][8 * s2 + j] - m_new);
-                    h16 ph = (h16)pv;
-                    pf[kt][s2][j] = ph;
-                    if (!C::ONES) psum += (float)ph;
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x2 e;
+                    e.x = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj] - m_new);
+                    e.y = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj + 1] - m_new);
+                    pf[kt][s2].p[jj] = __builtin_convertvector(e, h16x2);
+                    if (!C::ONES) psum += e.x + e.y;
                 }
         if (!C::ONES) {
             psum += __shfl_xor(psum, 32);
             l_run = l_run * alpha + psum;
         }
+        // rescale the running output only when some query of this wave saw a new maximum (wave-uniform branch; after the
+        // first few tiles the maximum rarely moves, so the steady state skips DT*16 multiplies per lane)
+        if (__any(grew)) {
 #pragma unroll
-        for (int t = 0; t < C::DT; ++t)
+            for (int t = 0; t < C::DT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
 
         // ---- O^T[t] += V^T_tile[t] . P^T ;  A fragment element j of lane-half h must be key 16 s2 + 8 (j>>2) + 4 h + (j&3) ----
 #pragma unroll
@@ -192,10 +201,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
                     h16x8 vf;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][s2], oacc[t], 0, 0, 0);
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][s2].v, oacc[t], 0, 0, 0);
                 }
         }
-    }
+    };
+
+    const int nfull = Nkv / KVT;
+    for (int tile = 0; tile < nfull; ++tile) process_tile(tile * KVT, std::false_type{});
+    if (nfull * KVT < Nkv) process_tile(nfull * KVT, std::true_type{});
 
     // ---- epilogue: O[q][dd] = O^T[dd][q] / l ----
     float l = l_run;
