@@ -225,7 +225,8 @@ class Recorder:
                 _lib.check(rc, "bc_gemm")
 
         self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part))
-        variant = ("gemm_fast<" if fast else "gemm_generic<") + _lib.TILE_NAMES[cfg] + ">" + ("+splitk" if sk > 1 else "")
+        variant = ("gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
+            ("+splitk_reduce" if sk > 1 else "")
         self._push(fn, kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out
 
