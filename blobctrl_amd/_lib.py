@@ -68,6 +68,8 @@ _SIGNATURES = {
     "bc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bc_graph_destroy": (C.c_int, [C.c_void_p]),
     "bc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bc_event_create_sync": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bc_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "bc_event_destroy": (C.c_int, [C.c_void_p]),

@@ -20,8 +20,6 @@
 namespace {
 
 constexpr int QW = 32;        // queries per wave
-constexpr int NWAVE = 4;
-constexpr int QB = QW * NWAVE;  // queries per workgroup
 constexpr int KVT = 64;       // keys per tile
 
 template <int D>
@@ -36,8 +34,10 @@ struct AttnCfg {
     static constexpr int LDS_BYTES = (KVT * K_STRIDE + DP * V_STRIDE) * 2;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
+// NW = waves (x 32 queries) per workgroup: 4 for long sequences; 2 or 1 when the (query-block, head, batch) grid would
+// otherwise leave most of the 256 CUs idle (N = 512 / 128 tokens at batch 1).
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                          const h16* __restrict__ Vt, h16* __restrict__ O, int Nq, int Nkv,
                                                          int ldq, int ldk, int ldvt, int ldo, long long q_bs, long long k_bs,
                                                          long long vt_bs, long long o_bs, float scale_log2e) {
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qcol = lane & 31, half = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB + wave * QW;
+    constexpr int NT = 64 * NW;
+    const int q0 = blockIdx.x * (QW * NW) + wave * QW;
 
     const h16* Qb = Q + (size_t)b * q_bs + (size_t)head * D;
     const h16* Kb = K + (size_t)b * k_bs + (size_t)head * D;
@@ -78,13 +79,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
 
     // ---- constant parts of the LDS tiles: K pad columns, V^T pad rows (ones row first) ----
     if (C::DK > D) {
-        for (int i = tid; i < KVT * ((C::DK - D) / 8); i += 256) {
+        for (int i = tid; i < KVT * ((C::DK - D) / 8); i += NT) {
             int key = i / ((C::DK - D) / 8), ch = i % ((C::DK - D) / 8);
             bc_st16(ldsK + key * C::K_STRIDE + D + ch * 8, make_uint4(0, 0, 0, 0));
         }
     }
     if (C::DP > D) {
-        for (int i = tid; i < (C::DP - D) * KVT; i += 256) {
+        for (int i = tid; i < (C::DP - D) * KVT; i += NT) {
             int r = D + i / KVT, c = i % KVT;
             ldsV[r * C::V_STRIDE + c] = (C::ONES && r == D) ? (h16)1.0f : (h16)0.f;
         }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
         // ---- stage K tile: KVT keys x D (row copy, 16-byte chunks) ----
         {
             constexpr int CH = D / 8;
-            for (int i = tid; i < KVT * CH; i += 256) {
+            for (int i = tid; i < KVT * CH; i += NT) {
                 int key = i / CH, ch = i % CH;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (!MASKED || kbase + key < Nkv) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
         // ---- stage V^T tile: D rows x KVT keys (padding of Vt beyond Nkv is zero by contract) ----
         {
             constexpr int CH = KVT / 8;
-            for (int i = tid; i < D * CH; i += 256) {
+            for (int i = tid; i < D * CH; i += NT) {
                 int r = i / CH, ch = i % CH;
                 uint4 v = bc_ld16(Vb + (size_t)r * ldvt + kbase + ch * 8);
                 // V_STRIDE*2 bytes = 136 is only 8-byte aligned: store as two 8-byte halves
@@ -237,16 +238,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const h16* __restrict__ Q
     }
 }
 
+template <int D, int NW>
+int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
+                   int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
+                   hipStream_t stream) {
+    using C = AttnCfg<D>;
+    dim3 grid(bc_ceil_div(Nq, QW * NW), heads, B), block(64 * NW);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
+                       qbs, kbs, vbs, obs, scale * 1.4426950408889634f);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int D>
 int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                 int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
                 hipStream_t stream) {
-    using C = AttnCfg<D>;
-    dim3 grid(bc_ceil_div(Nq, QB), heads, B), block(256);
-    hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
-                       qbs, kbs, vbs, obs, scale * 1.4426950408889634f);
-    BC_CHECK_LAUNCH();
-    return 0;
+    const long long per = (long long)heads * B;
+    if (bc_ceil_div(Nq, 128) * per >= 384)
+        return launch_attn_nw<D, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    if (bc_ceil_div(Nq, 64) * per >= 256)
+        return launch_attn_nw<D, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    return launch_attn_nw<D, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
 }
 
 }  // namespace

@@ -39,7 +39,7 @@ extern "C" int bc_graph_end(bc_stream stream, void** graph_exec_out) {
     BC_CHECK_HIP(hipStreamEndCapture(reinterpret_cast<hipStream_t>(stream), &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) {
         bc_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
         return 2;
@@ -64,6 +64,19 @@ extern "C" int bc_event_create(void** ev) {
     hipEvent_t e;
     BC_CHECK_HIP(hipEventCreate(&e));
     *ev = e;
+    return 0;
+}
+
+extern "C" int bc_event_create_sync(void** ev) {
+    BC_CHECK_ARG(ev != nullptr, "bc_event_create_sync: null output");
+    hipEvent_t e;
+    BC_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return 0;
+}
+
+extern "C" int bc_stream_wait_event(bc_stream stream, void* ev) {
+    BC_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(ev), 0));
     return 0;
 }
 

@@ -48,7 +48,7 @@ class Residuals:
     mid: torch.Tensor
     up: List[torch.Tensor]
     bmod: int
-    xmin_of: callable = None
+    events: Optional[dict] = None        # data_ptr -> event signalled by the producer (two-stream execution)
 
 
 class TrunkPlan:
@@ -64,6 +64,10 @@ class TrunkPlan:
         """kwargs for the BlobNet residual add on an H x W output."""
         if res_t is None:
             return {}
+        if self.res_events is not None:
+            ev = self.res_events.get(res_t.data_ptr())
+            if ev is not None:
+                self.rec.wait(ev)         # the BlobNet branch (side stream) has produced this residual
         xmin = 0 if W == H else W - H
         return dict(R2=res_t, ldr2=res_t.shape[-1], r2_xmin=xmin, r2_bmod=self.res_bmod, out_w=W)
 
@@ -196,7 +200,8 @@ class TrunkPlan:
         self.tproj = self.dense(h, B, te, "temb_all", pw.temb_total, kind="temb")
 
     # ------------------------------------------------------------------------------------------- forward
-    def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None):
+    def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,
+                       signal_residuals: bool = False):
         """x_in: [B, H*W, pad8(in_channels)] fp16.  UNet: returns eps fp32 [B, H*W, out_channels].
         BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx))."""
         cfg, pw = self.cfg, self.pw
@@ -206,8 +211,32 @@ class TrunkPlan:
         res_d = list(residuals.down) if residuals is not None else None
         res_u = list(residuals.up) if residuals is not None else None
         self.res_bmod = residuals.bmod if residuals is not None else 1
+        self.res_events = residuals.events if residuals is not None else None
         pop = (lambda lst: lst.pop(0)) if residuals is not None else (lambda lst: None)
-        feats_d, feats_u = [], []
+        alpha, alpha_dev, alpha_idx = zero_scale if zero_scale is not None else (1.0, None, None)
+        out_events = {} if signal_residuals else None
+
+        class _Feats(list):
+            """BlobNet: every trunk feature is turned into its residual (zero-conv 1x1, bn:860-864, 881, 921-924, times
+            conditioning_scale, bn:936-938) as soon as it exists, so the UNet branch can consume it while BlobNet runs on."""
+            def __init__(s2, prefix):
+                super().__init__()
+                s2.prefix, s2.res = prefix, []
+
+            def append(s2, f):
+                super().append(f)
+                if cfg.is_blobnet:
+                    name = s2.prefix if s2.prefix.endswith("mid_block") else f"{s2.prefix}.{len(s2) - 1}"
+                    M = self.B * f.H * f.W
+                    r = self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
+                                   alpha_idx=alpha_idx).view(self.B, f.H * f.W, f.C)
+                    if out_events is not None:
+                        ev = self.rec.new_event()
+                        self.rec.signal(ev)
+                        out_events[r.data_ptr()] = ev
+                    s2.res.append(r)
+
+        feats_d, feats_u, feats_m = _Feats("blobnet_down_blocks"), _Feats("blobnet_up_blocks"), _Feats("blobnet_mid_block")
 
         x = Act(x_in, pad8(cfg.in_channels), H, W)
         if residuals is not None and W == H:
@@ -239,6 +268,7 @@ class TrunkPlan:
         h = self.transformer("mid_block.attentions.0.", h)
         h = self.resnet("mid_block.resnets.1.", h, None, boc[-1], r2=residuals.mid if residuals is not None else None)
         feat_mid = h
+        feats_m.append(h)
         rev = list(reversed(boc))
         for i in range(nb):
             has_attn = i > 0
@@ -261,20 +291,9 @@ class TrunkPlan:
             n = self.groupnorm(h, None, "conv_norm_out", 1e-5, True)
             eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out")
             return eps.t
-        # BlobNet: zero-convs (bn:860-864, 881, 921-924) scaled by conditioning_scale (bn:936-938)
-        alpha, alpha_dev, alpha_idx = zero_scale if zero_scale is not None else (1.0, None, None)
-
-        def zc(name, f: Act):
-            M = self.B * f.H * f.W
-            return self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
-                              alpha_idx=alpha_idx).view(self.B, f.H * f.W, f.C)
-
-        down = [zc(f"blobnet_down_blocks.{k}", f) for k, f in enumerate(feats_d)]
-        mid = zc("blobnet_mid_block", feat_mid)
-        up = [zc(f"blobnet_up_blocks.{k}", f) for k, f in enumerate(feats_u)]
         self.feat_shapes = ([(f.C, f.H, f.W) for f in feats_d], (feat_mid.C, feat_mid.H, feat_mid.W),
                             [(f.C, f.H, f.W) for f in feats_u])
-        return Residuals(down, mid, up, bmod=self.B)
+        return Residuals(feats_d.res, feats_m.res[0], feats_u.res, bmod=self.B, events=out_events)
 
 
 def _ptr(t):

@@ -45,21 +45,26 @@ class Segment:
         self.flops = 0          # algorithmic 2*MAC of the GEMM / attention launches recorded here
         self.kinds = {}
         self.meta = []          # per call: dict(kind, flops, variant)
+        self.sids = []          # per call: 0 = main stream, 1 = side stream
 
-    def run(self, stream: int):
+    def run(self, stream: int, side: int = None):
+        """Replay on `stream`; launches recorded for the side stream go to `side` (default: same stream, i.e. serial)."""
         if self.graph is not None:
             _lib.check(_lib.load().bc_graph_launch(self.graph, stream), "bc_graph_launch")
             return
-        for fn in self.calls:
-            fn(stream)
+        streams = (stream, side if side is not None else stream)
+        for fn, sid in zip(self.calls, self.sids):
+            fn(streams[sid])
 
-    def capture(self, stream: int):
-        """Capture this segment into a hipGraph on `stream` (a non-default stream)."""
+    def capture(self, stream: int, side: int = None):
+        """Capture this segment into a hipGraph on `stream` (a non-default stream).  Side-stream work joins the capture
+        through the recorded fork / signal / wait events and becomes parallel branches of the graph."""
         lib = _lib.load()
+        streams = (stream, side if side is not None else stream)
         _lib.check(lib.bc_graph_begin(stream), "bc_graph_begin")
         try:
-            for fn in self.calls:
-                fn(stream)
+            for fn, sid in zip(self.calls, self.sids):
+                fn(streams[sid])
         finally:
             g = C.c_void_p()
             rc = lib.bc_graph_end(stream, C.byref(g))
@@ -71,7 +76,7 @@ class Segment:
         kernels run on).  Returns a list of (meta, milliseconds)."""
         lib = _lib.load()
         evs = []
-        for fn in self.calls:
+        for fn in self.calls:          # serial replay on ONE stream: isolates every kernel for the timing table
             a, b = C.c_void_p(), C.c_void_p()
             _lib.check(lib.bc_event_create(C.byref(a)), "bc_event_create")
             _lib.check(lib.bc_event_create(C.byref(b)), "bc_event_create")
@@ -107,6 +112,8 @@ class Recorder:
         self.num_cu = info[0]
         self.bytes_allocated = 0
         self.parts = {}                     # data_ptr of a GEMM output -> (per-channel GroupNorm partials, nslab)
+        self.sid = 0                        # stream id new launches are recorded for (0 main, 1 side)
+        self.events = []
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float16):
@@ -123,8 +130,36 @@ class Recorder:
         self.seg = Segment(name)
         return self.seg
 
+    # ------------------------------------------------------------------ streams / events
+    def new_event(self):
+        e = C.c_void_p()
+        _lib.check(self.lib.bc_event_create_sync(C.byref(e)), "bc_event_create_sync")
+        self.events.append(e)
+        return e
+
+    def signal(self, ev):
+        """Record `ev` on the stream currently being recorded for."""
+        lib = self.lib
+
+        def fn(stream):
+            rc = lib.bc_event_record(ev, stream)
+            if rc:
+                _lib.check(rc, "bc_event_record")
+        self._push(fn, "event_record")
+
+    def wait(self, ev):
+        """Make the stream currently being recorded for wait on `ev`."""
+        lib = self.lib
+
+        def fn(stream):
+            rc = lib.bc_stream_wait_event(stream, ev)
+            if rc:
+                _lib.check(rc, "bc_stream_wait_event")
+        self._push(fn, "event_wait")
+
     def _push(self, fn, kind, flops=0, variant="", shape=None):
         self.seg.calls.append(fn)
+        self.seg.sids.append(self.sid)
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
         self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape))

@@ -14,6 +14,7 @@ Execution model: one static launch plan per (batch, canvas, steps) configuration
 each captured once into a hipGraph and replayed per step; per-step scalars (timestep, scheduler coefficients,
 conditioning scale) live in device tables indexed by a device-side step counter.
 """
+import os
 from typing import List, Optional, Union
 
 import torch
@@ -49,6 +50,8 @@ class StableDiffusionBlobNetPipeline:
         self.scheduler_kind = scheduler
         self.use_graphs = use_graphs
         self.stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
+        self.two_streams = not os.environ.get("BC_ONE_STREAM")
         self._plans = {}
         self.feat_dim = blobnet_config.in_channels - 5
 
@@ -105,12 +108,20 @@ class StableDiffusionBlobNetPipeline:
             rec._push(step_fn, "cfg_step")
 
         # ---- step A: BlobNet + UNet
+        # The BlobNet branch is recorded for the side stream: fork (side waits for the start of the step on main), every
+        # residual is signalled when its zero-conv finishes, the UNet waits right before the GEMM whose epilogue adds it.
         P.step_active = rec.begin("step_active")
+        fork = rec.new_event()
+        rec.signal(fork)
+        rec.sid = 1
+        rec.wait(fork)
         rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
                  P.feat.data_ptr() if F > 0 else None, 1, F, B, h, w, blob_cin, P.blob_in.data_ptr(), kind="assemble")
         blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
         blob.record_time(P.t_table, P.step_idx)
-        residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx))
+        residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx),
+                                        signal_residuals=True)
+        rec.sid = 0
         P.residuals = residuals
         record_unet(unet_a, residuals)
         P.eps_active = P.eps
@@ -128,18 +139,22 @@ class StableDiffusionBlobNetPipeline:
     def _capture(self, P):
         if P.captured or not self.use_graphs:
             return
-        s = self.stream.cuda_stream
+        s, side = self._streams()
         # warm-up run outside capture (module loading, attribute setting) then capture each segment once
         torch.cuda.synchronize(self.device)
         for seg in (P.step_active, P.step_inactive):
             with torch.cuda.stream(self.stream):
                 P.step_idx.zero_()
-            seg.run(s)
-        self.stream.synchronize()
+            seg.run(s, side)
+        torch.cuda.synchronize(self.device)
         for seg in (P.step_active, P.step_inactive):
-            seg.capture(s)
-        self.stream.synchronize()
+            seg.capture(s, side)
+        torch.cuda.synchronize(self.device)
         P.captured = True
+
+    def _streams(self):
+        s = self.stream.cuda_stream
+        return s, (self.side_stream.cuda_stream if self.two_streams else s)
 
     # ------------------------------------------------------------------------------------------------ call
     def check_inputs(self, blobnet_conditioning_scale, start, end, num_inference_steps):
@@ -203,7 +218,7 @@ class StableDiffusionBlobNetPipeline:
             P.step_idx.zero_()
             P.hist.zero_()
         P.guidance[0] = float(guidance_scale)
-        s = self.stream.cuda_stream
+        s, side = self._streams()
         self.stream.synchronize()
         if teacher_latents is None and callback_on_step_end is None and trace is None:
             self._capture(P)
@@ -218,14 +233,14 @@ class StableDiffusionBlobNetPipeline:
                 with torch.cuda.stream(self.stream):
                     P.latents.copy_(teacher_latents[i].to(dev, torch.float32))
             seg = P.step_active if scales[i] != 0.0 else P.step_inactive
-            seg.run(s)
+            seg.run(s, side)
             if trace is not None:
                 self.stream.synchronize()
                 trace.append((P.eps_guided.clone(), P.latents.clone()))
             if callback_on_step_end is not None:
                 self.stream.synchronize()
                 callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
-        self.stream.synchronize()
+        torch.cuda.synchronize(self.device)
         return P.latents.clone()
 
     # convenience for bench / tests ------------------------------------------------------------------

@@ -188,6 +188,11 @@ int bc_graph_end(bc_stream stream, void** graph_exec_out);
 int bc_graph_launch(void* graph_exec, bc_stream stream);
 int bc_graph_destroy(void* graph_exec);
 
+/* Cross-stream dependencies (BlobNet and the UNet run concurrently on two streams; inside a captured graph these become
+ * DAG edges).  bc_event_create_sync makes a timing-disabled event. */
+int bc_event_create_sync(void** ev);
+int bc_stream_wait_event(bc_stream stream, void* ev);
+
 /* HIP-event timing on an arbitrary stream (torch.cuda.Event only sees torch's current stream). */
 int bc_event_create(void** ev);
 int bc_event_record(void* ev, bc_stream stream);
