@@ -254,12 +254,9 @@ template <int D>
 int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                 int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
                 hipStream_t stream) {
-    const long long per = (long long)heads * B;
-    if (bc_ceil_div(Nq, 128) * per >= 384)
-        return launch_attn_nw<D, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
-    if (bc_ceil_div(Nq, 64) * per >= 256)
-        return launch_attn_nw<D, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
-    return launch_attn_nw<D, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    // Measured on MI355X: splitting short sequences over more, smaller workgroups (NW = 2 / 1) is SLOWER (every workgroup
+    // re-stages the whole K / V with fewer threads: D=160, N=512: 18 vs 35 TFLOP/s), so the 4-wave form is always used.
+    return launch_attn_nw<D, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
 }
 
 }  // namespace

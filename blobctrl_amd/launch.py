@@ -105,8 +105,8 @@ class Recorder:
         self.device = device
         self.seg: Optional[Segment] = None
         self.keep = []                      # keeps ctypes blocks / tensors alive
-        self._slab = None
-        self._slab_elems = 0
+        self._slab = [None, None]           # split-K scratch PER STREAM (the two branches run concurrently)
+        self._slab_elems = [0, 0]
         info = (C.c_int * 4)()
         _lib.check(self.lib.bc_device_info(info), "bc_device_info")
         self.num_cu = info[0]
@@ -164,16 +164,13 @@ class Recorder:
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
         self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape))
 
-    def slab(self, elems: int):
-        """Shared split-K scratch: consumed by the reduce kernel that immediately follows on the same stream."""
-        if elems > self._slab_elems:
-            raise RuntimeError("split-K slab requested after planning froze its size")
-        return self._slab
-
     def reserve_slab(self, elems: int):
-        if elems > self._slab_elems:
-            self._slab = torch.empty(elems, dtype=torch.float32, device=self.device)
-            self._slab_elems = elems
+        """Shared split-K scratch of the CURRENT stream: consumed by the reduce kernel that immediately follows on that
+        stream, so one buffer per stream is enough."""
+        sid = self.sid
+        if elems > self._slab_elems[sid]:
+            self._slab[sid] = torch.empty(elems, dtype=torch.float32, device=self.device)
+            self._slab_elems[sid] = elems
 
     # ------------------------------------------------------------------ GEMM family
     def plan_gemm(self, M, N, K, fast, mode, tile_cfg=0, splitk=None):
@@ -252,9 +249,11 @@ class Recorder:
                 g.gn_part = part.data_ptr()
                 self.parts[g.C] = (part, nslab)
 
+        sid = self.sid
+
         def fn(stream, g=g, lib=self.lib):
             if g.splitk > 1:
-                g.slab = rec._slab.data_ptr()
+                g.slab = rec._slab[sid].data_ptr()
             rc = lib.bc_gemm(C.byref(g), stream)
             if rc:
                 _lib.check(rc, "bc_gemm")
