@@ -1,0 +1,55 @@
+"""Full-size (SD-1.5 / BlobNet, 512x512 canvas 64x128) parity of ONE denoise step against the CPU oracle on the same
+seeded synthetic weights and inputs: the BASELINE.json tolerance (PSNR >= 40 dB, max-abs <= 1e-2 of the tensor scale) at the
+benchmark's own problem size.  ~1 minute of host CPU time for the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import g, psnr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    from oracle.nets import NetConfig
+    usd, bsd = bench.synth_weights()
+    ucfg, bcfg = bench.full_configs()
+    return dict(usd=usd, bsd=bsd, ucfg=ucfg, bcfg=bcfg, oucfg=NetConfig(in_channels=5, cross_attention_dim=768),
+                obcfg=NetConfig(in_channels=1029, cross_attention_dim=None))
+
+
+def test_full_size_blobnet_and_unet_step(full):
+    from blobctrl_amd.modules import BlobNetModel, UNet2DConditionModel
+    from oracle.nets import blobnet_forward, unet_forward
+    torch.set_num_threads(min(32, len(__import__("os").sched_getaffinity(0))))
+    h, w = 64, 128
+    t = torch.tensor(601)
+    # ---- BlobNet at batch 1 (how the engine runs it) ----
+    xb = torch.cat([g(1, 1, 4, h, w), g(2, 1, 1, h, w).abs().clamp(max=1), g(3, 1, 1024, h, w) * 0.3], 1)
+    blobnet = BlobNetModel(full["bsd"], full["bcfg"])
+    down, mid, up = blobnet(xb.cuda(), t, conditioning_scale=1.0, return_dict=False)
+    rd, rm, ru = blobnet_forward(full["bsd"], full["obcfg"], xb, t, 1.0)
+    worst = 0.0
+    for a, b in list(zip(down, rd)) + [(mid, rm)] + list(zip(up, ru)):
+        a, b = a.float().cpu().numpy(), b.numpy()
+        scale = max(np.abs(b).max(), 1e-6)
+        worst = max(worst, np.abs(a - b).max() / scale)
+        assert psnr(a, b) > 40.0
+    assert worst < 1e-2, f"BlobNet residual max-abs/scale {worst:.3e}"
+    # ---- UNet at CFG batch 2 with the ORACLE's residuals (isolates the UNet) ----
+    xu = g(4, 2, 5, h, w)
+    ehs = g(5, 2, 77, 768)
+    sq = lambda r: r[..., -r.shape[-2]:].contiguous()
+    rd2 = [sq(r).repeat(2, 1, 1, 1) for r in rd]
+    rm2 = sq(rm).repeat(2, 1, 1, 1)
+    ru2 = [sq(r).repeat(2, 1, 1, 1) for r in ru]
+    ref = unet_forward(full["usd"], full["oucfg"], xu, t, ehs, rd2, rm2, ru2).numpy()
+    unet = UNet2DConditionModel(full["usd"], full["ucfg"])
+    eps = unet(xu.cuda(), t, encoder_hidden_states=ehs.cuda(), down_block_add_samples=[r.cuda() for r in rd2],
+               mid_block_add_sample=rm2.cuda(), up_block_add_samples=[r.cuda() for r in ru2], return_dict=False)[0]
+    eps = eps.float().cpu().numpy()
+    err = np.abs(eps - ref).max() / np.abs(ref).max()
+    print(f"full-size UNet eps: max-abs/scale {err:.3e}, PSNR {psnr(eps, ref):.1f} dB; BlobNet residuals worst {worst:.3e}")
+    assert err < 1e-2 and psnr(eps, ref) > 40.0
