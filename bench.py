@@ -177,8 +177,8 @@ def main():
     from blobctrl_amd.weights import PackedTrunk
     import torch.distributed as tdist
 
-    rank, world, local = bdist.init_from_env()
-    dev = torch.device(f"cuda:{local}")
+    rank, world, local = bdist.init_from_env(os.environ.get("BC_DIST_BACKEND"))
+    dev = torch.device(f"cuda:{local % max(1, torch.cuda.device_count())}")   # (modulo: lets a 1-GPU box exercise N > 1 with gloo)
     torch.cuda.set_device(dev)
     ucfg, bcfg = full_configs()
     h = w = args.res // 8

@@ -29,13 +29,23 @@ struct AttnCfg {
     static constexpr int DT = (D + 31) / 32;           // O^T row tiles
     static constexpr int DP = DT * 32;
     static constexpr bool ONES = (D % 32) != 0;        // spare padded V^T row available for the row sum
+    static constexpr bool BIAS = (D % 16) != 0;        // spare padded K column available: K[:, D] = 1, Q[:, D] = -m_ref
     static constexpr int K_STRIDE = DK + 8;            // halfs; (DK/8 + 1) odd 16-byte slots -> conflict-free ds_read_b128
     static constexpr int V_STRIDE = KVT + 4;           // halfs; 17 x 8-byte slots -> conflict-free ds_read_b64
-    static constexpr int LDS_BYTES = (KVT * K_STRIDE + DP * V_STRIDE) * 2;
+    static constexpr int STAGE_HALFS = KVT * K_STRIDE + DP * V_STRIDE;
+    static constexpr int LDS_BYTES = 2 * STAGE_HALFS * 2;          // two stages
 };
 
-// NW = waves (x 32 queries) per workgroup: 4 for long sequences; 2 or 1 when the (query-block, head, batch) grid would
-// otherwise leave most of the 256 CUs idle (N = 512 / 128 tokens at batch 1).
+constexpr float RESCALE_THR = 6.0f;    // log2 units: P <= 64 between reference updates (fp16 P, fp32 accumulation)
+
+// NW = waves (x 32 queries) per workgroup.
+//
+// Pipeline: K / V^T tiles are double-buffered in LDS; the global loads of tile t+1 are issued into registers before tile t is
+// multiplied and written to the other LDS stage afterwards (one barrier per tile, HBM/L2 latency hidden under the MFMAs).
+// Softmax reference: instead of subtracting the running maximum from every score (32 VALU ops per tile and lane), the kernel
+// keeps a per-query reference m_ref and, when head_dim leaves a padded K column (D = 40: columns 40..47), lets the MFMA do the
+// subtraction: K[:, D] = 1 and Q[:, D] = -m_ref (fp16; any consistent reference is valid for online softmax).  m_ref only moves
+// when a score exceeds it by more than RESCALE_THR (wave-uniform slow path), so the steady state is exp2 + max + pack only.
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                          const h16* __restrict__ Vt, h16* __restrict__ O, int Nq, int Nkv,
@@ -43,8 +53,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
                                                          long long vt_bs, long long o_bs, float scale_log2e) {
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    h16* ldsK = reinterpret_cast<h16*>(smem);                       // [KVT][K_STRIDE]
-    h16* ldsV = ldsK + KVT * C::K_STRIDE;                           // [DP][V_STRIDE]
+    h16* lds = reinterpret_cast<h16*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qcol = lane & 31, half = lane >> 5;
@@ -76,60 +85,88 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
             qf[s] = v;
         }
     }
+    // the bias slot: column D of the padded head_dim lives in fragment D/16, lane-half (D%16)/8, element D%8
+    constexpr int BS = D / 16, BH = (D % 16) / 8, BJ = D % 8;
 
-    // ---- constant parts of the LDS tiles: K pad columns, V^T pad rows (ones row first) ----
-    if (C::DK > D) {
-        for (int i = tid; i < KVT * ((C::DK - D) / 8); i += NT) {
-            int key = i / ((C::DK - D) / 8), ch = i % ((C::DK - D) / 8);
-            bc_st16(ldsK + key * C::K_STRIDE + D + ch * 8, make_uint4(0, 0, 0, 0));
+    // ---- constant parts of both LDS stages: K pad columns (column D = 1 when BIAS), V^T pad rows (row D = ones when ONES) ----
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        h16* ldsK = lds + st * C::STAGE_HALFS;
+        h16* ldsV = ldsK + KVT * C::K_STRIDE;
+        if (C::DK > D) {
+            for (int i = tid; i < KVT * (C::DK - D); i += NT) {
+                int key = i / (C::DK - D), c = D + i % (C::DK - D);
+                ldsK[key * C::K_STRIDE + c] = (C::BIAS && c == D) ? (h16)1.0f : (h16)0.f;
+            }
+        }
+        if (C::DP > D) {
+            for (int i = tid; i < (C::DP - D) * KVT; i += NT) {
+                int r = D + i / KVT, c = i % KVT;
+                ldsV[r * C::V_STRIDE + c] = (C::ONES && r == D) ? (h16)1.0f : (h16)0.f;
+            }
         }
     }
-    if (C::DP > D) {
-        for (int i = tid; i < (C::DP - D) * KVT; i += NT) {
-            int r = D + i / KVT, c = i % KVT;
-            ldsV[r * C::V_STRIDE + c] = (C::ONES && r == D) ? (h16)1.0f : (h16)0.f;
+
+    // ---- register prefetch of one K / V^T tile ----
+    constexpr int KCH = KVT * (D / 8), VCH = D * (KVT / 8);
+    constexpr int KL = (KCH + NT - 1) / NT, VL = (VCH + NT - 1) / NT;
+    uint4 kreg[KL], vreg[VL];
+    auto load_tile = [&](const int kbase, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            const int idx = tid + i * NT;
+            const int key = idx / (D / 8), ch = idx % (D / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < KCH && (!MASKED || kbase + key < Nkv)) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
+            kreg[i] = v;
         }
-    }
+#pragma unroll
+        for (int i = 0; i < VL; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (KVT / 8), ch = idx % (KVT / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < VCH) v = bc_ld16(Vb + (size_t)r * ldvt + kbase + ch * 8);   // Vt is zero-padded beyond Nkv by contract
+            vreg[i] = v;
+        }
+    };
+    auto store_tile = [&](const int st) {
+        h16* ldsK = lds + st * C::STAGE_HALFS;
+        h16* ldsV = ldsK + KVT * C::K_STRIDE;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            const int idx = tid + i * NT;
+            const int key = idx / (D / 8), ch = idx % (D / 8);
+            if (idx < KCH) bc_st16(ldsK + key * C::K_STRIDE + ch * 8, kreg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VL; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (KVT / 8), ch = idx % (KVT / 8);
+            if (idx < VCH) {      // V_STRIDE*2 bytes = 136 is only 8-byte aligned: two 8-byte stores
+                uint2* dst = reinterpret_cast<uint2*>(ldsV + r * C::V_STRIDE + ch * 8);
+                dst[0] = make_uint2(vreg[i].x, vreg[i].y);
+                dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+            }
+        }
+    };
 
     f32x16 oacc[C::DT];
 #pragma unroll
     for (int t = 0; t < C::DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = 0.f, l_run = 0.f;     // m_ref: reference exponent of this query's running softmax (exactly fp16-representable)
+    bool first = true;
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     union PFrag { h16x8 v; h16x2 p[4]; };
 
-    // one KV tile; MASKED = the tile holds keys >= Nkv (only ever the last one) -> kept out of the steady-state code path
-    auto process_tile = [&](const int kbase, auto masked_tag) {
+    auto compute_tile = [&](const int st, const int kbase, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        __syncthreads();     // previous tile fully consumed (also orders the constant-part stores before first use)
-        // ---- stage K tile: KVT keys x D (row copy, 16-byte chunks) ----
-        {
-            constexpr int CH = D / 8;
-            for (int i = tid; i < KVT * CH; i += NT) {
-                int key = i / CH, ch = i % CH;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (!MASKED || kbase + key < Nkv) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
-                bc_st16(ldsK + key * C::K_STRIDE + ch * 8, v);
-            }
-        }
-        // ---- stage V^T tile: D rows x KVT keys (padding of Vt beyond Nkv is zero by contract) ----
-        {
-            constexpr int CH = KVT / 8;
-            for (int i = tid; i < D * CH; i += NT) {
-                int r = i / CH, ch = i % CH;
-                uint4 v = bc_ld16(Vb + (size_t)r * ldvt + kbase + ch * 8);
-                // V_STRIDE*2 bytes = 136 is only 8-byte aligned: store as two 8-byte halves
-                uint2* dst = reinterpret_cast<uint2*>(ldsV + r * C::V_STRIDE + ch * 8);
-                dst[0] = make_uint2(v.x, v.y);
-                dst[1] = make_uint2(v.z, v.w);
-            }
-        }
-        __syncthreads();
-
-        // ---- S^T[kt] = K_tile[kt] . Q^T  (two 32-key tiles) ----
+        const h16* ldsK = lds + st * C::STAGE_HALFS;
+        const h16* ldsV = ldsK + KVT * C::K_STRIDE;
+        // ---- S'^T[kt] = K_tile[kt] . Q'^T  (two 32-key tiles); with BIAS the product already holds S - m_ref ----
         f32x16 sacc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -141,6 +178,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kt], 0, 0, 0);
             }
         }
+        if (!C::BIAS) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] -= m_ref;
+        }
         if (MASKED) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -150,18 +193,33 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
                     if (key >= Nkv) sacc[kt][r] = -INFINITY;
                 }
         }
-        // ---- online softmax (per query column; partner lane = lane ^ 32 holds the other 32 keys) ----
+        // ---- running reference: per query column; partner lane = lane ^ 32 holds the other 32 keys ----
         float mx = sacc[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        // m_new is finite as soon as one valid key was seen (every tile has >= 1 valid key)
-        const bool grew = m_new != m_run;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        const bool move = first || (mx > RESCALE_THR);
+        if (__any(move)) {
+            // slow path (wave-uniform): move the reference of the lanes that need it, rescale O and l, shift this tile's scores
+            const float want = move ? (m_ref + mx) : m_ref;                 // every tile holds >= 1 valid key: mx is finite
+            const float m_new = (float)(h16)want;                            // keep the reference fp16-exact (it rides in Q)
+            const float delta = m_new - m_ref;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_ref = m_new;
+            if (C::BIAS) qf[BS][BJ] = (half == BH) ? (h16)(-m_new) : qf[BS][BJ];
+            l_run *= alpha;
+#pragma unroll
+            for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] -= delta;
+            first = false;
+        }
         float psum = 0.f;
         PFrag pf[2][2];
 #pragma unroll
@@ -171,23 +229,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     f32x2 e;
-                    e.x = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj] - m_new);
-                    e.y = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj + 1] - m_new);
+                    e.x = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj]);
+                    e.y = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj + 1]);
                     pf[kt][s2].p[jj] = __builtin_convertvector(e, h16x2);
                     if (!C::ONES) psum += e.x + e.y;
                 }
-        if (!C::ONES) {
-            psum += __shfl_xor(psum, 32);
-            l_run = l_run * alpha + psum;
-        }
-        // rescale the running output only when some query of this wave saw a new maximum (wave-uniform branch; after the
-        // first few tiles the maximum rarely moves, so the steady state skips DT*16 multiplies per lane)
-        if (__any(grew)) {
-#pragma unroll
-            for (int t = 0; t < C::DT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-        }
+        if (!C::ONES) l_run += psum + __shfl_xor(psum, 32);
 
         // ---- O^T[t] += V^T_tile[t] . P^T ;  A fragment element j of lane-half h must be key 16 s2 + 8 (j>>2) + 4 h + (j&3) ----
 #pragma unroll
@@ -208,8 +255,21 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
     };
 
     const int nfull = Nkv / KVT;
-    for (int tile = 0; tile < nfull; ++tile) process_tile(tile * KVT, std::false_type{});
-    if (nfull * KVT < Nkv) process_tile(nfull * KVT, std::true_type{});
+    const int ntiles = (Nkv + KVT - 1) / KVT;
+    // prologue: tile 0 -> stage 0
+    if (nfull > 0) load_tile(0, std::false_type{}); else load_tile(0, std::true_type{});
+    store_tile(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int st = tile & 1;
+        const int nxt = tile + 1;
+        if (nxt < ntiles) {                                   // global loads of the next tile fly during this tile's MFMAs
+            if (nxt < nfull) load_tile(nxt * KVT, std::false_type{}); else load_tile(nxt * KVT, std::true_type{});
+        }
+        if (tile < nfull) compute_tile(st, tile * KVT, std::false_type{}); else compute_tile(st, tile * KVT, std::true_type{});
+        if (nxt < ntiles) store_tile(st ^ 1);                 // the other stage was last read one barrier ago
+        __syncthreads();
+    }
 
     // ---- epilogue: O[q][dd] = O^T[dd][q] / l ----
     float l = l_run;
@@ -244,6 +304,12 @@ int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int
                    hipStream_t stream) {
     using C = AttnCfg<D>;
     dim3 grid(bc_ceil_div(Nq, QW * NW), heads, B), block(64 * NW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, NW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
     hipLaunchKernelGGL((attn_fwd_kernel<D, NW>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
                        qbs, kbs, vbs, obs, scale * 1.4426950408889634f);
     BC_CHECK_LAUNCH();

@@ -160,3 +160,18 @@ def test_dinov2_matches_transformers_fixture(golden_dir, tag):
     ref = z[f"{tag}_pooled"]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1e-2 and psnr(out, ref) > 40.0
+
+
+def test_dinov2_vit_large_full_size():
+    """ViT-L/14 (24 layers, 1024 wide, 16 heads, 257 tokens at 224x224 with position embeddings resized from the 37x37
+    training grid) against the CPU oracle: the once-per-edit DINOv2 pass of pipeline_blobnet.py:690-703 at its real size."""
+    from blobctrl_amd import synth
+    from blobctrl_amd.dinov2 import Dinov2Model
+    from oracle.dinov2 import dinov2_pooled
+    sd = synth.synth_state_dict(synth.dinov2_param_shapes(1024, 24, 4, 14, 37 * 37), 11)
+    x = g(9, 1, 3, 224, 224)
+    ref = dinov2_pooled(sd, x, 16, 14).numpy()
+    model = Dinov2Model(sd, num_heads=16, patch_size=14)
+    out = model(x).pooler_output.cpu().numpy()
+    assert out.shape == ref.shape == (1, 1024)
+    assert rel_err(out, ref) < 1e-2 and psnr(out, ref) > 40.0, (rel_err(out, ref), psnr(out, ref))
