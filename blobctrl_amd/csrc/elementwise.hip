@@ -42,7 +42,7 @@ __global__ void splat_kernel(const SplatParams prm, int h, int w, double* __rest
 // pipeline_blobnet.py:724-739 + :706-721.  X[b][y][x][c], x in [0, 2w): left = clean image latents, right = noisy latents.
 __global__ void assemble_kernel(const float* __restrict__ latents, int Blat, const float* __restrict__ img_lat,
                                 const float* __restrict__ score, const float* __restrict__ feat, int Bimg, int F, int Bout,
-                                int h, int w, int Cpad, h16* __restrict__ X) {
+                                int h, int w, int Cpad, int dup_score, h16* __restrict__ X) {
     const long long total = (long long)Bout * h * 2 * w * (Cpad / 8);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -68,6 +68,8 @@ __global__ void assemble_kernel(const float* __restrict__ latents, int Blat, con
                 v = sc;
             } else if (c < 5 + F) {
                 v = sc * feat[(size_t)bi * F + c - 5];
+            } else if (dup_score && c == 5) {
+                v = sc;          // rank-1 collapsed feature channels: one extra copy of the score (see engine.py)
             }
             o[j] = (h16)v;
         }
@@ -213,15 +215,15 @@ extern "C" int bc_splat_scores(const double* params_host, int n, int h, int w, d
 }
 
 extern "C" int bc_assemble_input(const float* latents, int Blat, const float* img_lat, const float* score,
-                                 const float* feat, int Bimg, int F, int Bout, int h, int w, int Cpad, bc_half* X,
-                                 bc_stream stream_) {
+                                 const float* feat, int Bimg, int F, int Bout, int h, int w, int Cpad, int dup_score,
+                                 bc_half* X, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!feat) F = 0;
     BC_CHECK_ARG(latents && img_lat && score && X && Blat > 0 && Bout > 0 && Bimg > 0, "bc_assemble_input: bad args");
     BC_CHECK_ARG(Cpad % 8 == 0 && Cpad >= 5 + F, "bc_assemble_input: Cpad=%d must be a multiple of 8 and >= %d", Cpad, 5 + F);
     long long total = (long long)Bout * h * 2 * w * (Cpad / 8);
     hipLaunchKernelGGL(assemble_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, latents, Blat, img_lat, score, feat,
-                       Bimg, F, Bout, h, w, Cpad, reinterpret_cast<h16*>(X));
+                       Bimg, F, Bout, h, w, Cpad, dup_score, reinterpret_cast<h16*>(X));
     BC_CHECK_LAUNCH();
     return 0;
 }

@@ -186,6 +186,18 @@ class TrunkPlan:
                      ldc=ldvt, rows_per_batch=T, kind="ctx_kv")
             self.ctx_kv[bp] = (ck, cvt, T, ldvt)
 
+    # ------------------------------------------------------------------------------------------- per-edit weight collapse
+    def record_collapse(self, feat16: torch.Tensor):
+        """BlobNet conv_in over the F feature channels, which are score x f (rank 1, pipe:706-721, SURVEY 8a note iii):
+        g[o, tap] = sum_c W[o, 5+c, tap] * f_c is computed once per edit (one GEMV on the MFMA path) and written into input
+        channel 5 of an 8-channel conv_in weight; the step then convolves [latents(4), score, score, 0, 0]."""
+        pw = self.pw
+        w8 = pw.h["conv_in.weight8"]
+        fm = pw.h["conv_in.featmat"]
+        pw.h["conv_in8.weight"] = w8
+        pw.f["conv_in8.bias"] = pw.f["conv_in.bias"]
+        self.rec.gemm(A=fm, W=feat16, M=fm.shape[0], N=1, K=fm.shape[1], out=w8, ldc=8, out_offset=5, kind="collapse")
+
     # ------------------------------------------------------------------------------------------- time embedding
     def record_time(self, t_table, t_idx, t_value=0.0):
         """embeddings.py:27-78, 576-588 and the 22 `time_emb_proj(silu(emb))` of resnet.py:343-350 as three GEMMs."""
@@ -238,14 +250,17 @@ class TrunkPlan:
 
         feats_d, feats_u, feats_m = _Feats("blobnet_down_blocks"), _Feats("blobnet_up_blocks"), _Feats("blobnet_mid_block")
 
-        x = Act(x_in, pad8(cfg.in_channels), H, W)
+        x = Act(x_in, x_in.shape[-1], H, W)
+        conv_in_name = "conv_in"
+        if x_in.shape[-1] == 8 and pad8(cfg.in_channels) > 8:
+            conv_in_name = "conv_in8"        # rank-1-collapsed BlobNet input (see record_collapse)
         if residuals is not None and W == H:
             # square canvas: `sample = sample + r` rebinds, skip #0 stays WITHOUT the residual (unet_2d_condition.py:1213-1217)
-            skip0 = self.conv3x3(x, "conv_in", boc[0], kind="conv_in")
-            h = self.conv3x3(x, "conv_in", boc[0], r2=pop(res_d), kind="conv_in")
+            skip0 = self.conv3x3(x, conv_in_name, boc[0], kind="conv_in")
+            h = self.conv3x3(x, conv_in_name, boc[0], r2=pop(res_d), kind="conv_in")
         else:
             # wide canvas: in-place slice add aliases the tuple element => skip #0 carries the residual (:1219)
-            h = self.conv3x3(x, "conv_in", boc[0], r2=pop(res_d), kind="conv_in")
+            h = self.conv3x3(x, conv_in_name, boc[0], r2=pop(res_d), kind="conv_in")
             skip0 = h
         skips = [skip0]
         feats_d.append(h)

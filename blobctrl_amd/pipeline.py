@@ -82,7 +82,10 @@ class StableDiffusionBlobNetPipeline:
         P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32)
         P.guidance = [7.5]
 
-        unet_cin, blob_cin = pad8(self.unet_cfg.in_channels), pad8(self.blob_cfg.in_channels)
+        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h      # rank-1 collapse of the BlobNet feature channels
+        unet_cin = pad8(self.unet_cfg.in_channels)
+        blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
+        P.feat16 = rec.zeros(1, pad8(max(F, 1)))
         P.blob_in = rec.zeros(B, H * W, blob_cin)
         P.unet_in = rec.zeros(2 * B, H * W, unet_cin)
 
@@ -90,10 +93,13 @@ class StableDiffusionBlobNetPipeline:
         P.prologue = rec.begin("prologue")
         unet_a = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
         unet_a.record_context(P.ctx, T)
+        blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
+        if P.collapse:
+            blob.record_collapse(P.feat16)
 
         def record_unet(plan, residuals):
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, 1, 0,
-                     2 * B, h, w, unet_cin, P.unet_in.data_ptr(), kind="assemble")
+                     2 * B, h, w, unet_cin, 0, P.unet_in.data_ptr(), kind="assemble")
             plan.record_time(P.t_table, P.step_idx)
             eps = plan.record_forward(P.unet_in, residuals)
             P.eps = eps
@@ -115,9 +121,12 @@ class StableDiffusionBlobNetPipeline:
         rec.signal(fork)
         rec.sid = 1
         rec.wait(fork)
-        rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
-                 P.feat.data_ptr() if F > 0 else None, 1, F, B, h, w, blob_cin, P.blob_in.data_ptr(), kind="assemble")
-        blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
+        if P.collapse:
+            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(), None, 1, 0,
+                     B, h, w, blob_cin, 1, P.blob_in.data_ptr(), kind="assemble")
+        else:
+            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
+                     P.feat.data_ptr() if F > 0 else None, 1, F, B, h, w, blob_cin, 0, P.blob_in.data_ptr(), kind="assemble")
         blob.record_time(P.t_table, P.step_idx)
         residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx),
                                         signal_residuals=True)
@@ -211,6 +220,7 @@ class StableDiffusionBlobNetPipeline:
                 if dino_feats is None:
                     raise ValueError("dino_feats is required (BlobNet conditioning channels)")
                 P.feat.copy_(dino_feats.to(dev, torch.float32).reshape(1, self.feat_dim))
+                P.feat16[:, : self.feat_dim].copy_(P.feat)
             P.ctx.copy_(prompt_embeds.to(dev, torch.float16))
             P.t_table.copy_(sched.timesteps.to(torch.float32))
             P.coef.copy_(sched.table())

@@ -107,6 +107,15 @@ class PackedTrunk:
             else:
                 self.h[k] = pack_matrix(v).half().to(device)
         self.temb_total = off
+        w_in = sd["conv_in.weight"]
+        if w_in.shape[1] > 8:
+            # BlobNet: conditioning = 1 score channel + F feature channels that are (score x per-edit vector) (pipe:706-721).
+            # Keep the F-channel block as a [Co*9, F] matrix: a per-edit GEMV collapses it into ONE extra input channel.
+            co = w_in.shape[0]
+            base = torch.zeros(co, 3, 3, 8)
+            base[..., :5] = w_in[:, :5].permute(0, 2, 3, 1)
+            self.h["conv_in.weight8"] = base.reshape(co, 72).half().to(device)
+            self.h["conv_in.featmat"] = pack_matrix(w_in[:, 5:].permute(0, 2, 3, 1).reshape(co * 9, -1)).half().to(device)
         self.h["temb_all.weight"] = torch.cat(temb_w, 0).half().to(device)
         self.f["temb_all.bias"] = torch.cat(temb_b, 0).to(device)
         self._to_arenas()

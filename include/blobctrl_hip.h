@@ -147,9 +147,11 @@ int bc_splat_scores(const double* params_host, int n, int h, int w, double* out,
  * and the rank-1 feature splat (pipeline_blobnet.py:706-721).  Writes X[Bout][h][2w][Cpad]:
  *   left half  = (img_lat[bi][4], score[bi], score*feat[bi][0..F))   right half = (latents[b % Blat][4], score, score*feat)
  * with bi = b % Bimg.  latents fp32 [Blat][4][h][w] (NCHW), img_lat fp32 [Bimg][4][h][w], score fp32 [Bimg][h][w],
- * feat fp32 [Bimg][F] or NULL (F = 0). */
+ * feat fp32 [Bimg][F] or NULL (F = 0).  dup_score != 0 (with F = 0) writes the score a second time into channel 5: the input of the
+ * rank-1-collapsed BlobNet conv_in (the 1024 feature channels are score x vector, so their 3x3 conv equals a 1-channel conv of
+ * the score with the per-edit kernel sum_c W[:, 5+c] * f_c). */
 int bc_assemble_input(const float* latents, int Blat, const float* img_lat, const float* score, const float* feat,
-                      int Bimg, int F, int Bout, int h, int w, int Cpad, bc_half* X, bc_stream stream);
+                      int Bimg, int F, int Bout, int h, int w, int Cpad, int dup_score, bc_half* X, bc_stream stream);
 
 /* Sinusoidal timestep embedding (embeddings.py:27-78, flip_sin_to_cos=True, shift 0) for `rows` identical rows.
  * t = t_table[*t_idx] when t_table != NULL else t_value.  out [rows][dim] fp16. */

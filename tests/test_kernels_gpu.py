@@ -333,7 +333,7 @@ def test_assemble_matches_construct_blobnet_input(rec):
     X = rec.zeros(2 * B, hh * 2 * ww, Cpad)
     dl, di, ds, df = lat.cuda(), img.cuda(), sc.cuda(), feat.cuda()
     run(rec, lambda: rec.call("bc_assemble_input", dl.data_ptr(), B, di.data_ptr(), ds.data_ptr(), df.data_ptr(), 1, Fd,
-                              2 * B, hh, ww, Cpad, X.data_ptr()))
+                              2 * B, hh, ww, Cpad, 0, X.data_ptr()))
     lmi = torch.cat([lat] * 2)
     feats = torch.einsum("nmhw,nmc->nchw", sc.repeat(2 * B, 1, 1, 1), feat.repeat(2 * B, 1, 1))
     ref = construct_input(lmi, sc.repeat(2 * B, 1, 1, 1), img.repeat(2 * B, 1, 1, 1), feats)
