@@ -37,7 +37,7 @@ def synth_weights():
     return synth.synth_state_dict(us, 1234), synth.synth_state_dict(bs, 1235)
 
 
-def synth_inputs(h, w, T=77, ctx=768, feat=1024):
+def synth_inputs(h, w, T=77, ctx=768, feat=1024, batch=1):
     """SURVEY 8d synthetic inputs: seeded latents / prompt embeddings / DINO vector, move_hat blob scaled to the canvas."""
     import numpy as np
     from blobctrl_amd.splat import blob_dict_from_ellipse
@@ -46,8 +46,8 @@ def synth_inputs(h, w, T=77, ctx=768, feat=1024):
         return torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
     s = (8 * w) / 512.0
     ell = [[361.1067 * s, 367.8526 * s], [85.4812 * s, 103.6543 * s], 87.3739]
-    return dict(fg=g(1, 1, 4, h, w) * 0.18215 * 5, bg=g(2, 1, 4, h, w) * 0.18215 * 5, prompt=g(3, 2, T, ctx),
-                dino=g(4, 1, 1, feat), latents=g(1248464818 % (2 ** 31), 1, 4, h, w),
+    return dict(fg=g(1, 1, 4, h, w) * 0.18215 * 5, bg=g(2, 1, 4, h, w) * 0.18215 * 5, prompt=g(3, 2 * batch, T, ctx),
+                dino=g(4, 1, 1, feat), latents=g(1248464818 % (2 ** 31), batch, 4, h, w),
                 blob=blob_dict_from_ellipse(ell, 8 * w, 8 * h))
 
 
@@ -113,6 +113,25 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler):
                 host_cpus_visible=avail), None
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE passes of this same command, gfx950 correction applied: see profiles/*pmc_hbm_traffic.json).  PMC
+    counters cannot be read from inside the timed process, so the number is only reported when the summary names the
+    same kernel; otherwise null."""
+    import glob
+    import re
+    m = re.match(r"attn_fwd_kernel<(\d+)>", kernel_label)
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")))
+    if not m or not files:
+        return None
+    with open(files[-1]) as f:
+        rows = json.load(f)["kernels"]
+    for r in rows:
+        if f"attn_fwd_kernelILi{m.group(1)}E" in r["kernel"]:
+            return r["hbm_bytes_per_launch_corrected"]
+    return None
+
+
 def roofline(pipe, plan):
     """HIP-event time every launch of one BlobNet-active step on the launch stream; report the dominant kernel."""
     s = pipe.stream.cuda_stream
@@ -153,7 +172,7 @@ def roofline(pipe, plan):
     table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
              for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=None, launches_per_step=a["n"],
+                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(dom), launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3)), dict(by_kernel=table, top_shapes=detail)
 
@@ -166,6 +185,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "unipc"])
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1, help="images per edit (BASELINE configs[2]/[4] use 8 / 4; headline = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
@@ -196,7 +216,7 @@ def main():
     pw_b = bdist.broadcast_packed(build_blob, dev)
     t_weights = time.perf_counter() - t0
     pipe = StableDiffusionBlobNetPipeline(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=args.scheduler)
-    inp = synth_inputs(h, w)
+    inp = synth_inputs(h, w, batch=args.batch)
     inp_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}     # inputs resident in HBM
     score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device=str(dev))   # HIP rasteriser
 
@@ -220,13 +240,14 @@ def main():
         tdist.barrier()
     dt = bdist.barrier_max_seconds(time.perf_counter() - t0, dev)
 
-    plan = pipe.plan_for(1, h, w, 77, 768, args.denoise_steps)
+    plan = pipe.plan_for(args.batch, h, w, 77, 768, args.denoise_steps)
     line = {
-        "metric": "512x512_50step_blobctrl_edits_per_sec" if args.res == 512 else f"{args.res}x{args.res}_edits_per_sec",
+        "metric": "512x512_50step_blobctrl_edits_per_sec" if (args.res == 512 and args.batch == 1)
+        else f"{args.res}x{args.res}_batch{args.batch}_edits_per_sec",
         "value": world * args.steps / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: single {args.res}x{args.res} edit, batch 1 (CFG batch 2 for the UNet, "
+        "config": {"workload": f"BASELINE configs[1]: single {args.res}x{args.res} edit, batch {args.batch} (CFG batch {2 * args.batch} for the UNet, "
                                f"BlobNet shared across CFG halves), {args.denoise_steps} {args.scheduler.upper()} steps, "
                                "guidance window [0,1], fp16 activations / fp32 accumulate, LoRA pre-merged, hipGraph-replayed steps",
                    "edits_per_rank": args.steps, "denoise_steps": args.denoise_steps,
@@ -239,7 +260,7 @@ def main():
         line["roofline"] = rl
         if args.table:
             print(json.dumps(table, indent=1), file=sys.stderr)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == 1:
         cb, _ = cpu_baseline(state["usd"], state["bsd"], inp, h, w, args.denoise_steps, args.scheduler)
         line["cpu_baseline"] = cb
     if rank == 0:

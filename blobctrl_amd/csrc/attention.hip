@@ -57,9 +57,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qcol = lane & 31, half = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    // XCD-aware remap: an XCD's L2 then serves the K / V of a few (batch, head) pairs to all of their query blocks
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int lin = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
+    const int qblk = lin % (int)gridDim.x, head = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
     constexpr int NT = 64 * NW;
-    const int q0 = blockIdx.x * (QW * NW) + wave * QW;
+    const int q0 = qblk * (QW * NW) + wave * QW;
 
     const h16* Qb = Q + (size_t)b * q_bs + (size_t)head * D;
     const h16* Kb = K + (size_t)b * k_bs + (size_t)head * D;

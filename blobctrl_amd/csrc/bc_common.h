@@ -39,3 +39,13 @@ __device__ __forceinline__ float bc_gelu_f(float x) { return 0.5f * x * (1.0f + 
 
 __device__ __forceinline__ uint4 bc_ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void bc_st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// XCD-aware workgroup remap (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with a
+// private 4 MiB L2.  Remapping the linear id so that every XCD owns a CONTIGUOUS band of the grid makes tiles that share an
+// operand panel (column tiles of one row band, query blocks of one head) hit the same L2.  Bijective for any grid size.
+// Placement only affects speed, never results.
+__device__ __forceinline__ int bc_xcd_remap(int id, int nwg) {
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (id >> 3);
+}

@@ -36,9 +36,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    const int plane = gridDim.x * gridDim.y;
+    const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
+    const int lin = lin3 % plane;
+    const int m0 = (lin / (int)gridDim.x) * BM;        // an XCD owns a contiguous band of row tiles, all their column tiles
+    const int n0 = (lin % (int)gridDim.x) * BN;
+    const int split = lin3 / plane;
 
     const h16* __restrict__ A = reinterpret_cast<const h16*>(p.A);
     const h16* __restrict__ A2 = reinterpret_cast<const h16*>(p.A2);

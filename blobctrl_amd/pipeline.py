@@ -53,6 +53,7 @@ class StableDiffusionBlobNetPipeline:
         self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
         self._plans = {}
+        self._sched_cache = {}
         self.feat_dim = blobnet_config.in_channels - 5
 
     # ------------------------------------------------------------------------------------------------ planning
@@ -201,8 +202,11 @@ class StableDiffusionBlobNetPipeline:
         n = num_inference_steps
         P = self._plan(B, h, w, T, Dc, n)
         dev = self.device
-        sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
-        sched.set_timesteps(n)
+        sched = self._sched_cache.get((self.scheduler_kind, n))       # coefficient tables depend only on (scheduler, steps)
+        if sched is None:
+            sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
+            sched.set_timesteps(n)
+            self._sched_cache[(self.scheduler_kind, n)] = sched
         self.timesteps = sched.timesteps
         if latents is None:                                                          # pipe:438-453
             latents = torch.randn((B, 4, h, w), generator=generator, device=generator.device if generator else "cpu",
