@@ -101,6 +101,7 @@ __global__ void silu_kernel(const h16* __restrict__ x, h16* __restrict__ y, long
 //  [2] use_corrector
 //  [3] cc_x (last_sample) [4] cc_m0 (prev x0) [5] cc_m1 (prev-prev x0) [6] cc_mt (this x0)      x_c = sum
 //  [7] cp_x (x_c)         [8] cp_m0 (this x0) [9] cp_m1 (prev x0)  [10] cp_eps (guided eps)     x_next = sum
+//  [11] guidance scale (used when the launch argument is negative: lets a captured graph follow per-call values)
 __global__ void cfg_step_kernel(const float* __restrict__ eps, float* __restrict__ latents, const float* __restrict__ coef,
                                 int* __restrict__ step_idx, float* __restrict__ hist, float guidance, int B, int h, int w,
                                 float* __restrict__ eps_out) {
@@ -117,7 +118,8 @@ __global__ void cfg_step_kernel(const float* __restrict__ eps, float* __restrict
         size_t pu = (((size_t)b * h + yy) * (2 * w) + (w + xx)) * 4 + c;
         size_t pc = (((size_t)(B + b) * h + yy) * (2 * w) + (w + xx)) * 4 + c;
         float eu = eps[pu], ec = eps[pc];
-        float e = eu + guidance * (ec - eu);
+        const float gscale = guidance >= 0.f ? guidance : cf[11];     // < 0: read from the coefficient table (graph-replay safe)
+        float e = eu + gscale * (ec - eu);
         if (eps_out) eps_out[i] = e;
         float x = latents[i];
         float* m0 = hist, *m1 = hist + n, *last = hist + 2 * (size_t)n;

@@ -108,7 +108,7 @@ class StableDiffusionBlobNetPipeline:
 
             def step_fn(stream, lib=rec.lib):
                 rc = lib.bc_cfg_scheduler_step(eps.data_ptr(), P.latents.data_ptr(), P.coef.data_ptr(),
-                                               P.step_idx.data_ptr(), P.hist.data_ptr(), g[0], B, h, w,
+                                               P.step_idx.data_ptr(), P.hist.data_ptr(), -1.0, B, h, w,
                                                P.eps_guided.data_ptr(), 1, stream)
                 if rc:
                     _lib.check(rc, "bc_cfg_scheduler_step")
@@ -227,7 +227,9 @@ class StableDiffusionBlobNetPipeline:
                 P.feat16[:, : self.feat_dim].copy_(P.feat)
             P.ctx.copy_(prompt_embeds.to(dev, torch.float16))
             P.t_table.copy_(sched.timesteps.to(torch.float32))
-            P.coef.copy_(sched.table())
+            coef = sched.table().clone()
+            coef[:, 11] = float(guidance_scale)          # read by the captured cfg/scheduler kernel
+            P.coef.copy_(coef)
             P.scale_table.copy_(torch.tensor(scales, dtype=torch.float32))
             P.step_idx.zero_()
             P.hist.zero_()

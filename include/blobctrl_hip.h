@@ -169,6 +169,7 @@ int bc_silu(const bc_half* x, bc_half* y, long long n, bc_stream stream);
  *   coef     : device table [nsteps][16] (layout in blobctrl_amd/schedulers.py), row = *step_idx
  *   hist     : fp32 [3][B*4*h*w] scheduler history (x0_prev, x0_prevprev, last_sample)
  *   eps_out  : optional fp32 [B][4][h][w] guided epsilon (for parity tracing) or NULL
+ * guidance_scale < 0 => the scale is read from coef[*step_idx][11] (a captured graph then follows per-call values).
  * Increments *step_idx when advance != 0. */
 int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, int* step_idx, float* hist,
                           float guidance_scale, int B, int h, int w, float* eps_out, int advance, bc_stream stream);

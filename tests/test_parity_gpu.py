@@ -175,3 +175,19 @@ def test_dinov2_vit_large_full_size():
     out = model(x).pooler_output.cpu().numpy()
     assert out.shape == ref.shape == (1, 1024)
     assert rel_err(out, ref) < 1e-2 and psnr(out, ref) > 40.0, (rel_err(out, ref), psnr(out, ref))
+
+
+def test_captured_graph_follows_per_call_arguments():
+    """guidance_scale, conditioning scale / window and the step count tables are per-call data: a plan captured by an earlier
+    call must follow them (they live in device tables, not in kernel arguments frozen at capture)."""
+    from oracle import pipeline as o_pipe, schedulers as o_sched
+    usd, bsd = tiny_weights()
+    ucfg, bcfg = tiny_cfgs()
+    a = _loop_inputs()
+    pipe = make_pipeline(usd, bsd, scheduler="ddim", use_graphs=True)
+    for gs, cs in ((7.5, 1.0), (3.0, 0.5)):
+        out = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=3, guidance_scale=gs,
+                   latents=a["latents"], blobnet_conditioning_scale=cs).cpu().numpy()
+        ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 3, a["latents"], a["prompt"], a["fg"], a["bg"],
+                                  a["score"].float(), a["dino"], gs, cs).numpy()
+        assert rel_err(out, ref) < 2e-2, (gs, cs, rel_err(out, ref))
