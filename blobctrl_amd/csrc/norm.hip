@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int GN_PIX_PER_SLAB = 16;     // stand-alone statistics pass: small slabs => enough workgroups for 256 CUs
+constexpr int GN_PIX_PER_SLAB = 128;    // stand-alone statistics pass (same slab height as the smallest fused GEMM tiles)
 constexpr int GN_MAX_GROUPS = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -17,39 +17,55 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// part[b][slab][c][2] = per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab.  No atomics: every
-// partial is produced by exactly one thread in a fixed order, so GroupNorm (and everything downstream) is bit-reproducible.
-// Lane l owns 8-channel chunk(s) l, l + blockDim, ...; adjacent lanes read adjacent 16-byte chunks (coalesced rows).
+// part[b][slab][c][2] = per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab.  No atomics: every partial is
+// produced in a fixed order, so GroupNorm (and everything downstream) is bit-reproducible.  Four waves split the slab's
+// pixels; lane l of a wave owns 8-channel chunk(s) l, l + 64, ... (adjacent lanes read adjacent 16-byte chunks: coalesced
+// rows); the four wave partials are combined through LDS in wave order.
 // (Only used for tensors whose producer could not emit the partials itself - see BcGemm.gn_part.)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x, int C, int HW, float* __restrict__ part,
                                                          int nslab) {
+    __shared__ float red[4][64][16];
     const int b = blockIdx.y, slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = C / 8;
     const int p0 = slab * GN_PIX_PER_SLAB;
     const int np = min(GN_PIX_PER_SLAB, HW - p0);
+    const int per_wave = (np + 3) / 4;
+    const int pw0 = min(np, wave * per_wave), pw1 = min(np, pw0 + per_wave);
     float* dst = part + ((size_t)b * nslab + slab) * C * 2;
-    for (int ch = threadIdx.x; ch < nchunk; ch += blockDim.x) {
-        const int c = ch * 8;
-        const h16* src = x + ((size_t)b * HW + p0) * C + c;
+    for (int ch0 = 0; ch0 < nchunk; ch0 += 64) {
+        const int ch = ch0 + lane;
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        if (ch < nchunk) {
+            const h16* src = x + ((size_t)b * HW + p0) * C + ch * 8;
 #pragma unroll 8
-        for (int pl = 0; pl < np; ++pl) {
-            uint4 raw = bc_ld16(src + (size_t)pl * C);
-            const h16* v = reinterpret_cast<const h16*>(&raw);
+            for (int pl = pw0; pl < pw1; ++pl) {
+                uint4 raw = bc_ld16(src + (size_t)pl * C);
+                const h16* v = reinterpret_cast<const h16*>(&raw);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = (float)v[j];
-                s[j] += f;
-                q[j] += f * f;
+                for (int j = 0; j < 8; ++j) {
+                    float f = (float)v[j];
+                    s[j] += f;
+                    q[j] += f * f;
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            dst[(c + j) * 2] = s[j];
-            dst[(c + j) * 2 + 1] = q[j];
+        for (int j = 0; j < 8; ++j) { red[wave][lane][2 * j] = s[j]; red[wave][lane][2 * j + 1] = q[j]; }
+        __syncthreads();
+        if (wave == 0 && ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { ss += red[w][lane][2 * j]; qq += red[w][lane][2 * j + 1]; }
+                dst[(ch * 8 + j) * 2] = ss;
+                dst[(ch * 8 + j) * 2 + 1] = qq;
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -138,6 +154,103 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x
     }
 }
 
+// Fused finalize + apply: one launch per GroupNorm.  A workgroup owns a 64-channel range x a pixel range of one image; its
+// prologue re-reduces the per-channel partials of just the groups that overlap its channel range (<= 64/cpg + 2 groups, one
+// wave per group, fixed order, fp64) into LDS (a, b) pairs, then streams its pixels: y = silu?(a*x + b), 16-byte accesses.
+// Removes the separate finalize launch (which sat on the critical path with only G/4 x B workgroups).
+__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __restrict__ part1, int nslab1, int C1,
+                                                               const float* __restrict__ part2, int nslab2, int C2,
+                                                               const h16* __restrict__ x1, const h16* __restrict__ x2, int HW,
+                                                               int G, float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int silu, int pix_per_block,
+                                                               h16* __restrict__ y) {
+    __shared__ float ab_s[64 * 2];
+    const int b = blockIdx.z;
+    const int C = C1 + C2;
+    const int cpg = C / G;
+    const int c0 = blockIdx.x * 64, c1 = min(c0 + 64, C);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g_lo = c0 / cpg, g_hi = (c1 - 1) / cpg;
+    for (int g = g_lo + wave; g <= g_hi; g += 4) {
+        const int c_lo = g * cpg, c_hi = c_lo + cpg;
+        const int n1 = max(0, min(c_hi, C1) - c_lo);
+        const int n2 = cpg - n1;
+        double s = 0.0, q = 0.0;
+        if (n1 > 0) {
+            const float* base = part1 + ((size_t)b * nslab1 * C1 + c_lo) * 2;
+            const int items = n1 * nslab1;
+            for (int it0 = lane; it0 < items; it0 += 256) {          // 4 independent loads in flight per lane
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int it = it0 + u * 64;
+                    const int sl = it / n1, cj = it - sl * n1;
+                    v[u] = (it < items) ? *reinterpret_cast<const float2*>(base + ((size_t)sl * C1 + cj) * 2) : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+            }
+        }
+        if (n2 > 0) {
+            const int c2_lo = max(c_lo, C1) - C1;
+            const float* base = part2 + ((size_t)b * nslab2 * C2 + c2_lo) * 2;
+            const int items = n2 * nslab2;
+            for (int it0 = lane; it0 < items; it0 += 256) {          // 4 independent loads in flight per lane
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int it = it0 + u * 64;
+                    const int sl = it / n2, cj = it - sl * n2;
+                    v[u] = (it < items) ? *reinterpret_cast<const float2*>(base + ((size_t)sl * C2 + cj) * 2) : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            q += __shfl_xor(q, o);
+        }
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        for (int c = max(c_lo, c0) + lane; c < min(c_hi, c1); c += 64) {
+            const float a = rstd * gamma[c];
+            ab_s[(c - c0) * 2] = a;
+            ab_s[(c - c0) * 2 + 1] = beta[c] - meanf * a;
+        }
+    }
+    __syncthreads();
+    const int chunk = threadIdx.x & 7;                   // 8 channels
+    const int c = c0 + chunk * 8;
+    if (c >= c1) return;
+    float a8[8], b8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a8[j] = ab_s[(chunk * 8 + j) * 2]; b8[j] = ab_s[(chunk * 8 + j) * 2 + 1]; }
+    const int p_begin = blockIdx.y * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    const bool first = c < C1;
+    const h16* src = first ? x1 + (size_t)b * HW * C1 + c : x2 + (size_t)b * HW * C2 + (c - C1);
+    const int sstride = first ? C1 : C2;
+    h16* dst = y + (size_t)b * HW * C + c;
+#pragma unroll 4
+    for (int p = p_begin + (threadIdx.x >> 3); p < p_end; p += 32) {
+        const uint4 raw = bc_ld16(src + (size_t)p * sstride);
+        const h16* v = reinterpret_cast<const h16*>(&raw);
+        uint4 outraw;
+        h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = (float)v[j] * a8[j] + b8[j];
+            if (silu) r = bc_silu_f(r);
+            o[j] = (h16)r;
+        }
+        bc_st16(dst + (size_t)p * C, outraw);
+    }
+}
+
 // LayerNorm: one wave per row; the row (C <= 64*8*MAXC elements) lives in registers, two-pass statistics.
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ x, int rows, int C, int ldx,
@@ -197,8 +310,7 @@ extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, 
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BC_CHECK_ARG(x && part && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "bc_gn_stats: bad args (C %% 8 == 0)");
     BC_CHECK_ARG(nslab == bc_ceil_div(HW, GN_PIX_PER_SLAB), "bc_gn_stats: nslab must be ceil(HW/%d)", GN_PIX_PER_SLAB);
-    int threads = std::min(256, ((C / 8 + 63) / 64) * 64);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(threads), 0, stream, reinterpret_cast<const h16*>(x), C, HW, part,
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x), C, HW, part,
                        nslab);
     BC_CHECK_LAUNCH();
     return 0;
@@ -232,6 +344,26 @@ extern "C" int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2,
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x1), C1,
                        reinterpret_cast<const h16*>(x2), C2, HW, nchunk, (unsigned)mul, 31 + l, ab, silu,
                        reinterpret_cast<h16*>(y));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2,
+                                 const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
+                                 const float* beta, int silu, bc_half* y, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!part2 || !x2) { C2 = 0; nslab2 = 0; part2 = nullptr; x2 = nullptr; }
+    const int C = C1 + C2;
+    BC_CHECK_ARG(part1 && x1 && y && gamma && beta && G > 0 && C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && nslab1 > 0,
+                 "bc_gn_apply_fused: bad args");
+    const int cblocks = bc_ceil_div(C, 64);
+    // ~512 workgroups in total, at least 32 pixels each (the prologue's partial re-reduction is amortised over the pixels)
+    int pblocks = std::max(1, std::min(bc_ceil_div(HW, 32), bc_ceil_div(512, cblocks * B)));
+    int ppb = bc_ceil_div(bc_ceil_div(HW, pblocks), 32) * 32;
+    pblocks = bc_ceil_div(HW, ppb);
+    hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(cblocks, pblocks, B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2,
+                       C2, reinterpret_cast<const h16*>(x1), reinterpret_cast<const h16*>(x2), HW, G, eps, gamma, beta, silu,
+                       ppb, reinterpret_cast<h16*>(y));
     BC_CHECK_LAUNCH();
     return 0;
 }

@@ -284,20 +284,25 @@ class Recorder:
             if hit is not None and hit[0].shape[2] == c:
                 srcs.append((hit[0], hit[1]))
             else:
-                nslab = (HW + 15) // 16
+                nslab = (HW + 127) // 128
                 part = self.empty(B, nslab, c, 2, dtype=torch.float32)
                 stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
                 srcs.append((part, nslab))
         (pa1, ns1), (pa2, ns2) = srcs
         p1, p2, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
         pp1, pp2 = ptr(pa1), ptr(pa2)
+        fused = not os.environ.get("BC_GN_UNFUSED")
 
         def fn(stream):
             rc = 0
             for (px, c, pp, ns) in stats_calls:
                 rc = rc or lib.bc_gn_stats(px, c, B, HW, pp, ns, stream)
-            rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
-            rc = rc or lib.bc_gn_apply(p1, C1, p2, c2, B, HW, pab, 1 if silu else 0, po, stream)
+            if fused:
+                rc = rc or lib.bc_gn_apply_fused(pp1, ns1, C1, pp2, ns2, c2, p1, p2, B, HW, G, eps, pg, pb, 1 if silu else 0, po,
+                                                 stream)
+            else:
+                rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
+                rc = rc or lib.bc_gn_apply(p1, C1, p2, c2, B, HW, pab, 1 if silu else 0, po, stream)
             if rc:
                 _lib.check(rc, "groupnorm")
 

@@ -104,7 +104,7 @@ int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int*
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
  * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
  * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
- *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/16)][C][2] (no atomics: bit-reproducible).
+ *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/128)][C][2] (no atomics: bit-reproducible).
  *                    Only needed when the producing GEMM did not emit them itself (BcGemm.gn_part).
  *   bc_gn_finalize : per-channel affine of the concat (x1 | x2): ab[B][C1+C2][2] = (rstd*gamma, beta - mean*rstd*gamma),
  *                    from part_i[B][nslab_i][C_i][2] (part2 may be NULL)
@@ -115,6 +115,11 @@ int bc_gn_finalize(const float* part1, int nslab1, int C1, const float* part2, i
                    float eps, const float* gamma, const float* beta, float* ab, bc_stream stream);
 int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW,
                 const float* ab, int silu, bc_half* y, bc_stream stream);
+/* finalize + apply in ONE launch (what the engine uses): every workgroup re-reduces the partials of the groups overlapping
+ * its 64-channel range, then normalises its pixels. */
+int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2,
+                      const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
+                      const float* beta, int silu, bc_half* y, bc_stream stream);
 
 /* LayerNorm over the last dim of [rows][C]  (attention.py:447,491,517; transformers Dinov2Layer norm1/norm2/layernorm). */
 int bc_layernorm(const bc_half* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,
