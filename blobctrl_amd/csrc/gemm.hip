@@ -488,6 +488,9 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     auto aligned16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     g.vec_epilogue = p.out_mode == BC_OUT_F16 && g.n_out % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                      (!p.R || (p.ldr % 8 == 0 && aligned16(p.R))) && (!p.R2 || (p.ldr2 % 8 == 0 && aligned16(p.R2)));
+    static const bool no_vec_t = getenv("BC_NO_VEC_T") != nullptr;
+    g.vec_transposed = !no_vec_t && p.out_mode == BC_OUT_F16_T && p.rows_per_batch % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
+                       p.act == BC_ACT_NONE && !p.rowvec && !p.colscale && !p.R && !p.R2;
     if (p.gn_part) {
         const int slab_rows = p.splitk > 1 ? SK_ROWS : g.bm;
         BC_CHECK_ARG((fast_ok || p.splitk > 1) && g.vec_epilogue && p.N % 4 == 0 && p.rows_per_batch % slab_rows == 0 &&

@@ -39,6 +39,7 @@ struct GemmArgs {
     int cfg;             // resolved BC_TILE_* configuration
     int bm, bn;          // its tile shape
     int vec_epilogue;    // 1: LDS-staged 16-byte epilogue is legal (fp16 row-major output, widths % 8 == 0)
+    int vec_transposed;  // 1: BC_OUT_F16_T with rows_per_batch % 8 == 0 and ldc % 8 == 0: 16-byte stores along the token axis
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
@@ -219,6 +220,53 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
         gq[j] += f * f;
     }
     bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)m * p.ldc + c.n_first, outraw);
+}
+
+// Transposed parking of the accumulators: tileT[n][m] with row stride ts (= BM + 4: the 32 lanes of a store hit 32 different
+// rows, the +4 floats keep them on different banks).  Lane holds column n = lane&31 and 4 consecutive rows per register group.
+template <int TM, int TN>
+__device__ __forceinline__ void acc_to_tile_t(float* tile, int ts, const f32x16 (&acc)[TM][TN], int wave_m0, int wave_n0,
+                                              int frow, int fhalf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+                *reinterpret_cast<float4*>(tile + (wave_n0 + j * 32 + frow) * ts + wave_m0 + i * 32 + 8 * g4 + 4 * fhalf) = v;
+            }
+}
+
+// BC_OUT_F16_T epilogue (V^T for attention): thread = (output column n, 8 consecutive tokens) -> one 16-byte store into
+// C[(b*N + n)*ldc + pix].  Supports bias and alpha (what the V projections use); anything else takes the scalar path.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, const float* tileT, int ts, int m0, int n0, int tid) {
+    const BcGemm& p = g.p;
+    float alpha = p.alpha;
+    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    constexpr int MCH = BM / 8;                       // 8-token chunks per column
+    for (int idx = tid; idx < BN * MCH; idx += NT) {
+        const int col = idx / MCH, mc = idx - col * MCH;
+        const int n = n0 + col, m = m0 + mc * 8;
+        if (n >= p.N || m >= p.M) continue;
+        const float4 lo = *reinterpret_cast<const float4*>(tileT + col * ts + mc * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(tileT + col * ts + mc * 8 + 4);
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const int b = (int)fdiv((unsigned)m, g.div_rpb);
+        const int pix = m - b * (int)g.div_rpb.d;
+        uint4 outraw;
+        h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (h16)((v[j] + bias) * alpha);
+        h16* dst = reinterpret_cast<h16*>(p.C) + ((size_t)b * g.n_out + n) * p.ldc + pix;
+        if (m + 8 <= p.M) {
+            bc_st16(dst, outraw);
+        } else {
+            for (int j = 0; j < p.M - m; ++j) dst[j] = o[j];
+        }
+    }
 }
 
 }  // namespace bcg

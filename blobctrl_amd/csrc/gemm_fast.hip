@@ -214,6 +214,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
     // ------------------------------------------------------------------------------------------------ epilogue
     __syncthreads();                                   // all waves are done reading the operand stages
     float* tile = reinterpret_cast<float*>(smem);      // raw fp32 accumulators [BM][BN]
+    if (g.vec_transposed && p.splitk == 1) {
+        acc_to_tile_t<TM, TN>(tile, BM + 4, acc, wm * (BM / WM), wn * (BN / WN), frow, fhalf);
+        __syncthreads();
+        tile_epilogue_transposed<BM, BN, NT>(g, tile, BM + 4, m0, n0, tid);
+        return;
+    }
     acc_to_tile<TM, TN>(tile, BN, acc, wm * (BM / WM), wn * (BN / WN), frow, fhalf);
     __syncthreads();
     if (p.splitk > 1 || !g.vec_epilogue) {
@@ -299,7 +305,7 @@ int launch_fast(const GemmArgs& g, hipStream_t stream) {
     const BcGemm& p = g.p;
     dim3 grid(bc_ceil_div(p.N, BN), bc_ceil_div(p.M, BM), p.splitk);
     dim3 block(64 * WM * WN);
-    size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BM * BN * 4);
+    size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BN * (BM + 4) * 4);   // stages | epilogue tile (| transposed, padded)
     static bool attr_set = false;
     if (!attr_set) {
         BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>),
