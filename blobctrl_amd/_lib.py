@@ -22,7 +22,7 @@ class BcGemm(C.Structure):
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("lda2", C.c_int), ("C1", C.c_int), ("Cin", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("Hv", C.c_int), ("Wv", C.c_int),
-        ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int),
+        ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("conv_nopad_lo", C.c_int),
         ("W", C.c_void_p), ("ldw", C.c_int),
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int), ("rows_per_batch", C.c_int),
         ("act", C.c_int), ("colscale", C.c_void_p), ("alpha", C.c_float),
@@ -50,6 +50,8 @@ _SIGNATURES = {
                                     C.c_void_p]),
     "bc_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p]),
+    "bc_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bc_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "bc_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                C.c_int, C.c_void_p]),
     "bc_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -202,6 +202,21 @@ __global__ void patchify_kernel(const float* __restrict__ px, int B, int H, int 
     }
 }
 
+// vae.py:767-789: mean + exp(0.5 * clamp(logvar, -30, 20)) * noise, times the latent scaling factor
+__global__ void gaussian_sample_kernel(const h16* __restrict__ mom, const float* __restrict__ noise, int B, int Cz, int HW,
+                                       float scale, float* __restrict__ out) {
+    const long long total = (long long)B * Cz * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int p = (int)(i % HW);
+        int c = (int)((i / HW) % Cz);
+        int b = (int)(i / ((long long)HW * Cz));
+        const h16* m = mom + ((size_t)b * HW + p) * (2 * Cz);
+        float mean = (float)m[c];
+        float logvar = fminf(fmaxf((float)m[Cz + c], -30.f), 20.f);
+        out[i] = (mean + expf(0.5f * logvar) * noise[i]) * scale;
+    }
+}
+
 inline int ew_blocks(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -305,6 +320,17 @@ extern "C" int bc_patchify(const float* pixels, int B, int H, int W, int patch, 
     long long total = (long long)B * (H / patch) * (W / patch) * Kpad;
     hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, pixels, B, H, W, patch, Kpad,
                        reinterpret_cast<h16*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_gaussian_sample(const bc_half* moments, const float* noise, int B, int Cz, int HW, float scale, float* out,
+                                  bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(moments && noise && out && B > 0 && Cz > 0 && HW > 0, "bc_gaussian_sample: bad args");
+    long long total = (long long)B * Cz * HW;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream,
+                       reinterpret_cast<const h16*>(moments), noise, B, Cz, HW, scale, out);
     BC_CHECK_LAUNCH();
     return 0;
 }

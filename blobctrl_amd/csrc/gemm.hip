@@ -64,8 +64,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             int oy = (int)fdiv((unsigned)rem, g.div_wout);
             int ox = rem - oy * p.Wout;
             a_base[i] = b * p.Hin * p.Win;
-            a_iy0[i] = ok ? oy * p.stride - 1 : -(1 << 20);
-            a_ix0[i] = ox * p.stride - 1;
+            const int pad_lo = p.conv_nopad_lo ? 0 : 1;
+            a_iy0[i] = ok ? oy * p.stride - pad_lo : -(1 << 20);
+            a_ix0[i] = ox * p.stride - pad_lo;
         } else {
             a_base[i] = ok ? m : -1;
             a_iy0[i] = 0;
@@ -424,7 +425,8 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         if (p.Hv <= 0) p.Hv = p.Hin;
         if (p.Wv <= 0) p.Wv = p.Win;
         BC_CHECK_ARG(p.M % (p.Hout * p.Wout) == 0, "bc_gemm: conv M=%d not a multiple of Hout*Wout", p.M);
-        BC_CHECK_ARG(p.Hout == (p.Hv + 2 - 3) / p.stride + 1 && p.Wout == (p.Wv + 2 - 3) / p.stride + 1,
+        const int pads = p.conv_nopad_lo ? 1 : 2;
+        BC_CHECK_ARG(p.Hout == (p.Hv + pads - 3) / p.stride + 1 && p.Wout == (p.Wv + pads - 3) / p.stride + 1,
                      "bc_gemm: conv output size %dx%d inconsistent with input %dx%d stride %d", p.Hout, p.Wout, p.Hv, p.Wv, p.stride);
         BC_CHECK_ARG(p.A2 == nullptr, "bc_gemm: conv mode takes a single source");
         p.rows_per_batch = p.Hout * p.Wout;

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
                 a_mask[i] = ok ? 0x1ff : 0;
                 a2_off[i] = cs * 8;
             } else {
-                const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+                const int pad_lo = p.conv_nopad_lo ? 0 : 1;
+                const int iy0 = oy * p.stride - pad_lo, ix0 = ox * p.stride - pad_lo;
                 a_off[i] = (((long long)b * p.Hin + iy0) * p.Win + ix0) * p.Cin + cs * 8;
                 int mask = 0;
 #pragma unroll

@@ -304,6 +304,49 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16* __restrict__ 
     }
 }
 
+// Row softmax, one wave per row, fp32 maths, in place.  cols <= 64*8*MAXC.
+template <int MAXC>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(h16* __restrict__ x, int rows, int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = cols / 8;
+    float v[MAXC][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            uint4 raw = bc_ld16(x + (size_t)row * ld + ch * 8);
+            const h16* hh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)hh[j]; mx = fmaxf(mx, v[i][j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i][j] = __expf(v[i][j] - mx); sum += v[i][j]; }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            uint4 outraw;
+            h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (h16)(v[i][j] * inv);
+            bc_st16(x + (size_t)row * ld + ch * 8, outraw);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, int nslab, bc_stream stream_) {
@@ -379,6 +422,20 @@ extern "C" int bc_layernorm(const bc_half* x, int rows, int C, int ldx, const fl
     if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
     else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
     else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, xi, rows, C, ldx, gamma, beta, eps, yo, ldy);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_softmax_rows(bc_half* x, int rows, int cols, int ld, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(x && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols && cols <= 64 * 8 * 18,
+                 "bc_softmax_rows: cols=%d must be a multiple of 8 and <= 9216", cols);
+    dim3 grid(bc_ceil_div(rows, 4)), block(256);
+    h16* xi = reinterpret_cast<h16*>(x);
+    if (cols <= 512) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, stream, xi, rows, cols, ld);
+    else if (cols <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, stream, xi, rows, cols, ld);
+    else if (cols <= 4096) hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, block, 0, stream, xi, rows, cols, ld);
+    else hipLaunchKernelGGL(softmax_rows_kernel<18>, grid, block, 0, stream, xi, rows, cols, ld);
     BC_CHECK_LAUNCH();
     return 0;
 }

@@ -188,7 +188,7 @@ class Recorder:
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
-             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0):
+             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -203,8 +203,9 @@ class Recorder:
             g.Cin, g.Hin, g.Win = conv["Cin"], conv["Hin"], conv["Win"]
             g.Hv, g.Wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
             g.Hout, g.Wout, g.stride = conv["Hout"], conv["Wout"], conv.get("stride", 1)
+            g.conv_nopad_lo = 1 if conv.get("nopad_lo") else 0
         g.W = W.data_ptr() + w_offset * W.element_size()
-        g.ldw = K
+        g.ldw = ldw if ldw is not None else K
         g.bias = ptr(bias)
         g.rowvec = ptr(rowvec) if not isinstance(rowvec, int) else rowvec
         g.ld_rowvec, g.rows_per_batch = ld_rowvec, rows_per_batch

@@ -163,6 +163,58 @@ def dinov2_param_shapes(hidden: int, layers: int, mlp_ratio: int, patch: int, nu
     return s
 
 
+def vae_param_shapes(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, in_channels=3,
+                     out_channels=3) -> "OrderedDict[str, tuple]":
+    """`AutoencoderKL.state_dict()` layout of the SD-1.5 VAE (D/models/autoencoders/autoencoder_kl.py:72-137, vae.py:47-348)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    boc = tuple(block_out_channels)
+    nb = len(boc)
+
+    def res(p, cin, cout):
+        s[p + "norm1.weight"] = (cin,); s[p + "norm1.bias"] = (cin,)
+        s[p + "conv1.weight"] = (cout, cin, 3, 3); s[p + "conv1.bias"] = (cout,)
+        s[p + "norm2.weight"] = (cout,); s[p + "norm2.bias"] = (cout,)
+        s[p + "conv2.weight"] = (cout, cout, 3, 3); s[p + "conv2.bias"] = (cout,)
+        if cin != cout:
+            s[p + "conv_shortcut.weight"] = (cout, cin, 1, 1); s[p + "conv_shortcut.bias"] = (cout,)
+
+    def mid(p, c):
+        s[p + "attentions.0.group_norm.weight"] = (c,); s[p + "attentions.0.group_norm.bias"] = (c,)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s[p + f"attentions.0.{n}.weight"] = (c, c); s[p + f"attentions.0.{n}.bias"] = (c,)
+        res(p + "resnets.0.", c, c)
+        res(p + "resnets.1.", c, c)
+
+    s["encoder.conv_in.weight"] = (boc[0], in_channels, 3, 3); s["encoder.conv_in.bias"] = (boc[0],)
+    ch = boc[0]
+    for i in range(nb):
+        for j in range(layers_per_block):
+            res(f"encoder.down_blocks.{i}.resnets.{j}.", ch if j == 0 else boc[i], boc[i])
+        if i < nb - 1:
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (boc[i], boc[i], 3, 3)
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (boc[i],)
+        ch = boc[i]
+    mid("encoder.mid_block.", boc[-1])
+    s["encoder.conv_norm_out.weight"] = (boc[-1],); s["encoder.conv_norm_out.bias"] = (boc[-1],)
+    s["encoder.conv_out.weight"] = (2 * latent_channels, boc[-1], 3, 3); s["encoder.conv_out.bias"] = (2 * latent_channels,)
+    rev = list(reversed(boc))
+    s["decoder.conv_in.weight"] = (rev[0], latent_channels, 3, 3); s["decoder.conv_in.bias"] = (rev[0],)
+    ch = rev[0]
+    for i in range(nb):
+        for j in range(layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}.", ch if j == 0 else rev[i], rev[i])
+        if i < nb - 1:
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (rev[i], rev[i], 3, 3)
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (rev[i],)
+        ch = rev[i]
+    mid("decoder.mid_block.", rev[0])
+    s["decoder.conv_norm_out.weight"] = (boc[0],); s["decoder.conv_norm_out.bias"] = (boc[0],)
+    s["decoder.conv_out.weight"] = (out_channels, boc[0], 3, 3); s["decoder.conv_out.bias"] = (out_channels,)
+    s["quant_conv.weight"] = (2 * latent_channels, 2 * latent_channels, 1, 1); s["quant_conv.bias"] = (2 * latent_channels,)
+    s["post_quant_conv.weight"] = (latent_channels, latent_channels, 1, 1); s["post_quant_conv.bias"] = (latent_channels,)
+    return s
+
+
 def synth_tensor(name: str, shape: tuple, seed: int) -> np.ndarray:
     """One parameter, float32, from a PCG64 stream keyed by (seed, crc32(name)).
 

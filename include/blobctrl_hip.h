@@ -55,7 +55,9 @@ typedef struct BcGemm {
     int Hin, Win;            /* CONV3X3: stored input image size */
     int Hv, Wv;              /* CONV3X3: virtual (nearest-upsampled) input size the 3x3 window slides over; = Hin,Win when no upsample */
     int Hout, Wout;          /* CONV3X3: output size */
-    int stride;              /* CONV3X3: 1 or 2 (pad is always 1) */
+    int stride;              /* CONV3X3: 1 or 2 */
+    int conv_nopad_lo;       /* CONV3X3: 0 = pad 1 on every side; 1 = no top/left padding (pad only bottom/right): the VAE encoder's
+                              * Downsample2D(padding=0) = F.pad(x, (0,1,0,1)) + conv stride 2 (D/models/downsampling.py:141-147) */
     /* ---- B operand ---- */
     const bc_half* W;        /* [N][ldw], K contiguous */
     int ldw;
@@ -120,6 +122,15 @@ int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int
 int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2,
                       const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
                       const float* beta, int silu, bc_half* y, bc_stream stream);
+
+/* Row softmax in place on fp16 [rows][cols] (fp32 maths): the single-head, head_dim-512 attention of the VAE mid block is run
+ * as GEMM (QK^T) -> softmax -> GEMM (PV)  (attention_processor.py:2216 with heads = 1). */
+int bc_softmax_rows(bc_half* x, int rows, int cols, int ld, bc_stream stream);
+
+/* Posterior sample of the VAE encoder (D/models/autoencoders/vae.py:767-789): moments token-major [B][HW][2*Cz] (mean | logvar),
+ * noise fp32 NCHW [B][Cz][HW]; out fp32 NCHW = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale. */
+int bc_gaussian_sample(const bc_half* moments, const float* noise, int B, int Cz, int HW, float scale, float* out,
+                       bc_stream stream);
 
 /* LayerNorm over the last dim of [rows][C]  (attention.py:447,491,517; transformers Dinov2Layer norm1/norm2/layernorm). */
 int bc_layernorm(const bc_half* x, int rows, int C, int ldx, const float* gamma, const float* beta, float eps,

@@ -120,3 +120,15 @@ def test_dinov2_oracle_vs_transformers():
     x = g(3, 1, 3, 42, 42)
     np.testing.assert_allclose(o_dino.dinov2_pooled(sd, x, 2, 14).numpy(), model(pixel_values=x).pooler_output.numpy(),
                                rtol=1e-4, atol=1e-5)
+
+
+def test_vae_oracle_vs_reference_fixture(golden_dir):
+    from oracle import vae as o_vae
+    z = load(golden_dir, "vae_tiny.npz")
+    sd = synth.synth_state_dict(synth.vae_param_shapes((32, 32, 64, 64), 2, 4), 21)
+    mom = o_vae.encode_moments(sd, torch.from_numpy(z["img"]), groups=8)
+    np.testing.assert_allclose(mom.numpy(), z["moments"], rtol=1e-4, atol=1e-5)
+    smp = o_vae.sample_posterior(mom, torch.from_numpy(z["noise"]), scale=1.0)
+    np.testing.assert_allclose(smp.numpy(), z["sample"], rtol=1e-4, atol=1e-5)
+    dec = o_vae.decode(sd, torch.from_numpy(z["z"]), groups=8)
+    np.testing.assert_allclose(dec.numpy(), z["decoded"], rtol=1e-4, atol=1e-5)

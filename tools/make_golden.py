@@ -256,8 +256,44 @@ def golden_dinov2():
     print("dinov2: pooled std %.4f" % out["native_pooled"].std())
 
 
+# ------------------------------------------------------------------------------------------------ 6. VAE
+def golden_vae():
+    from diffusers import AutoencoderKL
+    with torch.device("meta"):
+        full = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
+                             up_block_types=("UpDecoderBlock2D",) * 4, block_out_channels=(128, 256, 512, 512),
+                             layers_per_block=2, latent_channels=4, norm_num_groups=32, sample_size=512)
+    sh = synth.vae_param_shapes()
+    ref = {k: tuple(v.shape) for k, v in full.state_dict().items()}
+    assert set(ref) == set(sh) and all(ref[k] == tuple(sh[k]) for k in ref), "VAE schema mismatch"
+    print(f"full-size VAE: {len(ref)} tensors, {sum(int(np.prod(v)) for v in ref.values())/1e6:.1f} M params - schema OK")
+    boc = (32, 32, 64, 64)
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4, block_out_channels=boc, layers_per_block=2,
+                        latent_channels=4, norm_num_groups=8, sample_size=32).eval()
+    tsh = synth.vae_param_shapes(boc, 2, 4)
+    assert set(tsh) == set(vae.state_dict().keys())
+    vae.load_state_dict(synth.synth_state_dict(tsh, 21), strict=True)
+    out = {}
+    x = g(51, 2, 3, 32, 48).clamp(-1, 1)
+    post = vae.encode(x).latent_dist
+    out["img"] = x.numpy()
+    out["moments"] = post.parameters.numpy()
+    z = g(52, 2, 4, 4, 6)
+    out["z"] = z.numpy()
+    out["decoded"] = vae.decode(z, return_dict=False)[0].numpy()
+    gen = torch.Generator().manual_seed(5)
+    noise = torch.randn(post.mean.shape, generator=gen)
+    gen = torch.Generator().manual_seed(5)
+    out["noise"] = noise.numpy()
+    out["sample"] = post.sample(generator=gen).numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), **out)
+    print("vae: decoded std %.4f moments std %.4f" % (out["decoded"].std(), out["moments"].std()))
+
+
 if __name__ == "__main__":
     check_full_schema()
+    golden_vae()
     golden_splat()
     golden_schedulers()
     golden_dinov2()
