@@ -3,8 +3,9 @@
 Mirrors blobctrl/pipelines/pipeline_blobnet.py:743-1166 for the hot-path part:
 same keyword names and meaning (`num_inference_steps`, `guidance_scale`, `generator`, `latents`,
 `blobnet_conditioning_scale` (must be a Python float, pipe:395-396), `blobnet_control_guidance_start/end`,
-`output_type="latent"`), same error behaviour for bad arguments.  VAE encode/decode and the CLIP text encoder sit on
-either side of the loop and are out of scope this round: callers pass image latents and prompt embeddings.
+`output_type`), same error behaviour for bad arguments.  The VAE either side of the loop is optional:
+with `vae=blobctrl_amd.vae.AutoencoderKL(...)` the call also accepts `fg_image` / `bg_image` (pipe:970-971) and returns decoded
+images for `output_type="pt" | "np"` (pipe:1132-1146); the CLIP text encoder stays outside (callers pass prompt embeddings).
 
 Execution model: one static launch plan per (batch, canvas, steps) configuration -
     prologue (once per edit): cross-attention K/V of the prompt embeddings
@@ -35,7 +36,7 @@ class StableDiffusionBlobNetPipeline:
     """MI355X engine with the reference pipeline's call surface for the denoising hot path."""
 
     def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
-                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True):
+                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.BlobCtrlHipError("blobctrl_amd runs on MI355X only (device must be cuda:N); there is no CPU fallback")
@@ -55,6 +56,7 @@ class StableDiffusionBlobNetPipeline:
         self._plans = {}
         self._sched_cache = {}
         self.feat_dim = blobnet_config.in_channels - 5
+        self.vae = vae                                                # optional blobctrl_amd.vae.AutoencoderKL
 
     # ------------------------------------------------------------------------------------------------ planning
     def _plan(self, B, h, w, T, ctx_dim, nsteps):
@@ -179,19 +181,54 @@ class StableDiffusionBlobNetPipeline:
         if num_inference_steps < 1:
             raise ValueError("num_inference_steps must be >= 1")
 
+    def encode_latents(self, image: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """pipe:300-309: image [1,3,H,W] in [-1,1] -> posterior sample * scaling_factor, [1,4,H/8,W/8] fp32."""
+        if self.vae is None:
+            raise ValueError("this pipeline was built without a VAE: pass fg_image_latents / bg_image_latents, or vae=...")
+        with torch.cuda.stream(self.stream):
+            lat = self.vae.encode(image).latent_dist.sample(generator, scale=self.vae.config.scaling_factor)
+        self.stream.synchronize()
+        return lat
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        """pipe:1132-1146: vae.decode(latents / scaling_factor) then VaeImageProcessor.postprocess with denormalisation
+        ((x/2+0.5).clamp(0,1); "pt" = [B,3,H,W] tensor, "np" = [B,H,W,3] numpy)."""
+        if self.vae is None:
+            raise ValueError("this pipeline was built without a VAE: use output_type='latent', or pass vae=...")
+        with torch.cuda.stream(self.stream):
+            img = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
+            img = (img / 2 + 0.5).clamp(0, 1)
+        self.stream.synchronize()
+        return img if output_type == "pt" else img.permute(0, 2, 3, 1).cpu().float().numpy()
+
     @torch.no_grad()
-    def __call__(self, prompt_embeds: torch.Tensor, fg_image_latents: torch.Tensor, bg_image_latents: torch.Tensor,
-                 gs_score: torch.Tensor, dino_feats: Optional[torch.Tensor] = None, num_inference_steps: int = 50,
+    def __call__(self, prompt_embeds: torch.Tensor, fg_image_latents: Optional[torch.Tensor] = None,
+                 bg_image_latents: Optional[torch.Tensor] = None, gs_score: torch.Tensor = None, dino_feats: Optional[torch.Tensor] = None, num_inference_steps: int = 50,
                  guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None,
                  latents: Optional[torch.Tensor] = None, blobnet_conditioning_scale: float = 1.0,
                  blobnet_control_guidance_start: float = 0.0, blobnet_control_guidance_end: float = 1.0,
                  output_type: str = "latent", callback_on_step_end=None, trace: Optional[list] = None,
-                 teacher_latents: Optional[List[torch.Tensor]] = None):
+                 teacher_latents: Optional[List[torch.Tensor]] = None, fg_image: Optional[torch.Tensor] = None,
+                 bg_image: Optional[torch.Tensor] = None):
         """prompt_embeds [2B, T, D] = cat(negative, positive) (pipe:937-949); fg/bg_image_latents [1,4,h,w] already scaled
         by 0.18215 (pipe:300-309); gs_score [1,2,h,w] = (bg, fg) scores (pipe:974); dino_feats [1,1,F] (pipe:982).
-        Returns the final latents [B,4,h,w] fp32 (`output_type="latent"`, pipe:1132,1143)."""
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode is outside the hot path (SURVEY 8f): use output_type='latent'")
+        Instead of the latents, `fg_image` / `bg_image` [1,3,8h,8w] in [-1,1] may be given when the pipeline has a VAE.
+        Returns the final latents [B,4,h,w] fp32 for `output_type="latent"` (pipe:1143), else the decoded, denormalised
+        images ("pt" / "np", pipe:1132-1146)."""
+        if output_type not in ("latent", "pt", "np"):
+            raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
+        if output_type != "latent" and self.vae is None:
+            raise ValueError("this pipeline was built without a VAE: use output_type='latent', or pass vae=...")
+        if gs_score is None:
+            raise ValueError("gs_score is required")
+        if fg_image_latents is None:
+            if fg_image is None:
+                raise ValueError("give fg_image_latents or fg_image")
+            fg_image_latents = self.encode_latents(fg_image)
+        if bg_image_latents is None:
+            if bg_image is None:
+                raise ValueError("give bg_image_latents or bg_image")
+            bg_image_latents = self.encode_latents(bg_image)
         self.check_inputs(blobnet_conditioning_scale, blobnet_control_guidance_start, blobnet_control_guidance_end,
                           num_inference_steps)
         B2, T, Dc = prompt_embeds.shape
@@ -257,7 +294,8 @@ class StableDiffusionBlobNetPipeline:
                 self.stream.synchronize()
                 callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
         torch.cuda.synchronize(self.device)
-        return P.latents.clone()
+        out = P.latents.clone()
+        return out if output_type == "latent" else self.decode_latents(out, output_type)
 
     # convenience for bench / tests ------------------------------------------------------------------
     def plan_for(self, B, h, w, T, ctx_dim, nsteps):

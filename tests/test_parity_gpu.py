@@ -131,8 +131,12 @@ def test_pipeline_argument_errors():
     with pytest.raises(ValueError):
         pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2,
              blobnet_control_guidance_start=0.9, blobnet_control_guidance_end=0.5)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, output_type="pil")
+    with pytest.raises(ValueError):                                  # built without a VAE: images can be neither read nor made
+        pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, output_type="pt")
+    with pytest.raises(ValueError):
+        pipe(a["prompt"], None, a["bg"], a["score"], a["dino"], num_inference_steps=2)
 
 
 def test_remove_edit_skips_blobnet():
