@@ -4,13 +4,13 @@
 // N = 8192/2048/512/128 tokens and head_dim 40/80/160, UNet cross-attention to 77 CLIP tokens) and the eager attention of
 // transformers' Dinov2SelfAttention (257 tokens, head_dim 64).
 //
-// Structure (per workgroup: 4 waves x 32 query rows, KV tiles of 64 keys staged in LDS):
+// Structure (per workgroup: 4 waves x 1 or 2 blocks of 32 query rows, KV tiles of 64 keys staged in LDS):
 //   S^T = K . Q^T   "swapped" product: MFMA A-operand = K rows from LDS, B-operand = Q rows held in registers, so each
 //                   lane owns ONE query column and 16 keys per 32-key tile -> row max / sum are in-lane + one xor-32 shuffle.
 //   P   = exp2(S^T - m)   (scale * log2(e) is folded into Q once), fp32 online softmax.
 //   O^T += V^T . P^T      the S^T accumulator registers, converted to fp16, ARE the B operand of the next MFMA
-//                         (cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand"); the matching
-//                         k-permutation is applied to the V^T fragment read (two ds_read_b64 per fragment).
+//                         (cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand"); the K rows
+//                         are fed in a bit-swapped order so that the matching V^T fragment is ONE aligned ds_read_b128.
 //   V arrives TRANSPOSED from the to_v GEMM epilogue (BC_OUT_F16_T), so the V^T tile is a coalesced row copy.
 //   When D is not a multiple of 32 the padded V^T tile carries a row of ones, which makes the MFMA produce the softmax
 //   denominator for free (removes 32 v_add per tile from the VALU-bound D=40 case).
@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int QW = 32;        // queries per wave
+constexpr int QW = 32;        // queries per query block (one MFMA column tile)
 constexpr int KVT = 64;       // keys per tile
 
 template <int D>
@@ -31,22 +31,41 @@ struct AttnCfg {
     static constexpr bool ONES = (D % 32) != 0;        // spare padded V^T row available for the row sum
     static constexpr bool BIAS = (D % 16) != 0;        // spare padded K column available: K[:, D] = 1, Q[:, D] = -m_ref
     static constexpr int K_STRIDE = DK + 8;            // halfs; (DK/8 + 1) odd 16-byte slots -> conflict-free ds_read_b128
-    static constexpr int V_STRIDE = KVT + 4;           // halfs; 17 x 8-byte slots -> conflict-free ds_read_b64
+    static constexpr int V_STRIDE = KVT + 8;           // halfs; 9 x 16-byte slots (odd) -> conflict-free ds_read_b128
     static constexpr int STAGE_HALFS = KVT * K_STRIDE + DP * V_STRIDE;
     static constexpr int LDS_BYTES = 2 * STAGE_HALFS * 2;          // two stages
 };
 
 constexpr float RESCALE_THR = 6.0f;    // log2 units: P <= 64 between reference updates (fp16 P, fp32 accumulation)
 
-// NW = waves (x 32 queries) per workgroup.
+// NOTE: no inline asm on MFMA results - the compiler's hazard recogniser does not see inside asm strings and would not insert the
+// wait states an MFMA -> VALU read needs (measured: wrong maxima on the first registers of a tile).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+// max over the two 32-lane halves (lane l <-> lane l^32) with v_permlane32_swap: VALU-only, no LDS crossbar round trip
+__device__ __forceinline__ float halves_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// NW = waves per workgroup, QB = 32-query blocks per wave (a wave's K / V^T fragment reads from LDS are shared by its QB blocks
+// and the blocks' MFMA and softmax chains are independent, so the scheduler can run one block's exp2 under the other's MFMAs).
 //
 // Pipeline: K / V^T tiles are double-buffered in LDS; the global loads of tile t+1 are issued into registers before tile t is
-// multiplied and written to the other LDS stage afterwards (one barrier per tile, HBM/L2 latency hidden under the MFMAs).
+// multiplied and written to the other LDS stage afterwards (one barrier per tile, HBM/L2 latency hidden under the MFMAs).  Each
+// (wave, load slot) stages either a K piece or a V^T piece - a wave-uniform choice, so the staging code has no divergent
+// branches.
+// Key permutation: MFMA row i of the S^T tile is fed key pi(i) = i with bits 2 and 3 swapped.  The S^T accumulator registers
+// 8 s2 .. 8 s2 + 7 of lane-half h then hold the 8 CONSECUTIVE keys 16 s2 + 8 h .. + 7, so the matching V^T fragment is one
+// aligned ds_read_b128.
 // Softmax reference: instead of subtracting the running maximum from every score (32 VALU ops per tile and lane), the kernel
 // keeps a per-query reference m_ref and, when head_dim leaves a padded K column (D = 40: columns 40..47), lets the MFMA do the
 // subtraction: K[:, D] = 1 and Q[:, D] = -m_ref (fp16; any consistent reference is valid for online softmax).  m_ref only moves
 // when a score exceeds it by more than RESCALE_THR (wave-uniform slow path), so the steady state is exp2 + max + pack only.
-template <int D, int NW>
+template <int D, int NW, int QB>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                          const h16* __restrict__ Vt, h16* __restrict__ O, int Nq, int Nkv,
                                                          int ldq, int ldk, int ldvt, int ldo, long long q_bs, long long k_bs,
@@ -55,24 +74,27 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* lds = reinterpret_cast<h16*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qcol = lane & 31, half = lane >> 5;
+    const int krow = (qcol & ~12) | ((qcol & 4) << 1) | ((qcol & 8) >> 1);      // pi(qcol)
     // XCD-aware remap: an XCD's L2 then serves the K / V of a few (batch, head) pairs to all of their query blocks
     const int nwg = gridDim.x * gridDim.y * gridDim.z;
     const int lin = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg);
     const int qblk = lin % (int)gridDim.x, head = (lin / (int)gridDim.x) % (int)gridDim.y, b = lin / (int)(gridDim.x * gridDim.y);
     constexpr int NT = 64 * NW;
-    const int q0 = qblk * (QW * NW) + wave * QW;
+    const int q0 = qblk * (QW * QB * NW) + wave * (QW * QB);
 
     const h16* Qb = Q + (size_t)b * q_bs + (size_t)head * D;
     const h16* Kb = K + (size_t)b * k_bs + (size_t)head * D;
     const h16* Vb = Vt + (size_t)b * vt_bs + (size_t)head * D * ldvt;
     h16* Ob = O + (size_t)b * o_bs + (size_t)head * D;
 
-    // ---- Q fragments (B operand): lane holds Q[q0 + qcol][16 s + 8 half .. +7], pre-scaled by scale*log2(e) ----
-    h16x8 qf[C::D16];
-    {
-        const int q = q0 + qcol;
+    // ---- Q fragments (B operand): lane holds Q[q][16 s + 8 half .. +7], pre-scaled by scale*log2(e) ----
+    h16x8 qf[QB][C::D16];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + qb * QW + qcol;
 #pragma unroll
         for (int s = 0; s < C::D16; ++s) {
             int dcol = 16 * s + 8 * half;
@@ -85,7 +107,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (h16)((float)h[j] * scale_log2e);
             }
-            qf[s] = v;
+            qf[qb][s] = v;
         }
     }
     // the bias slot: column D of the padded head_dim lives in fragment D/16, lane-half (D%16)/8, element D%8
@@ -110,56 +132,59 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
         }
     }
 
-    // ---- register prefetch of one K / V^T tile ----
-    constexpr int KCH = KVT * (D / 8), VCH = D * (KVT / 8);
-    constexpr int KL = (KCH + NT - 1) / NT, VL = (VCH + NT - 1) / NT;
-    uint4 kreg[KL], vreg[VL];
-    auto load_tile = [&](const int kbase, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
+    // ---- register prefetch of one K / V^T tile: 64-chunk pieces, piece p < KP is K, KP <= p < 2 KP is V^T ----
+    // Everything that does not depend on the tile is computed once here and the per-tile code is branch-free arithmetic on
+    // fixed registers: a branchy prefetch makes the compiler merge its paths with register copies, and the copies wait for
+    // the loads (s_waitcnt vmcnt(0) BEFORE the MFMAs - the prefetch would hide nothing).  K rows past Nkv are clamped to the
+    // last row (finite data; their scores are set to -inf by the masked tail tile).
+    constexpr int KP = KVT * (D / 8) / 64;                 // = D / 8 pieces of 64 x 16 bytes each for K and for V^T
+    constexpr int NL = (2 * KP + NW - 1) / NW;             // pieces per wave
+    const h16* sptr[NL];
+    int srow[NL], srowmul[NL], scolmul[NL], soff[NL];
+    bool sval[NL];
 #pragma unroll
-        for (int i = 0; i < KL; ++i) {
-            const int idx = tid + i * NT;
+    for (int i = 0; i < NL; ++i) {
+        const int piece = i * NW + wave;                   // wave-uniform
+        sval[i] = piece < 2 * KP;
+        if (piece < KP) {
+            const int idx = piece * 64 + lane;
             const int key = idx / (D / 8), ch = idx % (D / 8);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < KCH && (!MASKED || kbase + key < Nkv)) v = bc_ld16(Kb + (size_t)(kbase + key) * ldk + ch * 8);
-            kreg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < VL; ++i) {
-            const int idx = tid + i * NT;
+            sptr[i] = Kb + ch * 8;
+            srow[i] = key; srowmul[i] = ldk; scolmul[i] = 0;
+            soff[i] = key * C::K_STRIDE + ch * 8;
+        } else {
+            const int idx = (min(piece, 2 * KP - 1) - KP) * 64 + lane;      // a wave without a piece re-loads the last one
             const int r = idx / (KVT / 8), ch = idx % (KVT / 8);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < VCH) v = bc_ld16(Vb + (size_t)r * ldvt + kbase + ch * 8);   // Vt is zero-padded beyond Nkv by contract
-            vreg[i] = v;
+            sptr[i] = Vb + (size_t)r * ldvt + ch * 8;                       // Vt is zero-padded beyond Nkv by contract
+            srow[i] = 0; srowmul[i] = 0; scolmul[i] = 1;
+            soff[i] = KVT * C::K_STRIDE + r * C::V_STRIDE + ch * 8;
+        }
+    }
+    uint4 sreg[NL];
+    auto load_tile = [&](const int kbase) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int off = min(kbase + srow[i], Nkv - 1) * srowmul[i] + kbase * scolmul[i];
+            sreg[i] = bc_ld16(sptr[i] + off);
         }
     };
     auto store_tile = [&](const int st) {
-        h16* ldsK = lds + st * C::STAGE_HALFS;
-        h16* ldsV = ldsK + KVT * C::K_STRIDE;
+        h16* stage = lds + st * C::STAGE_HALFS;
 #pragma unroll
-        for (int i = 0; i < KL; ++i) {
-            const int idx = tid + i * NT;
-            const int key = idx / (D / 8), ch = idx % (D / 8);
-            if (idx < KCH) bc_st16(ldsK + key * C::K_STRIDE + ch * 8, kreg[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < VL; ++i) {
-            const int idx = tid + i * NT;
-            const int r = idx / (KVT / 8), ch = idx % (KVT / 8);
-            if (idx < VCH) {      // V_STRIDE*2 bytes = 136 is only 8-byte aligned: two 8-byte stores
-                uint2* dst = reinterpret_cast<uint2*>(ldsV + r * C::V_STRIDE + ch * 8);
-                dst[0] = make_uint2(vreg[i].x, vreg[i].y);
-                dst[1] = make_uint2(vreg[i].z, vreg[i].w);
-            }
-        }
+        for (int i = 0; i < NL; ++i)
+            if (sval[i]) bc_st16(stage + soff[i], sreg[i]);
     };
 
-    f32x16 oacc[C::DT];
+    f32x16 oacc[QB][C::DT];
 #pragma unroll
-    for (int t = 0; t < C::DT; ++t)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_ref = 0.f, l_run = 0.f;     // m_ref: reference exponent of this query's running softmax (exactly fp16-representable)
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][t][r] = 0.f;
+    float m_ref[QB], l_run[QB];     // m_ref: reference exponent of a query's running softmax (exactly fp16-representable)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_ref[qb] = 0.f; l_run[qb] = 0.f; }
     bool first = true;
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -169,90 +194,100 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
         constexpr bool MASKED = decltype(masked_tag)::value;
         const h16* ldsK = lds + st * C::STAGE_HALFS;
         const h16* ldsV = ldsK + KVT * C::K_STRIDE;
-        // ---- S'^T[kt] = K_tile[kt] . Q'^T  (two 32-key tiles); with BIAS the product already holds S - m_ref ----
-        f32x16 sacc[2];
+        // ---- S'^T[qb][kt] = K_tile[kt] . Q'^T[qb]  (two 32-key tiles); with BIAS the product already holds S - m_ref ----
+        f32x16 sacc[QB][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-#pragma unroll
             for (int s = 0; s < C::D16; ++s) {
-                const h16x8 kf = *reinterpret_cast<const h16x8*>(ldsK + (kt * 32 + qcol) * C::K_STRIDE + 16 * s + 8 * half);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kt], 0, 0, 0);
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(ldsK + (kt * 32 + krow) * C::K_STRIDE + 16 * s + 8 * half);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (s == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        sacc[qb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][s], z, 0, 0, 0);
+                    } else {
+                        sacc[qb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][s], sacc[qb][kt], 0, 0, 0);
+                    }
+                }
             }
         }
-        if (!C::BIAS) {
+        PFrag pf[QB][2][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (!C::BIAS) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[qb][kt][r] -= m_ref[qb];
+            }
+            if (MASKED) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int key = kbase + kt * 32 + 16 * (r >> 3) + 8 * half + (r & 7);     // pi applied
+                        if (key >= Nkv) sacc[qb][kt][r] = -INFINITY;
+                    }
+            }
+            // ---- running reference: per query column; partner lane = lane ^ 32 holds the other 32 keys ----
+            float mx = max3f(sacc[qb][0][0], sacc[qb][0][1], sacc[qb][0][2]);
+            mx = max3f(mx, sacc[qb][0][3], sacc[qb][0][4]);
+#pragma unroll
+            for (int r = 5; r < 15; r += 2) mx = max3f(mx, sacc[qb][0][r], sacc[qb][0][r + 1]);
+            float mx1 = max3f(sacc[qb][1][0], sacc[qb][1][1], sacc[qb][1][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx1 = max3f(mx1, sacc[qb][1][r], sacc[qb][1][r + 1]);
+            mx = max3f(mx, mx1, sacc[qb][0][15]);
+            mx = max3f(mx, sacc[qb][1][15], sacc[qb][1][15]);
+            mx = halves_max(mx);
+            const bool move = first || (mx > RESCALE_THR);
+            if (__any(move)) {
+                // slow path (wave-uniform): move the reference of the lanes that need it, rescale O and l, shift this tile's scores
+                const float want = move ? (m_ref[qb] + mx) : m_ref[qb];         // every tile holds >= 1 valid key: mx is finite
+                const float m_new = (float)(h16)want;                            // keep the reference fp16-exact (it rides in Q)
+                const float delta = m_new - m_ref[qb];
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref[qb] = m_new;
+                if (C::BIAS) qf[qb][BS][BJ] = (half == BH) ? (h16)(-m_new) : qf[qb][BS][BJ];
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qb][t][r] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[qb][kt][r] -= delta;
+            }
+            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kt][r] -= m_ref;
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        f32x2 e;
+                        e.x = __builtin_amdgcn_exp2f(sacc[qb][kt][8 * s2 + 2 * jj]);
+                        e.y = __builtin_amdgcn_exp2f(sacc[qb][kt][8 * s2 + 2 * jj + 1]);
+                        pf[qb][kt][s2].p[jj] = __builtin_convertvector(e, h16x2);
+                        if (!C::ONES) psum += e.x + e.y;
+                    }
+            if (!C::ONES) l_run[qb] += halves_sum(psum);
         }
-        if (MASKED) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (key >= Nkv) sacc[kt][r] = -INFINITY;
-                }
-        }
-        // ---- running reference: per query column; partner lane = lane ^ 32 holds the other 32 keys ----
-        float mx = sacc[0][0];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const bool move = first || (mx > RESCALE_THR);
-        if (__any(move)) {
-            // slow path (wave-uniform): move the reference of the lanes that need it, rescale O and l, shift this tile's scores
-            const float want = move ? (m_ref + mx) : m_ref;                 // every tile holds >= 1 valid key: mx is finite
-            const float m_new = (float)(h16)want;                            // keep the reference fp16-exact (it rides in Q)
-            const float delta = m_new - m_ref;
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-            m_ref = m_new;
-            if (C::BIAS) qf[BS][BJ] = (half == BH) ? (h16)(-m_new) : qf[BS][BJ];
-            l_run *= alpha;
-#pragma unroll
-            for (int t = 0; t < C::DT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kt][r] -= delta;
-            first = false;
-        }
-        float psum = 0.f;
-        PFrag pf[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    f32x2 e;
-                    e.x = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj]);
-                    e.y = __builtin_amdgcn_exp2f(sacc[kt][8 * s2 + 2 * jj + 1]);
-                    pf[kt][s2].p[jj] = __builtin_convertvector(e, h16x2);
-                    if (!C::ONES) psum += e.x + e.y;
-                }
-        if (!C::ONES) l_run += psum + __shfl_xor(psum, 32);
+        first = false;
 
-        // ---- O^T[t] += V^T_tile[t] . P^T ;  A fragment element j of lane-half h must be key 16 s2 + 8 (j>>2) + 4 h + (j&3) ----
+        // ---- O^T[qb][t] += V^T_tile[t] . P^T[qb] ;  A fragment = V^T[t*32 + row][16 s2 + 8 half .. + 7] (one b128) ----
 #pragma unroll
         for (int t = 0; t < C::DT; ++t) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const h16* src = ldsV + (t * 32 + qcol) * C::V_STRIDE + kt * 32 + 16 * s2 + 4 * half;
-                    h16x4 lo = *reinterpret_cast<const h16x4*>(src);
-                    h16x4 hi = *reinterpret_cast<const h16x4*>(src + 8);
-                    h16x8 vf;
+                    const h16x8 vf = *reinterpret_cast<const h16x8*>(ldsV + (t * 32 + qcol) * C::V_STRIDE + kt * 32 + 16 * s2 + 8 * half);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][s2].v, oacc[t], 0, 0, 0);
+                    for (int qb = 0; qb < QB; ++qb)
+                        oacc[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kt][s2].v, oacc[qb][t], 0, 0, 0);
                 }
         }
     };
@@ -260,63 +295,73 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
     const int nfull = Nkv / KVT;
     const int ntiles = (Nkv + KVT - 1) / KVT;
     // prologue: tile 0 -> stage 0
-    if (nfull > 0) load_tile(0, std::false_type{}); else load_tile(0, std::true_type{});
+    load_tile(0);
     store_tile(0);
     __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
+    for (int tile = 0; tile < nfull; ++tile) {
         const int st = tile & 1;
-        const int nxt = tile + 1;
-        if (nxt < ntiles) {                                   // global loads of the next tile fly during this tile's MFMAs
-            if (nxt < nfull) load_tile(nxt * KVT, std::false_type{}); else load_tile(nxt * KVT, std::true_type{});
-        }
-        if (tile < nfull) compute_tile(st, tile * KVT, std::false_type{}); else compute_tile(st, tile * KVT, std::true_type{});
-        if (nxt < ntiles) store_tile(st ^ 1);                 // the other stage was last read one barrier ago
+        load_tile(min(tile + 1, ntiles - 1) * KVT);           // global loads of the next tile fly during this tile's MFMAs
+        compute_tile(st, tile * KVT, std::false_type{});
+        store_tile(st ^ 1);                                   // the other stage was last read one barrier ago
         __syncthreads();
     }
+    if (ntiles > nfull) compute_tile(nfull & 1, nfull * KVT, std::true_type{});      // ragged tail: masked scores
 
     // ---- epilogue: O[q][dd] = O^T[dd][q] / l ----
-    float l = l_run;
-    if (C::ONES) {
-        // the ones row is row D of the padded V^T: tile D/32, in-tile row i = D%32 -> register r with
-        // (r&3) + 8 (r>>2) = i - 4 h  on lane-half h = (i>>2)&1
-        constexpr int TI = D / 32, I = D % 32, H = (I >> 2) & 1, RI = (I & 3) + 4 * (I >> 3);
-        float mine = (half == H) ? oacc[TI][RI] : 0.f;
-        l = mine + __shfl_xor(mine, 32);
-    }
-    const float inv = 1.0f / l;
-    const int q = q0 + qcol;
-    if (q < Nq) {
 #pragma unroll
-        for (int t = 0; t < C::DT; ++t)
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = l_run[qb];
+        if (C::ONES) {
+            // the ones row is row D of the padded V^T: tile D/32, in-tile row i = D%32 -> register r with
+            // (r&3) + 8 (r>>2) = i - 4 h  on lane-half h = (i>>2)&1
+            constexpr int TI = D / 32, I = D % 32, H = (I >> 2) & 1, RI = (I & 3) + 4 * (I >> 3);
+            float mine = (half == H) ? oacc[qb][TI][RI] : 0.f;
+            l = halves_sum(mine);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + qb * QW + qcol;
+        if (q < Nq) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int dd = t * 32 + 8 * g + 4 * half;          // rows (r&3) + 8 (r>>2) + 4 half, r = 4 g .. 4 g + 3
-                if (dd < D) {
-                    h16x4 o4;
+            for (int t = 0; t < C::DT; ++t)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o4[j] = (h16)(oacc[t][4 * g + j] * inv);
-                    *reinterpret_cast<h16x4*>(Ob + (size_t)q * ldo + dd) = o4;
+                for (int g = 0; g < 4; ++g) {
+                    int dd = t * 32 + 8 * g + 4 * half;          // rows (r&3) + 8 (r>>2) + 4 half, r = 4 g .. 4 g + 3
+                    if (dd < D) {
+                        h16x4 o4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o4[j] = (h16)(oacc[qb][t][4 * g + j] * inv);
+                        *reinterpret_cast<h16x4*>(Ob + (size_t)q * ldo + dd) = o4;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, int QB>
 int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                    int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
                    hipStream_t stream) {
     using C = AttnCfg<D>;
-    dim3 grid(bc_ceil_div(Nq, QW * NW), heads, B), block(64 * NW);
+    dim3 grid(bc_ceil_div(Nq, QW * QB * NW), heads, B), block(64 * NW);
     static bool attr_set = false;
     if (!attr_set) {
-        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, NW>),
+        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, NW, QB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, QB>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
                        qbs, kbs, vbs, obs, scale * 1.4426950408889634f);
     BC_CHECK_LAUNCH();
     return 0;
+}
+
+int attn_qb_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("BC_ATTN_QB");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 template <int D>
@@ -325,7 +370,16 @@ int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int he
                 hipStream_t stream) {
     // Measured on MI355X: splitting short sequences over more, smaller workgroups (NW = 2 / 1) is SLOWER (every workgroup
     // re-stages the whole K / V with fewer threads: D=160, N=512: 18 vs 35 TFLOP/s), so the 4-wave form is always used.
-    return launch_attn_nw<D, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    // Two query blocks per wave (QB = 2) when the grid still fills the chip and the accumulators fit (D <= 80).
+    int qb = 1;
+    if constexpr (D <= 80) {
+        const long long wgs2 = (long long)bc_ceil_div(Nq, QW * 2 * 4) * heads * B;
+        qb = wgs2 >= 256 ? 2 : 1;
+        if (attn_qb_override() > 0) qb = attn_qb_override();
+        if (qb == 2)
+            return launch_attn_nw<D, 4, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    }
+    return launch_attn_nw<D, 4, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
 }
 
 }  // namespace
