@@ -291,8 +291,40 @@ def golden_vae():
     print("vae: decoded std %.4f moments std %.4f" % (out["decoded"].std(), out["moments"].std()))
 
 
+def golden_lora_keys():
+    """Key renaming + alpha defaults of the reference LoRA loader (peft itself is absent here, so only the parts that live in the
+    vendored diffusers tree are pinned: convert_unet_state_dict_to_peft and get_peft_kwargs)."""
+    from diffusers.utils.state_dict_utils import convert_unet_state_dict_to_peft
+    from diffusers.utils.peft_utils import get_peft_kwargs
+    mods = ["down_blocks.0.attentions.0.transformer_blocks.0.attn1", "mid_block.attentions.0.transformer_blocks.0.attn2",
+            "up_blocks.3.attentions.2.transformer_blocks.0.attn1.processor"]
+    keys = []
+    for m in mods:
+        for proj in ("to_q", "to_k", "to_v", "to_out"):
+            for d in ("down", "up"):
+                keys.append(f"{m}.{proj}_lora.{d}.weight")
+    keys += ["conv_in.lora.down.weight", "conv_in.lora.up.weight", "down_blocks.1.resnets.0.conv1.lora.down.weight",
+             "down_blocks.1.resnets.0.conv1.lora.up.weight", "down_blocks.0.attentions.0.proj_in.lora_A.weight",
+             "down_blocks.0.attentions.0.proj_in.lora_B.weight", "up_blocks.1.attentions.0.transformer_blocks.0.ff.net.2.lora.down.weight",
+             "up_blocks.1.attentions.0.transformer_blocks.0.ff.net.2.lora.up.weight",
+             "mid_block.attentions.0.transformer_blocks.0.attn1.to_out.0.lora_A.weight"]
+    conv = convert_unet_state_dict_to_peft({k: i for i, k in enumerate(keys)})
+    out = {"pairs": [[k, nk] for k, nk in zip(keys, conv.keys())]}
+    # alpha / rank defaults: ranks in file order 4, 8, 4, 4 without alphas; then with alphas
+    peft_sd = {"a.lora_A.weight": 0, "a.lora_B.weight": 0, "b.lora_A.weight": 0, "b.lora_B.weight": 0,
+               "c.lora_A.weight": 0, "c.lora_B.weight": 0}
+    ranks = {"a.lora_B.weight": 8, "b.lora_B.weight": 4, "c.lora_B.weight": 4}
+    out["kwargs_no_alpha"] = {k: v for k, v in get_peft_kwargs(ranks, None, peft_sd).items() if k != "target_modules"}
+    alphas = {"a.lora_A.weight.alpha": 16.0, "b.lora_A.weight.alpha": 4.0, "c.lora_A.weight.alpha": 4.0}
+    out["kwargs_alpha"] = {k: v for k, v in get_peft_kwargs(ranks, alphas, peft_sd).items() if k != "target_modules"}
+    with open(os.path.join(OUT, "lora_keys.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("lora keys:", len(out["pairs"]), "pairs;", out["kwargs_no_alpha"], out["kwargs_alpha"])
+
+
 if __name__ == "__main__":
     check_full_schema()
+    golden_lora_keys()
     golden_vae()
     golden_splat()
     golden_schedulers()
