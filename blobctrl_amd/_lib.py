@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libblobctrl_hip.so")
 
 A_DENSE, A_CONV3X3 = 0, 1
-ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
 TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64"]
 
@@ -57,6 +57,11 @@ _SIGNATURES = {
     "bc_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
                                C.c_longlong, C.c_float, C.c_void_p]),
+    "bc_attention_causal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
+                                      C.c_longlong, C.c_float, C.c_void_p]),
+    "bc_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
     "bc_splat_scores": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_assemble_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -81,7 +81,7 @@ template <int D, int NW, int QB>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict__ Q, const h16* __restrict__ K,
                                                          const h16* __restrict__ Vt, h16* __restrict__ O, int Nq, int Nkv,
                                                          int ldq, int ldk, int ldvt, int ldo, long long q_bs, long long k_bs,
-                                                         long long vt_bs, long long o_bs, float scale_log2e) {
+                                                         long long vt_bs, long long o_bs, float scale_log2e, int causal) {
 #if defined(__HIP_DEVICE_COMPILE__)    // the body uses device-only builtins (buffer resources, LDS-DMA): the host pass only needs the stub
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int key = kbase + kt * 32 + 16 * (r >> 3) + 8 * half + (r & 7);     // pi applied
-                        if (key >= Nkv) sacc[qb][kt][r] = -INFINITY;
+                        if (key >= Nkv || (causal && key > q0 + qb * QW + qcol)) sacc[qb][kt][r] = -INFINITY;
                     }
             }
             // ---- running reference: per query column; partner lane = lane ^ 32 holds the other 32 keys ----
@@ -311,8 +311,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
         }
     };
 
-    const int nfull = Nkv / KVT;
-    const int ntiles = (Nkv + KVT - 1) / KVT;
+    // causal: every tile takes the masked path, and tiles wholly above the diagonal of this workgroup's last query are skipped
+    const int ntiles = causal ? min((Nkv + KVT - 1) / KVT, (min(Nq, qblk * (QW * QB * NW) + QW * QB * NW) + KVT - 1) / KVT)
+                              : (Nkv + KVT - 1) / KVT;
+    const int nfull = causal ? 0 : Nkv / KVT;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     // prologue: tile 0 -> stage 0
@@ -331,10 +333,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
         if (tile + 1 < ntiles) issue_tile(tile + 1, 1);
         compute_tile(S0{}, tile * KVT, std::false_type{});
         __syncthreads();
+        ++tile;
     }
-    if (ntiles > nfull) {                                     // ragged tail: masked scores
-        if (nfull & 1) compute_tile(S1{}, nfull * KVT, std::true_type{});
-        else compute_tile(S0{}, nfull * KVT, std::true_type{});
+    for (; tile < ntiles; ++tile) {                           // ragged tail (one tile) or the causal tiles: masked scores
+        if (tile + 1 < ntiles) issue_tile(tile + 1, (tile + 1) & 1);
+        if (tile & 1) compute_tile(S1{}, tile * KVT, std::true_type{});
+        else compute_tile(S0{}, tile * KVT, std::true_type{});
+        __syncthreads();
     }
 
     // ---- epilogue: O[q][dd] = O^T[dd][q] / l ----
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const h16* __restrict
 template <int D, int NW, int QB>
 int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                    int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
-                   hipStream_t stream) {
+                   int causal, hipStream_t stream) {
     using C = AttnCfg<D>;
     dim3 grid(bc_ceil_div(Nq, QW * QB * NW), heads, B), block(64 * NW);
     static bool attr_set = false;
@@ -381,7 +386,7 @@ int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int
         attr_set = true;
     }
     hipLaunchKernelGGL((attn_fwd_kernel<D, NW, QB>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
-                       qbs, kbs, vbs, obs, scale * 1.4426950408889634f);
+                       qbs, kbs, vbs, obs, scale * 1.4426950408889634f, causal);
     BC_CHECK_LAUNCH();
     return 0;
 }
@@ -398,26 +403,27 @@ int attn_qb_override() {
 template <int D>
 int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                 int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
-                hipStream_t stream) {
+                int causal, hipStream_t stream) {
     // Measured on MI355X: splitting short sequences over more, smaller workgroups (NW = 2 / 1) is SLOWER (every workgroup
     // re-stages the whole K / V with fewer threads: D=160, N=512: 18 vs 35 TFLOP/s), so the 4-wave form is always used.
     // Two query blocks per wave (QB = 2, BC_ATTN_QB=2) halve the LDS fragment traffic but cost occupancy; with the LDS-DMA
     // pipeline QB = 1 is faster at every shape of the loop (d=40 N=8192: 613 vs 556 TFLOP/s), so it is the default.
     if constexpr (D <= 64) {
         if (attn_qb_override() == 2)
-            return launch_attn_nw<D, 4, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+            return launch_attn_nw<D, 4, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
     }
-    return launch_attn_nw<D, 4, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream);
+    return launch_attn_nw<D, 4, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
 }
 
 }  // namespace
 
-extern "C" int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O, int B, int heads, int d,
+static int attention_impl(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O, int B, int heads, int d,
                             int Nq, int Nkv, int ldq, int ldk, int ldvt, int ldo, long long q_bstride,
                             long long k_bstride, long long vt_bstride, long long o_bstride, float scale,
-                            bc_stream stream_) {
+                            int causal, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BC_CHECK_ARG(Q && K && Vt && O && B > 0 && heads > 0 && Nq > 0 && Nkv > 0, "bc_attention: bad args");
+    BC_CHECK_ARG(!causal || Nq == Nkv, "bc_attention_causal: needs Nq == Nkv (Nq=%d Nkv=%d)", Nq, Nkv);
     BC_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "bc_attention: strides must be multiples of 8 (ldo: 4)");
     BC_CHECK_ARG(ldvt >= bc_ceil_div(Nkv, KVT) * KVT, "bc_attention: ldvt=%d must cover Nkv=%d rounded up to %d (zero padded)", ldvt, Nkv, KVT);
     BC_CHECK_ARG(q_bstride % 8 == 0 && k_bstride % 8 == 0 && vt_bstride % 8 == 0 && o_bstride % 4 == 0, "bc_attention: batch strides must be multiples of 8");
@@ -428,7 +434,7 @@ extern "C" int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* V
 #define BC_ATTN_CASE(DD)                                                                                         \
     case DD:                                                                                                     \
         return launch_attn<DD>(q, k, v, o, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, q_bstride, k_bstride, vt_bstride, \
-                               o_bstride, scale, stream);
+                               o_bstride, scale, causal, stream);
     switch (d) {
         BC_ATTN_CASE(8)
         BC_ATTN_CASE(16)
@@ -442,4 +448,20 @@ extern "C" int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* V
             return 1;
     }
 #undef BC_ATTN_CASE
+}
+
+extern "C" int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O, int B, int heads, int d,
+                            int Nq, int Nkv, int ldq, int ldk, int ldvt, int ldo, long long q_bstride,
+                            long long k_bstride, long long vt_bstride, long long o_bstride, float scale,
+                            bc_stream stream) {
+    return attention_impl(Q, K, Vt, O, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, q_bstride, k_bstride, vt_bstride, o_bstride,
+                          scale, 0, stream);
+}
+
+extern "C" int bc_attention_causal(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O, int B, int heads, int d,
+                                   int Nq, int Nkv, int ldq, int ldk, int ldvt, int ldo, long long q_bstride,
+                                   long long k_bstride, long long vt_bstride, long long o_bstride, float scale,
+                                   bc_stream stream) {
+    return attention_impl(Q, K, Vt, O, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, q_bstride, k_bstride, vt_bstride, o_bstride,
+                          scale, 1, stream);
 }

@@ -37,6 +37,9 @@ __device__ __forceinline__ float bc_silu_f(float x) { return x / (1.0f + __expf(
 // exact-erf GELU (activations.py:93-123 uses F.gelu default = erf form)
 __device__ __forceinline__ float bc_gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// CLIP's "quick_gelu": x * sigmoid(1.702 x)  (transformers activations.QuickGELUActivation)
+__device__ __forceinline__ float bc_quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
 __device__ __forceinline__ uint4 bc_ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void bc_st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 

@@ -217,6 +217,26 @@ __global__ void gaussian_sample_kernel(const h16* __restrict__ mom, const float*
     }
 }
 
+// CLIPTextEmbeddings (transformers models/clip/modeling_clip.py): token_embedding(ids) + position_embedding(arange(T))
+__global__ void embed_tokens_kernel(const long long* __restrict__ ids, const h16* __restrict__ tok, const float* __restrict__ pos,
+                                    int B, int T, int D, int vocab, h16* __restrict__ out) {
+    const long long total = (long long)B * T * (D / 8);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % (D / 8));
+        const long long row = i / (D / 8);
+        const int t = (int)(row % T);
+        long long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const uint4 raw = bc_ld16(tok + (size_t)id * D + ch * 8);
+        const h16* e = reinterpret_cast<const h16*>(&raw);
+        uint4 o;
+        h16* oh = reinterpret_cast<h16*>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = (h16)((float)e[j] + pos[(size_t)t * D + ch * 8 + j]);
+        bc_st16(out + (size_t)row * D + ch * 8, o);
+    }
+}
+
 inline int ew_blocks(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -331,6 +351,17 @@ extern "C" int bc_gaussian_sample(const bc_half* moments, const float* noise, in
     long long total = (long long)B * Cz * HW;
     hipLaunchKernelGGL(gaussian_sample_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream,
                        reinterpret_cast<const h16*>(moments), noise, B, Cz, HW, scale, out);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_embed_tokens(const long long* ids, const bc_half* tok_emb, const float* pos_emb, int B, int T, int D, int vocab,
+                               bc_half* out, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(ids && tok_emb && pos_emb && out && B > 0 && T > 0 && D > 0 && D % 8 == 0 && vocab > 0, "bc_embed_tokens: bad args");
+    long long total = (long long)B * T * (D / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, ids, reinterpret_cast<const h16*>(tok_emb),
+                       pos_emb, B, T, D, vocab, reinterpret_cast<h16*>(out));
     BC_CHECK_LAUNCH();
     return 0;
 }

@@ -228,6 +228,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
     float v = pre_act(g, a, m, n);
     if (p.act == BC_ACT_GELU) v = bc_gelu_f(v);
     else if (p.act == BC_ACT_SILU) v = bc_silu_f(v);
+    else if (p.act == BC_ACT_QUICK_GELU) v = bc_quick_gelu_f(v);
     epilogue_store(g, v, m, n, alpha);
 }
 

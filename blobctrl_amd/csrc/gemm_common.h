@@ -139,6 +139,7 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmArgs& g, const fl
             float v = pre_act(g, tile[idx], m, n);
             if (p.act == BC_ACT_GELU) v = bc_gelu_f(v);
             else if (p.act == BC_ACT_SILU) v = bc_silu_f(v);
+            else if (p.act == BC_ACT_QUICK_GELU) v = bc_quick_gelu_f(v);
             epilogue_store(g, v, m, n, alpha);
         }
     }
@@ -190,6 +191,9 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
     } else if (p.act == BC_ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+    } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= c.cs[j];

@@ -330,15 +330,15 @@ class Recorder:
 
     # ------------------------------------------------------------------ attention
     def attention(self, Q, K, Vt, out, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale,
-                  q_off=0, k_off=0):
+                  q_off=0, k_off=0, causal=False):
         lib = self.lib
+        entry = lib.bc_attention_causal if causal else lib.bc_attention
         pq = Q.data_ptr() + q_off * 2
         pk = K.data_ptr() + k_off * 2
         pv, po = ptr(Vt), ptr(out)
 
         def fn(stream):
-            rc = lib.bc_attention(pq, pk, pv, po, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale,
-                                  stream)
+            rc = entry(pq, pk, pv, po, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream)
             if rc:
                 _lib.check(rc, "bc_attention")
 

@@ -5,7 +5,8 @@ same keyword names and meaning (`num_inference_steps`, `guidance_scale`, `genera
 `blobnet_conditioning_scale` (must be a Python float, pipe:395-396), `blobnet_control_guidance_start/end`,
 `output_type`), same error behaviour for bad arguments.  The VAE either side of the loop is optional:
 with `vae=blobctrl_amd.vae.AutoencoderKL(...)` the call also accepts `fg_image` / `bg_image` (pipe:970-971) and returns decoded
-images for `output_type="pt" | "np"` (pipe:1132-1146); the CLIP text encoder stays outside (callers pass prompt embeddings).
+images for `output_type="pt" | "np"` (pipe:1132-1146); with `text_encoder=blobctrl_amd.clip_text.CLIPTextModel(...)`,
+`encode_prompt(prompt_ids, negative_prompt_ids)` produces the prompt embeddings (tokenisation stays on the host).
 
 Execution model: one static launch plan per (batch, canvas, steps) configuration -
     prologue (once per edit): cross-attention K/V of the prompt embeddings
@@ -36,7 +37,7 @@ class StableDiffusionBlobNetPipeline:
     """MI355X engine with the reference pipeline's call surface for the denoising hot path."""
 
     def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
-                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None):
+                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None, text_encoder=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.BlobCtrlHipError("blobctrl_amd runs on MI355X only (device must be cuda:N); there is no CPU fallback")
@@ -57,6 +58,7 @@ class StableDiffusionBlobNetPipeline:
         self._sched_cache = {}
         self.feat_dim = blobnet_config.in_channels - 5
         self.vae = vae                                                # optional blobctrl_amd.vae.AutoencoderKL
+        self.text_encoder = text_encoder                              # optional blobctrl_amd.clip_text.CLIPTextModel
 
     # ------------------------------------------------------------------------------------------------ planning
     def _plan(self, B, h, w, T, ctx_dim, nsteps):
@@ -180,6 +182,18 @@ class StableDiffusionBlobNetPipeline:
             raise ValueError(f"control guidance end: {end} can't be larger than 1.0.")
         if num_inference_steps < 1:
             raise ValueError("num_inference_steps must be >= 1")
+
+    def encode_prompt(self, prompt_ids: torch.Tensor, negative_prompt_ids: torch.Tensor, clip_skip: Optional[int] = None):
+        """pipe:508-687 after tokenisation: token ids [B, 77] of the prompt and of the negative prompt -> prompt_embeds
+        [2B, 77, D] = cat(negative, positive) (pipe:937-949), ready for `__call__`."""
+        if self.text_encoder is None:
+            raise ValueError("this pipeline was built without a text encoder: pass prompt_embeds, or text_encoder=...")
+        if prompt_ids.shape != negative_prompt_ids.shape:
+            raise ValueError("prompt_ids and negative_prompt_ids must have the same shape")
+        with torch.cuda.stream(self.stream):
+            emb = self.text_encoder(torch.cat([negative_prompt_ids, prompt_ids], 0), clip_skip=clip_skip)[0]
+        self.stream.synchronize()
+        return emb
 
     def encode_latents(self, image: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """pipe:300-309: image [1,3,H,W] in [-1,1] -> posterior sample * scaling_factor, [1,4,H/8,W/8] fp32."""

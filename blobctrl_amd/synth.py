@@ -163,6 +163,30 @@ def dinov2_param_shapes(hidden: int, layers: int, mlp_ratio: int, patch: int, nu
     return s
 
 
+def clip_text_param_shapes(vocab: int = 49408, hidden: int = 768, layers: int = 12, intermediate: int = 3072,
+                           max_pos: int = 77) -> "OrderedDict[str, tuple]":
+    """transformers `CLIPTextModel.state_dict()` layout (call site pipe:599,668; defaults = SD-1.5's CLIP ViT-L/14 text tower)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["text_model.embeddings.token_embedding.weight"] = (vocab, hidden)
+    s["text_model.embeddings.position_embedding.weight"] = (max_pos, hidden)
+    for i in range(layers):
+        p = f"text_model.encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (hidden, hidden)
+            s[p + f"self_attn.{n}.bias"] = (hidden,)
+        s[p + "layer_norm1.weight"] = (hidden,)
+        s[p + "layer_norm1.bias"] = (hidden,)
+        s[p + "mlp.fc1.weight"] = (intermediate, hidden)
+        s[p + "mlp.fc1.bias"] = (intermediate,)
+        s[p + "mlp.fc2.weight"] = (hidden, intermediate)
+        s[p + "mlp.fc2.bias"] = (hidden,)
+        s[p + "layer_norm2.weight"] = (hidden,)
+        s[p + "layer_norm2.bias"] = (hidden,)
+    s["text_model.final_layer_norm.weight"] = (hidden,)
+    s["text_model.final_layer_norm.bias"] = (hidden,)
+    return s
+
+
 def vae_param_shapes(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, in_channels=3,
                      out_channels=3) -> "OrderedDict[str, tuple]":
     """`AutoencoderKL.state_dict()` layout of the SD-1.5 VAE (D/models/autoencoders/autoencoder_kl.py:72-137, vae.py:47-348)."""

@@ -40,7 +40,7 @@ int bc_device_info(int* out4);
  *           (unet_2d_blocks.py:1303-1307 et al.).
  * --------------------------------------------------------------------------------------------------------------- */
 enum { BC_A_DENSE = 0, BC_A_CONV3X3 = 1 };
-enum { BC_ACT_NONE = 0, BC_ACT_GELU = 1, BC_ACT_GEGLU = 2, BC_ACT_SILU = 3 };
+enum { BC_ACT_NONE = 0, BC_ACT_GELU = 1, BC_ACT_GEGLU = 2, BC_ACT_SILU = 3, BC_ACT_QUICK_GELU = 4 /* x*sigmoid(1.702x), CLIP */ };
 enum { BC_OUT_F16 = 0, BC_OUT_F16_T = 1, BC_OUT_F32 = 2 };
 
 typedef struct BcGemm {
@@ -127,6 +127,10 @@ int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2
  * as GEMM (QK^T) -> softmax -> GEMM (PV)  (attention_processor.py:2216 with heads = 1). */
 int bc_softmax_rows(bc_half* x, int rows, int cols, int ld, bc_stream stream);
 
+/* CLIP text embeddings: out[b][t][:] = tok_emb[ids[b][t]][:] + pos_emb[t][:]  (ids int64, clamped to the vocabulary). */
+int bc_embed_tokens(const long long* ids, const bc_half* tok_emb, const float* pos_emb, int B, int T, int D, int vocab,
+                    bc_half* out, bc_stream stream);
+
 /* Posterior sample of the VAE encoder (D/models/autoencoders/vae.py:767-789): moments token-major [B][HW][2*Cz] (mean | logvar),
  * noise fp32 NCHW [B][Cz][HW]; out fp32 NCHW = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale. */
 int bc_gaussian_sample(const bc_half* moments, const float* noise, int B, int Cz, int HW, float scale, float* out,
@@ -150,6 +154,13 @@ int bc_attention(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half*
                  int ldq, int ldk, int ldvt, int ldo,
                  long long q_bstride, long long k_bstride, long long vt_bstride, long long o_bstride,
                  float scale, bc_stream stream);
+/* Same with the causal mask of the CLIP text encoder (key j visible to query i iff j <= i; pipe:599 -> transformers
+ * CLIPTextTransformer); needs Nq == Nkv. */
+int bc_attention_causal(const bc_half* Q, const bc_half* K, const bc_half* Vt, bc_half* O,
+                        int B, int heads, int d, int Nq, int Nkv,
+                        int ldq, int ldk, int ldvt, int ldo,
+                        long long q_bstride, long long k_bstride, long long vt_bstride, long long o_bstride,
+                        float scale, bc_stream stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Blob maths and loop glue

@@ -132,3 +132,17 @@ def test_vae_oracle_vs_reference_fixture(golden_dir):
     np.testing.assert_allclose(smp.numpy(), z["sample"], rtol=1e-4, atol=1e-5)
     dec = o_vae.decode(sd, torch.from_numpy(z["z"]), groups=8)
     np.testing.assert_allclose(dec.numpy(), z["decoded"], rtol=1e-4, atol=1e-5)
+
+
+def test_clip_text_oracle_vs_transformers_fixture(golden_dir):
+    from oracle.clip_text import clip_text_hidden
+    z = load(golden_dir, "clip_text_tiny.npz")
+    sd = synth.synth_state_dict(synth.clip_text_param_shapes(99, 64, 3, 128, 77), 77)
+    ids = torch.from_numpy(z["ids"])
+    np.testing.assert_allclose(clip_text_hidden(sd, ids, 4).numpy(), z["last_hidden_state"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(clip_text_hidden(sd, ids, 4, clip_skip=1).numpy(), z["clip_skip_1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(clip_text_hidden(sd, torch.from_numpy(z["short_ids"]), 4).numpy(), z["short_last_hidden_state"],
+                               rtol=0, atol=2e-5)
+    # both key layouts (with / without the "text_model." prefix) are accepted
+    bare = {k[len("text_model."):]: v for k, v in sd.items()}
+    assert torch.equal(clip_text_hidden(bare, ids, 4), clip_text_hidden(sd, ids, 4))

@@ -256,6 +256,38 @@ def golden_dinov2():
     print("dinov2: pooled std %.4f" % out["native_pooled"].std())
 
 
+def golden_clip_text():
+    """CLIP text tower (transformers, third-party; call site pipe:599-611 incl. the clip_skip branch)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=99, hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                         max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    model = CLIPTextModel(cfg).eval()
+    shapes = synth.clip_text_param_shapes(99, 64, 3, 128, 77)
+    # the on-disk SD-1.5 checkpoint (transformers 4.49 layout) prefixes every key with "text_model."; the transformers installed
+    # here (5.x) dropped the prefix - same tensors
+    have = {k for k in model.state_dict().keys() if "position_ids" not in k}
+    pre = "" if any(k.startswith("text_model.") for k in have) else "text_model."
+    assert set(shapes.keys()) == {pre + k for k in have}, "clip schema mismatch"
+    sd = synth.synth_state_dict(shapes, 77)
+    model.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=False)
+    rng = np.random.Generator(np.random.PCG64(5))
+    ids = torch.from_numpy(rng.integers(1, 98, size=(2, 77)).astype(np.int64))
+    ids[:, 0] = 0
+    ids[0, 20:] = 98                                       # eos padding pattern
+    out = {"ids": ids.numpy()}
+    with torch.no_grad():
+        r = model(ids, output_hidden_states=True)
+    out["last_hidden_state"] = r[0].numpy()
+    fln = model.text_model.final_layer_norm if hasattr(model, "text_model") else model.final_layer_norm
+    out["clip_skip_1"] = fln(r.hidden_states[-2]).detach().numpy()                                    # pipe:604-611
+    short = ids[:, :16].clone()
+    with torch.no_grad():
+        out["short_ids"] = short.numpy()
+        out["short_last_hidden_state"] = model(short)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "clip_text_tiny.npz"), **out)
+    print("clip text: last_hidden std %.4f" % out["last_hidden_state"].std())
+
+
 # ------------------------------------------------------------------------------------------------ 6. VAE
 def golden_vae():
     from diffusers import AutoencoderKL
@@ -325,6 +357,7 @@ def golden_lora_keys():
 if __name__ == "__main__":
     check_full_schema()
     golden_lora_keys()
+    golden_clip_text()
     golden_vae()
     golden_splat()
     golden_schedulers()
