@@ -150,26 +150,29 @@ def roofline(pipe, plan):
     by = {}
     for m, ms in timed:
         v = m["variant"] or m["kind"]
-        a = by.setdefault(v, dict(ms=0.0, flops=0, n=0))
+        a = by.setdefault(v, dict(ms=0.0, flops=0, n=0, bytes=0))
         a["ms"] += ms
         a["flops"] += m["flops"]
+        a["bytes"] += m.get("bytes", 0)
         a["n"] += 1
     total_ms = sum(a["ms"] for a in by.values())
     shapes = {}
     for m, ms in timed:
         key = (m["kind"], m["variant"], m["shape"])
-        a = shapes.setdefault(key, dict(ms=0.0, n=0, flops=0))
+        a = shapes.setdefault(key, dict(ms=0.0, n=0, flops=0, bytes=0))
         a["ms"] += ms
         a["n"] += 1
         a["flops"] += m["flops"]
+        a["bytes"] += m.get("bytes", 0)
     detail = [dict(kind=k[0], variant=k[1], shape=k[2], launches=v["n"], ms=round(v["ms"], 4),
-                   tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
-              for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])][:40]
+                   tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1), gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+              for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])][:60]
     cand = {k: a for k, a in by.items() if a["flops"] > 0 and "+splitk" not in k}
     dom = max(cand, key=lambda k: cand[k]["ms"])
     a = cand[dom]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
-    table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1))
+    table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                     gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
              for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(dom), launches_per_step=a["n"],

@@ -157,12 +157,13 @@ class Recorder:
                 _lib.check(rc, "bc_stream_wait_event")
         self._push(fn, "event_wait")
 
-    def _push(self, fn, kind, flops=0, variant="", shape=None):
+    def _push(self, fn, kind, flops=0, variant="", shape=None, bytes_=0):
         self.seg.calls.append(fn)
         self.seg.sids.append(self.sid)
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
-        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape))
+        # bytes_ = algorithmic HBM bytes of an HBM-bound launch (each activation read once + written once, fp16)
+        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape, bytes=bytes_))
 
     def reserve_slab(self, elems: int):
         """Shared split-K scratch of the CURRENT stream: consumed by the reduce kernel that immediately follows on that
@@ -308,7 +309,9 @@ class Recorder:
                 _lib.check(rc, "groupnorm")
 
         self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta, out))
-        self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"))
+        nbytes = 2 * B * HW * Cc * 2 + sum(B * HW * c * 2 for (_, c, _, _) in stats_calls)     # stats pass re-reads its source
+        self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"), variant="gn_apply_fused_kernel",
+                   shape=("gn", B, HW, Cc), bytes_=nbytes)
         return out
 
     def layernorm(self, x, rows, Cc, gamma, beta, eps, out=None, ldx=None, ldy=None):
@@ -325,7 +328,7 @@ class Recorder:
                 _lib.check(rc, "bc_layernorm")
 
         self.keep.append((x, gamma, beta, out))
-        self._push(fn, "layernorm")
+        self._push(fn, "layernorm", variant="layernorm_kernel", shape=("ln", rows, Cc), bytes_=2 * rows * Cc * 2)
         return out
 
     # ------------------------------------------------------------------ attention

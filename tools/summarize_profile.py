@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 PMC counter CSVs per kernel (run on the GPU box by tools/profile_round.sh) and, in the build container,
+copy the round's summaries into profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def agg(path_glob):
+    out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for p in glob.glob(path_glob, recursive=True):
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                k = out[r["Kernel_Name"]][r["Counter_Name"]]
+                k[0] += float(r["Counter_Value"])
+                k[1] += 1
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    fetch, write, mfma = (agg(os.path.join(d, sub, "**", "*counter_collection.csv")) for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"))
+    kernels = []
+    for name in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(name, {}).get("FETCH_SIZE", [0.0, 0])
+        w, nw = write.get(name, {}).get("WRITE_SIZE", [0.0, 0])
+        n = max(nf, nw, 1)
+        kernels.append(dict(kernel=name, launches=n, fetch_kib_raw=round(f / max(nf, 1), 1), write_kib_raw=round(w / max(nw, 1), 1),
+                            hbm_bytes_per_launch_corrected=int((2 * f / max(nf, 1) + w / max(nw, 1)) * 1024)))
+    kernels.sort(key=lambda r: -r["hbm_bytes_per_launch_corrected"] * r["launches"])
+    json.dump(dict(command="rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 1 --warmup 1 "
+                           "--no-cpu-baseline --no-roofline --denoise-steps 2",
+                   correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports half of a wide coalesced read "
+                              "stream; WRITE_SIZE exact; MI355X_MICROARCH.md section HBM)",
+                   kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
+    util = []
+    for name, c in mfma.items():
+        if "GRBM_GUI_ACTIVE" not in c:
+            continue
+        n = c["GRBM_GUI_ACTIVE"][1]
+        cyc = c["GRBM_GUI_ACTIVE"][0] / 8.0                      # summed over the 8 XCDs
+        util.append(dict(kernel=name, launches=n, gpu_cycles_per_launch=round(cyc / n, 1),
+                         mfma_busy_frac=round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 1])[0] / (1024.0 * cyc), 4),
+                         valu_issue_busy_frac=round(c.get("SQ_ACTIVE_INST_VALU", [0, 1])[0] * 4 / (1024.0 * cyc), 4),
+                         lds_busy_frac=round(c.get("SQ_LDS_IDX_ACTIVE", [0, 1])[0] / (256.0 * cyc), 4)))
+    util.sort(key=lambda r: -r["gpu_cycles_per_launch"] * r["launches"])
+    json.dump(dict(command="rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE -- python3 bench.py "
+                           "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --denoise-steps 2",
+                   note="fractions of the launch's own GPU cycles (GRBM_GUI_ACTIVE/8): MFMA pipe busy over 1024 SIMDs, VALU issue port "
+                        "(SQ_ACTIVE_INST_VALU counts 4-cycle quads), LDS array over 256 CUs; all launches of a kernel summed",
+                   kernels=util), open(os.path.join(d, "pmc_mfma_util.json"), "w"), indent=1)
+    print("summaries:", os.listdir(d))
+
+
+if __name__ == "__main__":
+    main()
