@@ -155,9 +155,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x
 }
 
 // Fused finalize + apply: one launch per GroupNorm.  A workgroup owns a 64-channel range x a pixel range of one image; its
-// prologue re-reduces the per-channel partials of just the groups that overlap its channel range (<= 64/cpg + 2 groups, one
-// wave per group, fixed order, fp64) into LDS (a, b) pairs, then streams its pixels: y = silu?(a*x + b), 16-byte accesses.
-// Removes the separate finalize launch (which sat on the critical path with only G/4 x B workgroups).
+// prologue re-reduces the per-channel partials of just the groups that overlap its channel range into LDS (a, b) pairs, then
+// streams its pixels: y = silu?(a*x + b), 16-byte accesses.  The prologue is the critical path of this (latency-bound) kernel, so
+// it is ONE round of independent loads: thread (channel cc, row r) sums slabs r, r+R, ... of its own channel (coalesced across
+// channels, fixed order, fp64), the R rows and the channels of a group are then combined through LDS by one thread per group.
 __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __restrict__ part1, int nslab1, int C1,
                                                                const float* __restrict__ part2, int nslab2, int C2,
                                                                const h16* __restrict__ x1, const h16* __restrict__ x2, int HW,
@@ -165,59 +166,58 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __rest
                                                                const float* __restrict__ beta, int silu, int pix_per_block,
                                                                h16* __restrict__ y) {
     __shared__ float ab_s[64 * 2];
+    __shared__ double sq_s[256 * 2];
     const int b = blockIdx.z;
     const int C = C1 + C2;
     const int cpg = C / G;
     const int c0 = blockIdx.x * 64, c1 = min(c0 + 64, C);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g_lo = c0 / cpg, g_hi = (c1 - 1) / cpg;
-    for (int g = g_lo + wave; g <= g_hi; g += 4) {
-        const int c_lo = g * cpg, c_hi = c_lo + cpg;
-        const int n1 = max(0, min(c_hi, C1) - c_lo);
-        const int n2 = cpg - n1;
+    const int cA = g_lo * cpg, nch = (g_hi + 1) * cpg - cA;          // channels whose partials this workgroup needs (<= 256)
+    int nchp = 1;
+    while (nchp < nch) nchp <<= 1;
+    const int R = 256 / nchp;                                         // slab rows summed in parallel
+    {
+        const int cc = threadIdx.x & (nchp - 1), r = threadIdx.x / nchp;
         double s = 0.0, q = 0.0;
-        if (n1 > 0) {
-            const float* base = part1 + ((size_t)b * nslab1 * C1 + c_lo) * 2;
-            const int items = n1 * nslab1;
-            for (int it0 = lane; it0 < items; it0 += 256) {          // 4 independent loads in flight per lane
-                float2 v[4];
+        if (cc < nch) {
+            const int c = cA + cc;
+            const bool first = c < C1;
+            const int ns = first ? nslab1 : nslab2, Cs = first ? C1 : C2;
+            const float* base = (first ? part1 : part2) + ((size_t)b * ns * Cs + (first ? c : c - C1)) * 2;
+            const size_t step = (size_t)Cs * 2;
+            int sl = r;
+            for (; sl + 7 * R < ns; sl += 8 * R) {                    // 8 independent loads in flight
+                float2 v[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int it = it0 + u * 64;
-                    const int sl = it / n1, cj = it - sl * n1;
-                    v[u] = (it < items) ? *reinterpret_cast<const float2*>(base + ((size_t)sl * C1 + cj) * 2) : make_float2(0.f, 0.f);
-                }
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(base + (size_t)(sl + u * R) * step);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+                for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+            }
+            for (; sl < ns; sl += R) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)sl * step);
+                s += v.x;
+                q += v.y;
             }
         }
-        if (n2 > 0) {
-            const int c2_lo = max(c_lo, C1) - C1;
-            const float* base = part2 + ((size_t)b * nslab2 * C2 + c2_lo) * 2;
-            const int items = n2 * nslab2;
-            for (int it0 = lane; it0 < items; it0 += 256) {          // 4 independent loads in flight per lane
-                float2 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int it = it0 + u * 64;
-                    const int sl = it / n2, cj = it - sl * n2;
-                    v[u] = (it < items) ? *reinterpret_cast<const float2*>(base + ((size_t)sl * C2 + cj) * 2) : make_float2(0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        sq_s[threadIdx.x * 2] = s;
+        sq_s[threadIdx.x * 2 + 1] = q;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= g_hi - g_lo) {                            // one thread per group: fixed-order combine
+        const int g = g_lo + threadIdx.x;
+        const int cl = g * cpg - cA;
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < R; ++r)
+            for (int j = 0; j < cpg; ++j) {
+                s += sq_s[(r * nchp + cl + j) * 2];
+                q += sq_s[(r * nchp + cl + j) * 2 + 1];
             }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o);
-            q += __shfl_xor(q, o);
-        }
         const double n = (double)HW * cpg;
         const double mean = s / n;
         double var = q / n - mean * mean;
         if (var < 0.0) var = 0.0;
         const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-        for (int c = max(c_lo, c0) + lane; c < min(c_hi, c1); c += 64) {
+        for (int c = max(g * cpg, c0); c < min((g + 1) * cpg, c1); ++c) {
             const float a = rstd * gamma[c];
             ab_s[(c - c0) * 2] = a;
             ab_s[(c - c0) * 2 + 1] = beta[c] - meanf * a;
@@ -399,6 +399,7 @@ extern "C" int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const f
     const int C = C1 + C2;
     BC_CHECK_ARG(part1 && x1 && y && gamma && beta && G > 0 && C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && nslab1 > 0,
                  "bc_gn_apply_fused: bad args");
+    BC_CHECK_ARG(C / G <= 96, "bc_gn_apply_fused: %d channels per group (> 96): use bc_gn_finalize + bc_gn_apply", C / G);
     const int cblocks = bc_ceil_div(C, 64);
     // ~512 workgroups in total, at least 32 pixels each (the prologue's partial re-reduction is amortised over the pixels)
     int pblocks = std::max(1, std::min(bc_ceil_div(HW, 32), bc_ceil_div(512, cblocks * B)));

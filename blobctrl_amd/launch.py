@@ -293,7 +293,7 @@ class Recorder:
         (pa1, ns1), (pa2, ns2) = srcs
         p1, p2, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
         pp1, pp2 = ptr(pa1), ptr(pa2)
-        fused = not os.environ.get("BC_GN_UNFUSED")
+        fused = not os.environ.get("BC_GN_UNFUSED") and Cc // G <= 96          # (the fused kernel's LDS staging holds <= 256 channels)
 
         def fn(stream):
             rc = 0
