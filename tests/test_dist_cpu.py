@@ -60,3 +60,10 @@ def test_weight_broadcast_and_request_sharding_world2(tmp_path):
 def test_single_process_paths_are_noops():
     assert bdist.shard_requests(3, 0, 1) == [0, 1, 2]
     assert bdist.barrier_max_seconds(0.5) == 0.5
+
+
+def test_config_c4_partition_64_requests_over_8_ranks():
+    """BASELINE configs[3]: 64 edits, 8 per GPU, no request on two ranks, none dropped."""
+    parts = [bdist.shard_requests(64, r, 8) for r in range(8)]
+    assert all(len(p) == 8 for p in parts)
+    assert sorted(i for p in parts for i in p) == list(range(64))
