@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblobctrl_hip.so")
+# BLOBCTRL_HIP_LIB points at another build of the SAME C ABI (A/B measurements of kernel variants); default = the in-tree build
+LIB_PATH = os.environ.get("BLOBCTRL_HIP_LIB") or os.path.join(_HERE, "libblobctrl_hip.so")
 
 A_DENSE, A_CONV3X3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
