@@ -250,7 +250,8 @@ def main():
         "value": world * args.steps / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: single {args.res}x{args.res} edit, batch {args.batch} (CFG batch {2 * args.batch} for the UNet, "
+        "config": {"workload": f"BASELINE configs[{1 if (args.res == 512 and args.batch == 1) else (2 if args.res == 512 else 4)}]: "
+                               f"{args.res}x{args.res} edit, batch {args.batch} (CFG batch {2 * args.batch} for the UNet, "
                                f"BlobNet shared across CFG halves), {args.denoise_steps} {args.scheduler.upper()} steps, "
                                "guidance window [0,1], fp16 activations / fp32 accumulate, LoRA pre-merged, hipGraph-replayed steps",
                    "edits_per_rank": args.steps, "denoise_steps": args.denoise_steps,

@@ -27,7 +27,7 @@ class BcGemm(C.Structure):
         ("W", C.c_void_p), ("ldw", C.c_int),
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int), ("rows_per_batch", C.c_int),
         ("act", C.c_int), ("colscale", C.c_void_p), ("alpha", C.c_float),
-        ("alpha_dev", C.c_void_p), ("alpha_idx", C.c_void_p),
+        ("alpha_dev", C.c_void_p), ("alpha_idx", C.c_void_p), ("alpha_bstride", C.c_int),
         ("R", C.c_void_p), ("ldr", C.c_int),
         ("R2", C.c_void_p), ("ldr2", C.c_int), ("r2_xmin", C.c_int), ("r2_bmod", C.c_int), ("out_w", C.c_int),
         ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),

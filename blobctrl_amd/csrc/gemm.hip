@@ -209,8 +209,7 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
     if (idx >= total) return;
     int m = (int)(idx / g.n_out);
     int n = (int)(idx - (long long)m * g.n_out);
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    const float alpha = scalar_alpha(p);
     const size_t mn = (size_t)p.M * p.N;
     if (p.act == BC_ACT_GEGLU) {
         int nv = (n >> 5) * 64 + (n & 31), ng = nv + 32;
@@ -245,8 +244,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g
     const int n_first = blockIdx.x * 64 + col8 * 8;
     const bool geglu = p.act == BC_ACT_GEGLU;
     const int ncol_v = geglu ? (n_first >> 5) * 64 + (n_first & 31) : n_first;
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    const float alpha = scalar_alpha(p);
     Cols8 cols;
     cols8_init(g, cols, n_first, ncol_v, geglu, alpha);
     float gs[8], gq[8];
@@ -417,6 +415,8 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     BcGemm& p = g.p;
     BC_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "bc_gemm: bad dims M=%d N=%d K=%d", p.M, p.N, p.K);
     BC_CHECK_ARG(p.A && p.W && p.C, "bc_gemm: null A/W/C");
+    BC_CHECK_ARG(p.alpha_bstride == 0 || (p.alpha_bstride > 0 && p.alpha_dev && p.rows_per_batch > 0 && p.out_mode != BC_OUT_F16_T),
+                 "bc_gemm: alpha_bstride needs alpha_dev, rows_per_batch > 0 and a row-major output");
     BC_CHECK_ARG(p.K % 8 == 0 && p.ldw % 8 == 0 && p.ldw >= p.K, "bc_gemm: K=%d ldw=%d must be multiples of 8, ldw>=K", p.K, p.ldw);
     BC_CHECK_ARG(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0), "bc_gemm: A/W must be 16-byte aligned");
     if (p.a_mode == BC_A_CONV3X3) {

@@ -46,11 +46,23 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Launch-wide scalar multiplier; with alpha_bstride > 0 the device table holds one scalar per image and is applied per row.
+__device__ __forceinline__ float scalar_alpha(const BcGemm& p) {
+    float alpha = p.alpha;
+    if (p.alpha_dev && p.alpha_bstride == 0) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    return alpha;
+}
+__device__ __forceinline__ float batch_alpha(const GemmArgs& g, int b) {
+    const BcGemm& p = g.p;
+    return p.alpha_dev[(p.alpha_idx ? *p.alpha_idx : 0) * p.alpha_bstride + b];
+}
+
 // One output element: everything after the accumulator (+bias +rowvec, activation) has been applied by the caller.
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, float v, int m, int n, float alpha) {
     const BcGemm& p = g.p;
     if (p.colscale) v *= p.colscale[n];
     v *= alpha;
+    if (p.alpha_bstride > 0) v *= batch_alpha(g, (int)fdiv((unsigned)m, g.div_rpb));
     if (p.R) v += (float)reinterpret_cast<const h16*>(p.R)[(size_t)m * p.ldr + n];
     int b = 0, pix = m;
     if (p.R2 || p.out_mode == BC_OUT_F16_T) {
@@ -115,8 +127,7 @@ __device__ __forceinline__ void tile_epilogue_scalar(const GemmArgs& g, const fl
         }
         return;
     }
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    const float alpha = scalar_alpha(p);
     if (p.act == BC_ACT_GEGLU) {
         constexpr int BNO = BN / 2;
         for (int idx = tid; idx < BM * BNO; idx += NT) {
@@ -172,7 +183,7 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += c.bias_v[j];
     int b = 0, pix = m;
-    if (p.rowvec || p.R2) {
+    if (p.rowvec || p.R2 || p.alpha_bstride > 0) {
         b = (int)fdiv((unsigned)m, g.div_rpb);
         pix = m - b * (int)g.div_rpb.d;
     }
@@ -197,6 +208,11 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= c.cs[j];
+    if (p.alpha_bstride > 0) {
+        const float ab = batch_alpha(g, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= ab;
+    }
     if (p.R) {
         const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)m * p.ldr + c.n_first);
         const h16* rh = reinterpret_cast<const h16*>(&raw);
@@ -247,8 +263,7 @@ __device__ __forceinline__ void acc_to_tile_t(float* tile, int ts, const f32x16 
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, const float* tileT, int ts, int m0, int n0, int tid) {
     const BcGemm& p = g.p;
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    const float alpha = scalar_alpha(p);
     constexpr int MCH = BM / 8;                       // 8-token chunks per column
     for (int idx = tid; idx < BN * MCH; idx += NT) {
         const int col = idx / MCH, mc = idx - col * MCH;

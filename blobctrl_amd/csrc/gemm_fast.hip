@@ -230,8 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
 
     // ---- row-major pass, 8 output columns per thread: bias, time-embedding row vector, activation, LayerScale, scale,
     // ---- residual, BlobNet right-half residual, fp16 store (all 16-byte accesses) and GroupNorm partials ----
-    float alpha = p.alpha;
-    if (p.alpha_dev) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
+    const float alpha = scalar_alpha(p);
     const bool geglu = p.act == BC_ACT_GEGLU;
     const int TSO = geglu ? BN / 2 : BN;            // output columns of this block
     const int CPR = TSO / 8;                        // chunks per tile row (power of two: 4, 8, 16)

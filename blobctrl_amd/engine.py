@@ -215,7 +215,8 @@ class TrunkPlan:
     def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,
                        signal_residuals: bool = False):
         """x_in: [B, H*W, pad8(in_channels)] fp16.  UNet: returns eps fp32 [B, H*W, out_channels].
-        BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx))."""
+        BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx[, alpha_bstride]);
+        alpha_bstride = B selects per-image scales alpha_dev[step * B + image] for a batch of independent requests)."""
         cfg, pw = self.cfg, self.pw
         boc = cfg.block_out_channels
         nb = len(boc)
@@ -225,7 +226,7 @@ class TrunkPlan:
         self.res_bmod = residuals.bmod if residuals is not None else 1
         self.res_events = residuals.events if residuals is not None else None
         pop = (lambda lst: lst.pop(0)) if residuals is not None else (lambda lst: None)
-        alpha, alpha_dev, alpha_idx = zero_scale if zero_scale is not None else (1.0, None, None)
+        alpha, alpha_dev, alpha_idx, alpha_bstride = (tuple(zero_scale) + (0,))[:4] if zero_scale is not None else (1.0, None, None, 0)
         out_events = {} if signal_residuals else None
 
         class _Feats(list):
@@ -241,7 +242,8 @@ class TrunkPlan:
                     name = s2.prefix if s2.prefix.endswith("mid_block") else f"{s2.prefix}.{len(s2) - 1}"
                     M = self.B * f.H * f.W
                     r = self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
-                                   alpha_idx=alpha_idx).view(self.B, f.H * f.W, f.C)
+                                   alpha_idx=alpha_idx, alpha_bstride=alpha_bstride,
+                                   rows_per_batch=f.H * f.W).view(self.B, f.H * f.W, f.C)
                     if out_events is not None:
                         ev = self.rec.new_event()
                         self.rec.signal(ev)

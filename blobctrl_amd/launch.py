@@ -188,7 +188,7 @@ class Recorder:
 
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
-             alpha=1.0, alpha_dev=None, alpha_idx=None, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
+             alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
@@ -213,7 +213,7 @@ class Recorder:
         g.act = act
         g.colscale = ptr(colscale)
         g.alpha = alpha
-        g.alpha_dev, g.alpha_idx = ptr(alpha_dev), ptr(alpha_idx)
+        g.alpha_dev, g.alpha_idx, g.alpha_bstride = ptr(alpha_dev), ptr(alpha_idx), alpha_bstride
         g.R, g.ldr = (ptr(R) if not isinstance(R, int) else R), ldr
         g.R2, g.ldr2, g.r2_xmin, g.r2_bmod, g.out_w = ptr(R2), ldr2, r2_xmin, r2_bmod, out_w
         g.out_mode = out_mode

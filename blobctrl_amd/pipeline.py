@@ -61,8 +61,10 @@ class StableDiffusionBlobNetPipeline:
         self.text_encoder = text_encoder                              # optional blobctrl_amd.clip_text.CLIPTextModel
 
     # ------------------------------------------------------------------------------------------------ planning
-    def _plan(self, B, h, w, T, ctx_dim, nsteps):
-        key = (B, h, w, T, ctx_dim, nsteps)
+    def _plan(self, B, h, w, T, ctx_dim, nsteps, per_request=False):
+        """per_request: the B samples are B independent edit requests (own fg / bg latents, scores, DINO features and
+        conditioning scales) instead of B variations of one edit."""
+        key = (B, h, w, T, ctx_dim, nsteps, per_request)
         if key in self._plans:
             return self._plans[key]
         dev = self.device
@@ -72,22 +74,25 @@ class StableDiffusionBlobNetPipeline:
         H, W = h, 2 * w
         F = self.feat_dim
         f32 = torch.float32
+        Bi = B if per_request else 1                         # images (fg / bg / score / feature sets) behind the batch
+        P.Bi = Bi
         P.latents = rec.zeros(B, 4, h, w, dtype=f32)
-        P.fg_lat = rec.zeros(1, 4, h, w, dtype=f32)
-        P.bg_lat = rec.zeros(1, 4, h, w, dtype=f32)
-        P.fg_score = rec.zeros(1, h, w, dtype=f32)
-        P.bg_score = rec.zeros(1, h, w, dtype=f32)
-        P.feat = rec.zeros(1, max(F, 1), dtype=f32)
+        P.fg_lat = rec.zeros(Bi, 4, h, w, dtype=f32)
+        P.bg_lat = rec.zeros(Bi, 4, h, w, dtype=f32)
+        P.fg_score = rec.zeros(Bi, h, w, dtype=f32)
+        P.bg_score = rec.zeros(Bi, h, w, dtype=f32)
+        P.feat = rec.zeros(Bi, max(F, 1), dtype=f32)
         P.ctx = rec.zeros(2 * B, T, ctx_dim)
         P.step_idx = rec.zeros(1, dtype=torch.int32)
         P.t_table = rec.zeros(nsteps, dtype=f32)
         P.coef = rec.zeros(nsteps, 16, dtype=f32)
-        P.scale_table = rec.zeros(nsteps, dtype=f32)
+        P.scale_table = rec.zeros(nsteps * Bi, dtype=f32)   # [step][image] conditioning_scale * keep
         P.hist = rec.zeros(3, B * 4 * h * w, dtype=f32)
         P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32)
         P.guidance = [7.5]
 
-        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h      # rank-1 collapse of the BlobNet feature channels
+        # rank-1 collapse of the BlobNet feature channels (per-edit weight): not for per-request batches (one weight per launch)
+        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request
         unet_cin = pad8(self.unet_cfg.in_channels)
         blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
         P.feat16 = rec.zeros(1, pad8(max(F, 1)))
@@ -103,7 +108,7 @@ class StableDiffusionBlobNetPipeline:
             blob.record_collapse(P.feat16)
 
         def record_unet(plan, residuals):
-            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, 1, 0,
+            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, Bi, 0,
                      2 * B, h, w, unet_cin, 0, P.unet_in.data_ptr(), kind="assemble")
             plan.record_time(P.t_table, P.step_idx)
             eps = plan.record_forward(P.unet_in, residuals)
@@ -131,9 +136,9 @@ class StableDiffusionBlobNetPipeline:
                      B, h, w, blob_cin, 1, P.blob_in.data_ptr(), kind="assemble")
         else:
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
-                     P.feat.data_ptr() if F > 0 else None, 1, F, B, h, w, blob_cin, 0, P.blob_in.data_ptr(), kind="assemble")
+                     P.feat.data_ptr() if F > 0 else None, Bi, F, B, h, w, blob_cin, 0, P.blob_in.data_ptr(), kind="assemble")
         blob.record_time(P.t_table, P.step_idx)
-        residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx),
+        residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx, B if per_request else 0),
                                         signal_residuals=True)
         rec.sid = 0
         P.residuals = residuals
@@ -172,7 +177,10 @@ class StableDiffusionBlobNetPipeline:
 
     # ------------------------------------------------------------------------------------------------ call
     def check_inputs(self, blobnet_conditioning_scale, start, end, num_inference_steps):
-        if not isinstance(blobnet_conditioning_scale, float):                       # pipe:395-396
+        if isinstance(blobnet_conditioning_scale, (list, tuple)):                   # per-request batch (extension)
+            if not all(isinstance(v, float) for v in blobnet_conditioning_scale):
+                raise TypeError("per-request `blobnet_conditioning_scale` must be a list of `float`.")
+        elif not isinstance(blobnet_conditioning_scale, float):                     # pipe:395-396
             raise TypeError("For single blobnet: `blobnet_conditioning_scale` must be type `float`.")
         if start >= end:                                                            # pipe:424-427
             raise ValueError(f"control guidance start: {start} cannot be larger or equal to control guidance end: {end}.")
@@ -251,7 +259,18 @@ class StableDiffusionBlobNetPipeline:
         B = B2 // 2
         h, w = fg_image_latents.shape[-2:]
         n = num_inference_steps
-        P = self._plan(B, h, w, T, Dc, n)
+        per_request = fg_image_latents.dim() == 4 and fg_image_latents.shape[0] > 1
+        Bi = B if per_request else 1
+        if per_request:
+            for name, t_ in (("fg_image_latents", fg_image_latents), ("bg_image_latents", bg_image_latents), ("gs_score", gs_score),
+                             ("dino_feats", dino_feats)):
+                if t_ is not None and t_.shape[0] != B:
+                    raise ValueError(f"request batch: {name} must have leading dimension {B} (one per request), got {t_.shape[0]}")
+        req_scales = list(blobnet_conditioning_scale) if isinstance(blobnet_conditioning_scale, (list, tuple)) else \
+            [blobnet_conditioning_scale] * Bi
+        if len(req_scales) != Bi:
+            raise ValueError(f"blobnet_conditioning_scale: expected {Bi} values, got {len(req_scales)}")
+        P = self._plan(B, h, w, T, Dc, n, per_request)
         dev = self.device
         sched = self._sched_cache.get((self.scheduler_kind, n))       # coefficient tables depend only on (scheduler, steps)
         if sched is None:
@@ -263,25 +282,27 @@ class StableDiffusionBlobNetPipeline:
             latents = torch.randn((B, 4, h, w), generator=generator, device=generator.device if generator else "cpu",
                                   dtype=torch.float32)
         keep = blobnet_keep(n, blobnet_control_guidance_start, blobnet_control_guidance_end)
-        scales = [blobnet_conditioning_scale * k for k in keep]
+        scale_rows = [[sc * k for sc in req_scales] for k in keep]                   # [step][image]
+        scales = [max(abs(v) for v in row) for row in scale_rows]                    # a step is BlobNet-free iff every scale is 0
         bg, fg = gs_score.unbind(dim=1)                                              # pipe:974
         with torch.cuda.stream(self.stream):
             P.latents.copy_(latents.to(dev, torch.float32) * sched.init_noise_sigma)
-            P.fg_lat.copy_(fg_image_latents.to(dev, torch.float32).reshape(1, 4, h, w))
-            P.bg_lat.copy_(bg_image_latents.to(dev, torch.float32).reshape(1, 4, h, w))
-            P.fg_score.copy_(fg.to(dev, torch.float32).reshape(1, h, w))
-            P.bg_score.copy_(bg.to(dev, torch.float32).reshape(1, h, w))
+            P.fg_lat.copy_(fg_image_latents.to(dev, torch.float32).reshape(Bi, 4, h, w))
+            P.bg_lat.copy_(bg_image_latents.to(dev, torch.float32).reshape(Bi, 4, h, w))
+            P.fg_score.copy_(fg.to(dev, torch.float32).reshape(Bi, h, w))
+            P.bg_score.copy_(bg.to(dev, torch.float32).reshape(Bi, h, w))
             if self.feat_dim > 0:
                 if dino_feats is None:
                     raise ValueError("dino_feats is required (BlobNet conditioning channels)")
-                P.feat.copy_(dino_feats.to(dev, torch.float32).reshape(1, self.feat_dim))
-                P.feat16[:, : self.feat_dim].copy_(P.feat)
+                P.feat.copy_(dino_feats.to(dev, torch.float32).reshape(Bi, self.feat_dim))
+                if P.collapse:
+                    P.feat16[:, : self.feat_dim].copy_(P.feat)
             P.ctx.copy_(prompt_embeds.to(dev, torch.float16))
             P.t_table.copy_(sched.timesteps.to(torch.float32))
             coef = sched.table().clone()
             coef[:, 11] = float(guidance_scale)          # read by the captured cfg/scheduler kernel
             P.coef.copy_(coef)
-            P.scale_table.copy_(torch.tensor(scales, dtype=torch.float32))
+            P.scale_table.copy_(torch.tensor(scale_rows, dtype=torch.float32).reshape(-1))
             P.step_idx.zero_()
             P.hist.zero_()
         P.guidance[0] = float(guidance_scale)
@@ -312,5 +333,5 @@ class StableDiffusionBlobNetPipeline:
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
     # convenience for bench / tests ------------------------------------------------------------------
-    def plan_for(self, B, h, w, T, ctx_dim, nsteps):
-        return self._plan(B, h, w, T, ctx_dim, nsteps)
+    def plan_for(self, B, h, w, T, ctx_dim, nsteps, per_request=False):
+        return self._plan(B, h, w, T, ctx_dim, nsteps, per_request)

@@ -72,6 +72,8 @@ typedef struct BcGemm {
     float alpha;             /* scalar multiplier (1.0f default) */
     const float*   alpha_dev;/* optional device scalar table: alpha *= alpha_dev[*alpha_idx] (BlobNet conditioning_scale*keep[i]) */
     const int*     alpha_idx;
+    int alpha_bstride;       /* 0: one scalar per launch; B > 0: per-image scalars alpha_dev[*alpha_idx * B + m / rows_per_batch]
+                              * (a batch of independent edit requests with their own conditioning scales) */
     const bc_half* R;        /* residual [M][ldr] or NULL */
     int ldr;
     const bc_half* R2;       /* BlobNet residual, token-major [r2_bmod][rows_per_batch][ldr2], added where x >= r2_xmin */

@@ -1,6 +1,6 @@
 """BASELINE.json configs beyond the headline one, as parity / property tests (they are not bench lines):
-  C3  batch 8 at 512^2           - every sample of a batched edit equals the same edit run alone (tiny: exact plan comparison over
-                                   3 samples; full size: sample 0 and 7 of batch 8 vs batch 1);
+  C3  batch 8 at 512^2           - every sample of a batched edit equals the same edit run alone (tiny: 3 variations of one edit and
+                                   3 INDEPENDENT mixed-op requests incl. a `remove`; full size: sample 0 and 7 of batch 8 vs batch 1);
   C5  768^2, batch 4             - full-size properties the domain offers where the CPU oracle would take hours: bit-exact
                                    determinism of graph replays, exact affinity of the update in the guidance scale
                                    (eps = eps_u + s (eps_c - eps_u), pipe:1097-1098), finite outputs;
@@ -35,6 +35,36 @@ def test_batched_edit_equals_single_edits_tiny():
     for b in range(B):
         single = pipe(torch.cat([neg[b:b + 1], pos[b:b + 1]]), fg, bg, score, dino, latents=lat[b:b + 1], **kw).cpu().numpy()
         assert _rel(batched[b:b + 1], single) < 5e-3 and psnr(batched[b:b + 1], single) > 50.0, f"sample {b}"
+
+
+def test_request_batch_mixed_ops_equals_single_edits_tiny():
+    """C3 semantics at tiny size: B independent edits (own fg / bg / score / DINO features / strength, one of them a `remove`
+    with strength 0.0) in ONE batched call == the same edits run one at a time."""
+    usd, bsd = tiny_weights()
+    pipe = make_pipeline(usd, bsd, scheduler="ddim")
+    B, steps = 3, 3
+    lat = g(91, B, 4, 8, 8)
+    neg, pos = g(92, B, 7, TINY["ctx"]), g(93, B, 7, TINY["ctx"])
+    fg, bg = g(94, B, 4, 8, 8), g(95, B, 4, 8, 8)
+    score, dino = g(96, B, 2, 8, 8).abs().clamp(max=1), g(97, B, 1, TINY["feat"])
+    strengths = [1.0, 0.0, 1.7]
+    kw = dict(num_inference_steps=steps, guidance_scale=4.0, blobnet_control_guidance_end=0.7)
+    batched = pipe(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=strengths, **kw).cpu().numpy()
+    assert batched.shape == (B, 4, 8, 8) and np.isfinite(batched).all()
+    for b in range(B):
+        single = pipe(torch.cat([neg[b:b + 1], pos[b:b + 1]]), fg[b:b + 1], bg[b:b + 1], score[b:b + 1], dino[b:b + 1],
+                      latents=lat[b:b + 1], blobnet_conditioning_scale=strengths[b], **kw).cpu().numpy()
+        assert _rel(batched[b:b + 1], single) < 5e-3 and psnr(batched[b:b + 1], single) > 50.0, f"request {b}"
+    # the requests really differ from each other, and a batch of all-zero strengths takes the BlobNet-free plan
+    assert _rel(batched[0:1], batched[2:3]) > 1e-2
+    zero = pipe(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=[0.0] * B, **kw).cpu().numpy()
+    assert _rel(zero[1:2], batched[1:2]) < 5e-3
+    with pytest.raises(ValueError):
+        pipe(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=[1.0, 2.0], **kw)
+    with pytest.raises(TypeError):
+        pipe(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=[1, 2, 3], **kw)
+    with pytest.raises(ValueError):
+        pipe(torch.cat([neg, pos]), fg, bg[:2], score, dino, latents=lat, blobnet_conditioning_scale=strengths, **kw)
 
 
 @pytest.fixture(scope="module")

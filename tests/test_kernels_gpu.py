@@ -57,6 +57,24 @@ def test_gemm_dense_bias(rec, M, N, K):
     close(out, ref, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("N,K,splitk", [(192, 128, None), (192, 1280, 3), (20, 72, None)])
+def test_gemm_per_image_alpha(rec, N, K, splitk):
+    """alpha_bstride: one device scalar per image and step (request batches with their own conditioning scales)."""
+    from blobctrl_amd import _lib
+    B, rows = 3, 100
+    M = B * rows
+    A, W, b = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N)
+    tab = torch.tensor([9.0, 9.0, 9.0, 0.0, 0.7, 1.3]).cuda()          # [step][image]; step 1 is used
+    idx = torch.tensor([1], dtype=torch.int32).cuda()
+    out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), alpha=2.0, alpha_dev=tab,
+                                    alpha_idx=idx, alpha_bstride=B, rows_per_batch=rows, splitk=splitk))
+    v = (A.half().float() @ W.half().float().t() + b) * 2.0
+    ref = v * torch.tensor([0.0, 0.7, 1.3]).repeat_interleave(rows)[:, None]
+    close(out, ref, what="per-image alpha")
+    with pytest.raises(_lib.BlobCtrlHipError):                          # needs rows_per_batch
+        run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), alpha_dev=tab, alpha_idx=idx, alpha_bstride=B))
+
+
 @pytest.mark.parametrize("act", ["gelu", "silu"])
 def test_gemm_act_residual_colscale_alpha(rec, act):
     from blobctrl_amd import _lib
