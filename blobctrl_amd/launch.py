@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import BcGemm
 
 
-_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
+_TUNING_PATH = os.environ.get("BC_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
 _TUNING = None
 
 

@@ -54,6 +54,29 @@ def collect_shapes(res):
     return shapes
 
 
+def time_launch_cold(rec, seg, stream, iters, thrash, touch):
+    """In-situ-like timing: before every timed launch the caches are flushed by streaming `thrash` (> the 256 MiB Infinity Cache)
+    and the activation operand is touched again (in the loop it was just written by its producer, so it sits in L2 / MALL while
+    the weights - 3.4 GB per step - always come cold from HBM)."""
+    lib = rec.lib
+    tot = 0.0
+    for it in range(iters + 1):
+        thrash.add_(1)
+        for t in touch:
+            t.mul_(1)
+        a, b = C.c_void_p(), C.c_void_p()
+        lib.bc_event_create(C.byref(a)); lib.bc_event_create(C.byref(b))
+        lib.bc_event_record(a, stream)
+        seg.run(stream)
+        lib.bc_event_record(b, stream)
+        ms = C.c_float()
+        _lib.check(lib.bc_event_elapsed_ms(a, b, C.byref(ms)), "elapsed")
+        lib.bc_event_destroy(a); lib.bc_event_destroy(b)
+        if it > 0:
+            tot += ms.value
+    return tot * 1e3 / iters
+
+
 def time_launch(rec, seg, stream, iters):
     lib = rec.lib
     a, b = C.c_void_p(), C.c_void_p()
@@ -75,9 +98,9 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--out", default=os.path.join(REPO, "blobctrl_amd", "gemm_tuning.json"))
     ap.add_argument("--iters", type=int, default=8)
-    ap.add_argument("--gn-penalty-us", type=float, default=10.0,
-                    help="cost charged to split-K on convolutions: their outputs feed a GroupNorm whose statistics can only be "
-                         "fused into the epilogue when splitk == 1 (otherwise a stand-alone bc_gn_stats pass runs)")
+    ap.add_argument("--gn-penalty-us", type=float, default=0.0,
+                    help="extra cost charged to split-K on convolutions (0: the split-K reducer emits the GroupNorm partials too)")
+    ap.add_argument("--cold", action="store_true", help="flush the caches before every timed launch (weights cold, activations warm)")
     args = ap.parse_args()
     os.environ["BC_NO_TUNING"] = "1"
     dev = torch.device("cuda:0")
@@ -88,6 +111,7 @@ def main():
         shapes.update(collect_shapes(768)) if os.environ.get("BC_TUNE_768") else None
     table, report = {}, []
     t0 = time.time()
+    thrash = torch.zeros(160 * 1024 * 1024, dtype=torch.float32, device=dev) if args.cold else None      # 640 MB
     for (mode, M, N, K), conv in sorted(shapes.items()):
         nk = K // 64
         if K % 64 or (conv and conv["Cin"] % 64):
@@ -114,7 +138,8 @@ def main():
                 seg = rec.begin("t")
                 rec.gemm(A=A, W=Wt, M=M, N=N, K=K, out=out, bias=bias, conv=conv, tile_cfg=cfg, splitk=sk,
                          rows_per_batch=(conv["Hout"] * conv["Wout"] if conv else 0))
-                us = time_launch(rec, seg, stream, args.iters)
+                us = time_launch_cold(rec, seg, stream, args.iters, thrash, (A,)) if args.cold else \
+                    time_launch(rec, seg, stream, args.iters)
                 results.append((us, cfg, sk))
                 cost = us + (args.gn_penalty_us if (sk > 1 and mode != "dense") else 0.0)
                 if best is None or cost < best[3]:
