@@ -53,3 +53,26 @@ def test_full_size_blobnet_and_unet_step(full):
     err = np.abs(eps - ref).max() / np.abs(ref).max()
     print(f"full-size UNet eps: max-abs/scale {err:.3e}, PSNR {psnr(eps, ref):.1f} dB; BlobNet residuals worst {worst:.3e}")
     assert err < 1e-2 and psnr(eps, ref) > 40.0
+
+
+def test_full_size_two_step_loop_vs_oracle(full):
+    """The north-star bar at the benchmark's own size: final latents of a (2-step, DDIM, CFG 7.5) 512x512 edit through the
+    hipGraph-replayed engine vs the CPU oracle loop on the same seeded weights and inputs: PSNR >= 40 dB, max-abs <= 1e-2 of the
+    latent scale.  ~1.5 minutes of host CPU time (the oracle runs BlobNet on both CFG halves like the reference does)."""
+    import os
+    import bench
+    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.splat import splat_features
+    from oracle import pipeline as o_pipe, schedulers as o_sched
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    h = w = 64
+    inp = bench.synth_inputs(h, w, batch=1)
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
+    pipe = StableDiffusionBlobNetPipeline(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
+    out = pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=2, guidance_scale=7.5,
+               latents=inp["latents"]).cpu().numpy()
+    ref = o_pipe.denoise_loop(full["usd"], full["oucfg"], full["bsd"], full["obcfg"], o_sched.DDIMOracle(), 2, inp["latents"],
+                              inp["prompt"], inp["fg"], inp["bg"], score.cpu().float(), inp["dino"], 7.5, 1.0, 0.0, 1.0).numpy()
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    print(f"full-size 2-step loop: final latents max-abs/scale {err:.3e}, PSNR {psnr(out, ref):.1f} dB")
+    assert err < 1e-2 and psnr(out, ref) > 40.0
