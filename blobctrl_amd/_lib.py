@@ -104,6 +104,13 @@ def load():
         raise BlobCtrlHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  blobctrl_amd has no CPU fallback.")
+    # PyTorch (the device-memory / stream provider of this package) ships its own libamdhip64; if this library were loaded first
+    # it would pull in the system copy and the process would end up with TWO HIP runtimes - the second one then reports "no
+    # ROCm-capable device".  Importing torch first makes the loader bind our HIP calls to the runtime torch already uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:   # pragma: no cover - plain C / ctypes use without PyTorch: the system HIP runtime is the only one
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:   # pragma: no cover

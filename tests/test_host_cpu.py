@@ -113,3 +113,20 @@ def test_blobnet_keep_window():
     assert blobnet_keep(50, 0.0, 0.9).count(1.0) == 45          # script default (inf:306-307) -> 45 active steps
     assert blobnet_keep(50, 0.0, 1.0) == [1.0] * 50
     assert blobnet_keep(6, 0.0, 0.67) == [1.0, 1.0, 1.0, 1.0, 0.0, 0.0]
+
+
+def test_library_load_does_not_create_a_second_hip_runtime():
+    """Loading libblobctrl_hip.so before torch used to pull in the system libamdhip64 next to torch's bundled copy; the second HIP
+    runtime then reports "no ROCm-capable device" (seen in `__graft_entry__.smoke()` on the GPU box).  `_lib.load()` imports torch
+    first - one runtime, whatever the import order of the caller."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from blobctrl_amd import _lib\n"
+            "_lib.load()\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().startswith("1 "), out.stdout
