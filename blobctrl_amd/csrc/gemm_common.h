@@ -283,7 +283,9 @@ __device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, cons
         if (m + 8 <= p.M) {
             bc_st16(dst, outraw);
         } else {
-            for (int j = 0; j < p.M - m; ++j) dst[j] = o[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)               // (constant indices: a runtime-indexed o[] would live in scratch)
+                if (j < p.M - m) dst[j] = o[j];
         }
     }
 }
