@@ -130,3 +130,40 @@ def test_library_load_does_not_create_a_second_hip_runtime():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().startswith("1 "), out.stdout
+
+
+def test_no_hot_kernel_uses_scratch(tmp_path):
+    """Code-object metadata of the built library: the GEMM / norm / elementwise kernels must not touch scratch (an accumulator
+    array demoted to scratch once cost 25x: DESIGN 3.1), the attention kernels at most the few tail spills of the 128-VGPR
+    build.  Reads the embedded gfx950 code objects with the ROCm LLVM tools (skipped when they are absent)."""
+    import shutil
+    import subprocess
+    from blobctrl_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    bundler, readelf = os.path.join(llvm, "clang-offload-bundler"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(bundler) and os.path.exists(readelf) and shutil.which("objcopy")):
+        pytest.skip("ROCm LLVM tools not available")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat])
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+    assert len(starts) >= 5, "expected one offload bundle per translation unit with device code"
+    seen = {}
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        part, co = str(tmp_path / f"b{n}.bin"), str(tmp_path / f"b{n}.co")
+        open(part, "wb").write(blob[a:b])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--output={co}"], stderr=subprocess.DEVNULL)
+        notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split()[-1]
+            elif line.startswith(".private_segment_fixed_size:") and name:
+                seen[name] = int(line.split()[-1])
+    assert len(seen) >= 40, f"only {len(seen)} kernels found in the code objects"
+    for name, scratch in seen.items():
+        limit = 128 if "attn_fwd_kernel" in name else 0
+        assert scratch <= limit, f"{name}: {scratch} bytes of scratch per lane"
