@@ -37,12 +37,13 @@ class StableDiffusionBlobNetPipeline:
     """MI355X engine with the reference pipeline's call surface for the denoising hot path."""
 
     def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
-                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None, text_encoder=None):
+                 device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None, text_encoder=None,
+                 max_cached_plans: int = 4):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.BlobCtrlHipError("blobctrl_amd runs on MI355X only (device must be cuda:N); there is no CPU fallback")
         torch.cuda.set_device(self.device)
-        _lib.load()
+        self.lib = _lib.load()
         self.unet_cfg, self.blob_cfg = unet_config, blobnet_config
         # either reference-schema state dicts (packed here) or already-packed / broadcast replicas (dist.broadcast_packed)
         self.unet_w = unet_state_dict if isinstance(unet_state_dict, PackedTrunk) else \
@@ -54,7 +55,8 @@ class StableDiffusionBlobNetPipeline:
         self.stream = torch.cuda.Stream(device=self.device)
         self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
-        self._plans = {}
+        self._plans = {}                                              # (batch, canvas, steps, ...) -> plan, least recently used first
+        self.max_cached_plans = max(1, int(max_cached_plans))         # a 512^2 batch-1 plan holds ~2.5 GB of activations
         self._sched_cache = {}
         self.feat_dim = blobnet_config.in_channels - 5
         self.vae = vae                                                # optional blobctrl_amd.vae.AutoencoderKL
@@ -66,7 +68,16 @@ class StableDiffusionBlobNetPipeline:
         conditioning scales) instead of B variations of one edit."""
         key = (B, h, w, T, ctx_dim, nsteps, per_request)
         if key in self._plans:
+            self._plans[key] = self._plans.pop(key)                   # mark as most recently used
             return self._plans[key]
+        while len(self._plans) >= self.max_cached_plans:              # evict the least recently used plan and its graphs
+            old = self._plans.pop(next(iter(self._plans)))
+            torch.cuda.synchronize(self.device)
+            for seg in (old.prologue, old.step_active, old.step_inactive):
+                seg.release()
+            for ev in old.rec.events:
+                self.lib.bc_event_destroy(ev)
+            old.rec.events = []
         dev = self.device
         rec = Recorder(dev)
         P = type("Plan", (), {})()

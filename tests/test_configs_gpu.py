@@ -121,3 +121,19 @@ def test_batch8_samples_equal_batch1_full_size(full_pipe):
         # two fp16 realisations of the same arithmetic (different GEMM tilings), differences amplified 7.5x by the guidance:
         # PSNR is the bar (BASELINE: >= 40 dB); the max-abs bound is the looser free-running one of test_parity_gpu
         assert e < 3e-2 and psnr(out8[b:b + 1], single) > 40.0, f"sample {b}: rel {e:.3e} psnr {psnr(out8[b:b + 1], single):.1f}"
+
+
+def test_plan_cache_is_bounded():
+    """Plans (static buffers + captured graphs) are cached per (batch, canvas, steps); the cache evicts least-recently-used plans."""
+    usd, bsd = tiny_weights()
+    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from tests.gpu_common import tiny_trunk_configs
+    u, b = tiny_trunk_configs()
+    pipe = StableDiffusionBlobNetPipeline(usd, bsd, u, b, device="cuda:0", scheduler="ddim", max_cached_plans=2)
+    args = (g(82, 2, 7, TINY["ctx"]), g(84, 1, 4, 8, 8), g(85, 1, 4, 8, 8), g(86, 1, 2, 8, 8).abs().clamp(max=1), g(87, 1, 1, TINY["feat"]))
+    first = pipe(*args, num_inference_steps=2, latents=g(81, 1, 4, 8, 8)).cpu()
+    for n in (3, 4, 5):
+        pipe(*args, num_inference_steps=n, latents=g(81, 1, 4, 8, 8))
+        assert len(pipe._plans) <= 2
+    again = pipe(*args, num_inference_steps=2, latents=g(81, 1, 4, 8, 8)).cpu()      # re-planned after eviction: same bits
+    assert torch.equal(first, again)
