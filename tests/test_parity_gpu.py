@@ -195,3 +195,22 @@ def test_captured_graph_follows_per_call_arguments():
         ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 3, a["latents"], a["prompt"], a["fg"], a["bg"],
                                   a["score"].float(), a["dino"], gs, cs).numpy()
         assert rel_err(out, ref) < 2e-2, (gs, cs, rel_err(out, ref))
+
+
+@pytest.mark.parametrize("h,w", [(8, 16), (16, 8), (24, 8)])
+def test_non_square_edits_match_oracle(h, w):
+    """Edits whose latent is not square (the CLI derives width / height from the image, inf:163-164): canvas h x 2w, including the
+    h == 2w case where the CANVAS is square and the UNet takes the `sample + r` branch (unet_2d_condition.py:1213-1217)."""
+    from oracle import blob_splat, pipeline as o_pipe, schedulers as o_sched
+    usd, bsd = tiny_weights()
+    ucfg, bcfg = tiny_cfgs()
+    pipe = make_pipeline(usd, bsd, scheduler="ddim")
+    score = torch.from_numpy(blob_splat.splat_scores_from_ellipse([[40.0, 42.0], [20.0, 30.0], 25.0], 8 * w, 8 * h, h, w))
+    a = dict(latents=g(41, 1, 4, h, w), prompt=g(42, 2, 7, TINY["ctx"]), fg=g(43, 1, 4, h, w) * 0.18215 * 5,
+             bg=g(44, 1, 4, h, w) * 0.18215 * 5, dino=g(45, 1, 1, TINY["feat"]))
+    out = pipe(a["prompt"], a["fg"], a["bg"], score, a["dino"], num_inference_steps=2, guidance_scale=3.0,
+               latents=a["latents"]).cpu().numpy()
+    ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 2, a["latents"], a["prompt"], a["fg"], a["bg"],
+                              score.float(), a["dino"], 3.0).numpy()
+    assert out.shape == (1, 4, h, w)
+    assert rel_err(out, ref) < 2e-2 and psnr(out, ref) > 38.0, f"{h}x{w}: rel {rel_err(out, ref):.3e} psnr {psnr(out, ref):.1f}"
