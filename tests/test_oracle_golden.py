@@ -57,7 +57,7 @@ def test_schedulers(golden_dir, n):
     np.testing.assert_allclose(u.sigmas.numpy(), z[f"unipc_{n}_sigmas"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["wide", "square"])
+@pytest.mark.parametrize("tag", ["wide", "square", "odd"])
 def test_nets_tiny(golden_dir, tag):
     z = load(golden_dir, "nets_tiny.npz")
     usd, bsd = tiny_weights()

@@ -22,7 +22,7 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
-@pytest.mark.parametrize("tag", ["wide", "square"])
+@pytest.mark.parametrize("tag", ["wide", "square", "odd"])
 def test_blobnet_and_unet_modules_match_reference(golden_dir, tag):
     """Drop-in modules, called exactly like the reference modules (NCHW tensors, residual lists that get consumed)."""
     from blobctrl_amd.modules import BlobNetModel, UNet2DConditionModel
@@ -197,10 +197,11 @@ def test_captured_graph_follows_per_call_arguments():
         assert rel_err(out, ref) < 2e-2, (gs, cs, rel_err(out, ref))
 
 
-@pytest.mark.parametrize("h,w", [(8, 16), (16, 8), (24, 8)])
+@pytest.mark.parametrize("h,w", [(8, 16), (16, 8), (24, 8), (10, 12), (9, 7)])
 def test_non_square_edits_match_oracle(h, w):
     """Edits whose latent is not square (the CLI derives width / height from the image, inf:163-164): canvas h x 2w, including the
-    h == 2w case where the CANVAS is square and the UNet takes the `sample + r` branch (unet_2d_condition.py:1213-1217)."""
+    h == 2w case where the CANVAS is square and the UNet takes the `sample + r` branch (unet_2d_condition.py:1213-1217), and
+    sizes that are not multiples of 8 (odd feature maps down the pyramid: explicit-size upsampling, unet_2d_condition.py:1136-1147)."""
     from oracle import blob_splat, pipeline as o_pipe, schedulers as o_sched
     usd, bsd = tiny_weights()
     ucfg, bcfg = tiny_cfgs()

@@ -126,7 +126,8 @@ def golden_nets():
     unet, blob = build_tiny()
     c = TINY
     out = {}
-    for tag, (h, w) in (("wide", (8, 16)), ("square", (8, 8))):
+    # "odd": canvas 10 x 24 (latent 10 x 12) - feature maps 10x24 -> 5x12 -> 3x6 -> 2x3: the explicit-size upsampling branch
+    for tag, (h, w) in (("wide", (8, 16)), ("square", (8, 8)), ("odd", (10, 24))):
         B = 2
         x_b = g(11, B, 4 + 1 + c["feat"], h, w)
         t = torch.tensor(981)
