@@ -264,6 +264,13 @@ class StableDiffusionBlobNetPipeline:
             bg_image_latents = self.encode_latents(bg_image)
         self.check_inputs(blobnet_conditioning_scale, blobnet_control_guidance_start, blobnet_control_guidance_end,
                           num_inference_steps)
+        # pipe:494-497: guidance_scale <= 1 switches classifier-free guidance OFF in the reference (prompt_embeds then holds the
+        # positive prompt only and the UNet output is used as is).  The engine keeps its CFG-batch-2 plan: the positive embeddings
+        # fill both halves and the effective scale is 1, eps_u + 1 * (eps_c - eps_u) = eps_c.
+        if guidance_scale <= 1.0:
+            if latents is not None and prompt_embeds.shape[0] == latents.shape[0]:
+                prompt_embeds = torch.cat([prompt_embeds, prompt_embeds], 0)
+            guidance_scale = 1.0
         B2, T, Dc = prompt_embeds.shape
         if B2 % 2:
             raise ValueError("prompt_embeds must hold the negative and positive halves (classifier-free guidance)")

@@ -215,3 +215,22 @@ def test_non_square_edits_match_oracle(h, w):
                               score.float(), a["dino"], 3.0).numpy()
     assert out.shape == (1, 4, h, w)
     assert rel_err(out, ref) < 2e-2 and psnr(out, ref) > 38.0, f"{h}x{w}: rel {rel_err(out, ref):.3e} psnr {psnr(out, ref):.1f}"
+
+
+def test_guidance_scale_at_most_one_disables_cfg():
+    """pipe:494-497, 1096-1098: with guidance_scale <= 1 the reference runs without classifier-free guidance (noise_pred = the
+    conditional prediction).  Same result here, with either [2B] (negative ignored) or [B] (positive only) prompt embeddings."""
+    from oracle import pipeline as o_pipe, schedulers as o_sched
+    usd, bsd = tiny_weights()
+    ucfg, bcfg = tiny_cfgs()
+    pipe = make_pipeline(usd, bsd, scheduler="ddim")
+    a = _loop_inputs()
+    kw = dict(num_inference_steps=2, latents=a["latents"])
+    one = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], guidance_scale=1.0, **kw).cpu().numpy()
+    half = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], guidance_scale=0.5, **kw).cpu().numpy()
+    pos_only = pipe(a["prompt"][1:2], a["fg"], a["bg"], a["score"], a["dino"], guidance_scale=0.5, **kw).cpu().numpy()
+    assert np.array_equal(one, half)
+    assert rel_err(pos_only, one) < 1e-3           # (same arithmetic; the uncond half of the batch holds other data)
+    ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 2, a["latents"], a["prompt"], a["fg"], a["bg"],
+                              a["score"].float(), a["dino"], 1.0).numpy()
+    assert rel_err(one, ref) < 2e-2 and psnr(one, ref) > 38.0
