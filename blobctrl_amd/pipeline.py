@@ -242,12 +242,17 @@ class StableDiffusionBlobNetPipeline:
                  blobnet_control_guidance_start: float = 0.0, blobnet_control_guidance_end: float = 1.0,
                  output_type: str = "latent", callback_on_step_end=None, trace: Optional[list] = None,
                  teacher_latents: Optional[List[torch.Tensor]] = None, fg_image: Optional[torch.Tensor] = None,
-                 bg_image: Optional[torch.Tensor] = None):
+                 bg_image: Optional[torch.Tensor] = None, return_sample: bool = False, eta: float = 0.0):
         """prompt_embeds [2B, T, D] = cat(negative, positive) (pipe:937-949); fg/bg_image_latents [1,4,h,w] already scaled
         by 0.18215 (pipe:300-309); gs_score [1,2,h,w] = (bg, fg) scores (pipe:974); dino_feats [1,1,F] (pipe:982).
         Instead of the latents, `fg_image` / `bg_image` [1,3,8h,8w] in [-1,1] may be given when the pipeline has a VAE.
         Returns the final latents [B,4,h,w] fp32 for `output_type="latent"` (pipe:1143), else the decoded, denormalised
         images ("pt" / "np", pipe:1132-1146)."""
+        if return_sample:
+            # pipe:1052-1061 reads blobnet.conv_norm_out / conv_out, which BlobNetModel does not have (626-tensor schema): dead code
+            raise NotImplementedError("return_sample=True is not supported (the reference path dereferences layers BlobNet lacks)")
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 (stochastic DDIM) is not supported: the scheduler tables are the eta = 0 update")
         if output_type not in ("latent", "pt", "np"):
             raise ValueError(f"output_type must be 'latent', 'pt' or 'np', got {output_type!r}")
         if output_type != "latent" and self.vae is None:
@@ -345,7 +350,10 @@ class StableDiffusionBlobNetPipeline:
                 trace.append((P.eps_guided.clone(), P.latents.clone()))
             if callback_on_step_end is not None:
                 self.stream.synchronize()
-                callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
+                ret = callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
+                if isinstance(ret, dict) and ret.get("latents") is not None and ret["latents"] is not P.latents:
+                    with torch.cuda.stream(self.stream):                         # pipe:1112 `latents = callback_outputs.pop(...)`
+                        P.latents.copy_(ret["latents"].to(dev, torch.float32))
         torch.cuda.synchronize(self.device)
         out = P.latents.clone()
         return out if output_type == "latent" else self.decode_latents(out, output_type)

@@ -137,6 +137,20 @@ def test_pipeline_argument_errors():
         pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, output_type="pt")
     with pytest.raises(ValueError):
         pipe(a["prompt"], None, a["bg"], a["score"], a["dino"], num_inference_steps=2)
+    with pytest.raises(NotImplementedError):
+        pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, return_sample=True)
+    with pytest.raises(NotImplementedError):
+        pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, eta=0.5)
+    # a step-end callback may replace the latents (pipe:1112): zeroing them after step 0 changes the result
+    base = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, latents=a["latents"])
+    seen = []
+
+    def cb(p_, i, t, kw):
+        seen.append((i, t))
+        return {"latents": torch.zeros_like(kw["latents"])} if i == 0 else {}
+    alt = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=2, latents=a["latents"],
+               callback_on_step_end=cb)
+    assert [i for i, _ in seen] == [0, 1] and not torch.equal(base, alt)
 
 
 def test_remove_edit_skips_blobnet():
