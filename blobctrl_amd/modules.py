@@ -62,6 +62,14 @@ class BlobNetModel(_TrunkModule):
         assert config.is_blobnet
         super().__init__(state_dict, config, device)
 
+    @classmethod
+    def from_pretrained(cls, path, device="cuda:0", **_ignored):
+        """`BlobNetModel.from_pretrained(blobnet_path, ignore_mismatched_sizes=True)` (inf:252): a directory with
+        config.json + diffusion_pytorch_model.safetensors, or the .safetensors file itself."""
+        from .checkpoint import load_blobnet
+        sd, cfg = load_blobnet(path)
+        return cls(sd, cfg, device)
+
     def _plan(self, B, H, W):
         key = (B, H, W)
         if key not in self._plans:
@@ -108,6 +116,16 @@ class UNet2DConditionModel(_TrunkModule):
     def __init__(self, state_dict, config: TrunkConfig, device="cuda:0"):
         assert not config.is_blobnet
         super().__init__(state_dict, config, device)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, extra_in_channels=1, lora_path=None, lora_scale=1.0, device="cuda:0", **_ignored):
+        """`UNet2DConditionModel.from_pretrained(sd15_path, subfolder="unet")` + the conv_in 4 -> 5 surgery (inf:229-249) +
+        `load_lora_weights(unet_lora_path)` (inf:270-273) in one step: the packed weights are immutable, so the surgery and the
+        LoRA merge happen before packing (`extra_in_channels=0` / `lora_path=None` skip them)."""
+        import os
+        from .checkpoint import load_unet
+        sd, cfg = load_unet(os.path.join(path, subfolder) if subfolder else path, extra_in_channels, lora_path, lora_scale)
+        return cls(sd, cfg, device)
 
     def _res_shapes(self, H, W):
         boc = self.config.block_out_channels

@@ -248,3 +248,46 @@ def test_guidance_scale_at_most_one_disables_cfg():
     ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 2, a["latents"], a["prompt"], a["fg"], a["bg"],
                               a["score"].float(), a["dino"], 1.0).numpy()
     assert rel_err(one, ref) < 2e-2 and psnr(one, ref) > 38.0
+
+
+def test_modules_from_pretrained_round_trip(tmp_path):
+    """Checkpoints on disk (safetensors + config.json, 4-channel UNet conv_in + LoRA file) -> from_pretrained -> same outputs as
+    modules built from the equivalent in-memory state dicts (surgery + merged LoRA)."""
+    import json
+    from blobctrl_amd import checkpoint as ck, synth
+    from blobctrl_amd.modules import BlobNetModel, UNet2DConditionModel
+    from blobctrl_amd.weights import merge_lora
+    c = TINY
+    base = synth.synth_state_dict(synth.trunk_param_shapes(4, c["boc"], 2, c["ctx"], 4, blobnet=False), 5)
+    ud = tmp_path / "sd15" / "unet"
+    ud.mkdir(parents=True)
+    ck.write_safetensors(str(ud / "diffusion_pytorch_model.safetensors"), base)
+    json.dump({"block_out_channels": list(c["boc"]), "attention_head_dim": c["heads"], "norm_num_groups": c["groups"],
+               "cross_attention_dim": c["ctx"], "in_channels": 4}, open(ud / "config.json", "w"))
+    wq = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    lora = {f"unet.{wq}.lora_A.weight": g(1, 4, c["boc"][0]) * 0.2, f"unet.{wq}.lora_B.weight": g(2, c["boc"][0], 4) * 0.2,
+            "unet.conv_in.lora_A.weight": g(3, 4, 5, 3, 3) * 0.2, "unet.conv_in.lora_B.weight": g(4, c["boc"][0], 4, 1, 1) * 0.2}
+    ld = tmp_path / "unet_lora"
+    ld.mkdir()
+    ck.write_safetensors(str(ld / "pytorch_lora_weights.safetensors"), lora)
+    unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "sd15"), subfolder="unet", lora_path=str(ld))
+    assert unet.config.in_channels == 5
+    sd5 = ck.expand_conv_in(base, 1)
+    sd5 = merge_lora(sd5, {k[len("unet."):]: v for k, v in lora.items()})
+    ucfg, bcfg = tiny_trunk_configs()
+    ref_unet = UNet2DConditionModel(sd5, ucfg)
+    x, ehs, t = g(5, 2, 5, 8, 16).cuda(), g(6, 2, 7, c["ctx"]).cuda(), torch.tensor(500)
+    a = unet(x, t, encoder_hidden_states=ehs, return_dict=False)[0]
+    b = ref_unet(x, t, encoder_hidden_states=ehs, return_dict=False)[0]
+    assert torch.equal(a, b)
+    _, bsd = tiny_weights()
+    bd = tmp_path / "blobnet"
+    bd.mkdir()
+    ck.write_safetensors(str(bd / "diffusion_pytorch_model.safetensors"), bsd)
+    json.dump({"block_out_channels": list(c["boc"]), "attention_head_dim": c["heads"], "norm_num_groups": c["groups"],
+               "in_channels": 4, "conditioning_channels": 1 + c["feat"]}, open(bd / "config.json", "w"))
+    blob = BlobNetModel.from_pretrained(str(bd), ignore_mismatched_sizes=True)
+    xb = g(7, 1, 5 + c["feat"], 8, 16).cuda()
+    d1, m1, u1 = blob(xb, t, conditioning_scale=0.7, return_dict=False)
+    d2, m2, u2 = BlobNetModel(bsd, bcfg)(xb, t, conditioning_scale=0.7, return_dict=False)
+    assert torch.equal(m1, m2) and all(torch.equal(p, q) for p, q in zip(d1 + u1, d2 + u2))
