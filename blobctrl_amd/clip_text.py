@@ -48,6 +48,16 @@ class CLIPTextModel:
         self.h, self.f = h, f
         self._plans = {}
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, device="cuda:0", **_ignored):
+        """`CLIPTextModel.from_pretrained(sd15_path, subfolder="text_encoder")`: config.json + model.safetensors."""
+        import os
+        from .checkpoint import _config, _model_file, read_safetensors
+        d = os.path.join(path, subfolder) if subfolder else path
+        cfg = _config(d)
+        return cls(read_safetensors(_model_file(d)), num_heads=cfg.get("num_attention_heads", 12),
+                   eps=cfg.get("layer_norm_eps", 1e-5), device=device)
+
     def _plan(self, B, T):
         key = (B, T)
         if key in self._plans:

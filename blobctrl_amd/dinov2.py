@@ -54,6 +54,14 @@ class Dinov2Model:
         self.h, self.f = h, f
         self._plans = {}
 
+    @classmethod
+    def from_pretrained(cls, path, device="cuda:0", **_ignored):
+        """`Dinov2Model.from_pretrained(dinov2_path)` (inf:257): config.json + model.safetensors."""
+        from .checkpoint import _config, _model_file, read_safetensors
+        cfg = _config(path)
+        return cls(read_safetensors(_model_file(path)), num_heads=cfg.get("num_attention_heads", 16),
+                   patch_size=cfg.get("patch_size", 14), eps=cfg.get("layer_norm_eps", 1e-6), device=device)
+
     def _pos(self, gh, gw):
         pos = self.sd["embeddings.position_embeddings"]
         n = pos.shape[1] - 1

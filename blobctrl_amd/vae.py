@@ -80,6 +80,18 @@ class AutoencoderKL:
             self.f[a + "to_qk.bias"] = torch.cat([sd[a + "to_q.bias"], sd[a + "to_k.bias"]], 0).to(dev)
         self._plans = {}
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, device="cuda:0", **_ignored):
+        """`AutoencoderKL.from_pretrained(sd15_path, subfolder="vae")`: config.json + diffusion_pytorch_model.safetensors."""
+        import os
+        from .checkpoint import _config, _model_file, read_safetensors
+        d = os.path.join(path, subfolder) if subfolder else path
+        cfg = _config(d)
+        vae = cls(read_safetensors(_model_file(d)), norm_num_groups=cfg.get("norm_num_groups", 32),
+                  layers_per_block=cfg.get("layers_per_block", 2), device=device)
+        vae.config.scaling_factor = cfg.get("scaling_factor", 0.18215)
+        return vae
+
     # ------------------------------------------------------------------------------------------------ recorded blocks
     def _conv(self, rec, B, x: _Act, name, Cout, stride=1, up=False, nopad_lo=False, R=None, want_gn=True, out_f32=False):
         Hv, Wv = (2 * x.H, 2 * x.W) if up else (x.H, x.W)
