@@ -383,27 +383,15 @@ int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int
     return 0;
 }
 
-int attn_qb_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("BC_ATTN_QB");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 template <int D>
 int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int heads, int Nq, int Nkv, int ldq, int ldk,
                 int ldvt, int ldo, long long qbs, long long kbs, long long vbs, long long obs, float scale,
                 int causal, hipStream_t stream) {
     // Measured on MI355X: splitting short sequences over more, smaller workgroups (NW = 2 / 1) is SLOWER (every workgroup
     // re-stages the whole K / V with fewer threads: D=160, N=512: 18 vs 35 TFLOP/s), so the 4-wave form is always used.
-    // Two query blocks per wave (QB = 2, BC_ATTN_QB=2) halve the LDS fragment traffic but cost occupancy; with the LDS-DMA
-    // pipeline QB = 1 is faster at every shape of the loop (d=40 N=8192: 613 vs 556 TFLOP/s), so it is the default.
-    if constexpr (D <= 64) {
-        if (attn_qb_override() == 2)
-            return launch_attn_nw<D, 4, 2>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
-    }
+    // A second query block per wave (template parameter QB = 2: K / V fragments read once for 64 queries) was measured slower
+    // than QB = 1 at every shape of the loop once the tiles arrive by LDS-DMA (d=40 N=8192: 556 vs 613 TFLOP/s; it costs
+    // occupancy), so only QB = 1 is instantiated.
     if constexpr (D <= 40) {
         // enough workgroups for 4 per CU and a long key loop: take the 128-VGPR build (4 waves per SIMD)
         const long long wgs = (long long)bc_ceil_div(Nq, QW * 4) * heads * B;

@@ -52,7 +52,7 @@ def main():
         alt.bc_attention.restype = C.c_int
         alt.bc_last_error.restype = C.c_char_p
         lib = alt
-    print("lib =", sys.argv[1] if len(sys.argv) > 1 else "default", " BC_ATTN_QB =", os.environ.get("BC_ATTN_QB"))
+    print("lib =", sys.argv[1] if len(sys.argv) > 1 else "default")
     if os.environ.get("ATT_ONLY40"):
         run(lib, 2, 8, 40, 8192, 8192, check=False)
         run(lib, 4, 8, 40, 9216 * 2, 9216 * 2, iters=5, check=False)
