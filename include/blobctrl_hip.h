@@ -129,7 +129,9 @@ int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2
  * as GEMM (QK^T) -> softmax -> GEMM (PV)  (attention_processor.py:2216 with heads = 1). */
 int bc_softmax_rows(bc_half* x, int rows, int cols, int ld, bc_stream stream);
 
-/* CLIP text embeddings: out[b][t][:] = tok_emb[ids[b][t]][:] + pos_emb[t][:]  (ids int64, clamped to the vocabulary). */
+/* CLIP text embeddings (first stage of `self.text_encoder(text_input_ids)`, pipeline_blobnet.py:599; transformers
+ * models/clip/modeling_clip.py CLIPTextEmbeddings): out[b][t][:] = tok_emb[ids[b][t]][:] + pos_emb[t][:]  (ids int64, clamped to the
+ * vocabulary). */
 int bc_embed_tokens(const long long* ids, const bc_half* tok_emb, const float* pos_emb, int B, int T, int D, int vocab,
                     bc_half* out, bc_stream stream);
 
