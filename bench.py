@@ -126,10 +126,9 @@ def pmc_traffic(kernel_label):
         return None
     with open(files[-1]) as f:
         rows = json.load(f)["kernels"]
-    for r in rows:
-        if f"attn_fwd_kernelILi{m.group(1)}E" in r["kernel"]:
-            return r["hbm_bytes_per_launch_corrected"]
-    return None
+    hit = [r for r in rows if f"attn_fwd_kernelILi{m.group(1)}E" in r["kernel"]]      # (all builds of this head_dim)
+    n = sum(r["launches"] for r in hit)
+    return int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in hit) / n) if n else None
 
 
 def roofline(pipe, plan):
