@@ -137,3 +137,26 @@ def test_plan_cache_is_bounded():
         assert len(pipe._plans) <= 2
     again = pipe(*args, num_inference_steps=2, latents=g(81, 1, 4, 8, 8)).cpu()      # re-planned after eviction: same bits
     assert torch.equal(first, again)
+
+
+def test_build_edit_inputs_per_operation():
+    """what each edit operation hands to the pipeline (bg painting, score, strength)."""
+    from blobctrl_amd import blob_edit as be
+    rng = np.random.Generator(np.random.PCG64(1))
+    img = rng.integers(1, 255, size=(64, 64, 3)).astype(np.uint8)
+    start, target = ((20.0, 22.0), (16.0, 10.0), 10.0), ((44.0, 40.0), (18.0, 12.0), 60.0)
+    bg, score, s = be.build_edit_inputs("move", img, start, target, strength=1.2)
+    assert bg.shape == (64, 64, 3) and score.shape == (1, 2, 8, 8) and s == 1.2
+    assert tuple(bg[22, 20]) == (255, 255, 255) and tuple(bg[40, 44]) == (0, 0, 0)           # start painted white, target black
+    untouched = (be.ellipse_mask(start, 64, 64) == 0) & (be.ellipse_mask(target, 64, 64) == 0)
+    assert np.array_equal(bg[untouched], img[untouched])
+    sc = score.cpu().numpy()
+    np.testing.assert_allclose(sc[0, 0] + sc[0, 1], 1.0, atol=1e-12)                       # bg + fg == 1 (ut:162-194)
+    assert sc[0, 1].argmax() == np.ravel_multi_index((5, 5), (8, 8))                       # the target blob's latent cell (40/8, 44/8)
+    bg_r, score_r, s_r = be.build_edit_inputs("remove", img, start)
+    assert s_r == 0.0 and float(score_r[:, 0].min()) == 1.0 and float(score_r[:, 1].max()) == 0.0
+    assert tuple(bg_r[22, 20]) == (255, 255, 255) and not (bg_r == 0).all(-1).any()
+    with pytest.raises(ValueError):
+        be.build_edit_inputs("move", img, start)
+    with pytest.raises(ValueError):
+        be.build_edit_inputs("paint", img, start, target)

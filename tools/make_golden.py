@@ -257,6 +257,76 @@ def golden_dinov2():
     print("dinov2: pooled std %.4f" % out["native_pooled"].std())
 
 
+def golden_blob_edit():
+    """Pure-geometry functions of scripts/blobctrl_app.py (the app itself needs gradio / cv2 / SAM and loads models at import, so
+    only the wanted function definitions are taken out of its source with `ast` and executed here; cv2.boundingRect is the one
+    OpenCV call among them and is replaced by its definition - min / max of the non-zero pixels)."""
+    import ast
+    from PIL import Image
+    src = open("/root/reference/scripts/blobctrl_app.py").read()
+    want = ["normalize_ellipse", "composite_mask_and_image", "is_point_in_ellipse", "calculate_ellipse_vertices", "move_ellipse",
+            "resize_blob_func", "rotate_blob_func", "get_object_region_from_mask"]
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(body) == len(want)
+
+    class _Gr:
+        warnings = []
+
+        @staticmethod
+        def Warning(msg):
+            _Gr.warnings.append(msg)
+
+    class _Cv2:
+        @staticmethod
+        def boundingRect(m):
+            ys, xs = np.nonzero(m)
+            return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+    ns = {"np": np, "Image": Image, "gr": _Gr, "cv2": _Cv2}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "blobctrl_app_subset", "exec"), ns)
+    rng = np.random.Generator(np.random.PCG64(17))
+    out = {"ellipses": [], "normalize": [], "vertices": [], "inside": [], "move": [], "resize": [], "rotate": []}
+    ells = [((256.0, 256.0), (120.0, 80.0), 30.0), ((361.1067, 367.8526), (85.4812, 103.6543), 87.3739),
+            ((40.0, 470.0), (300.0, 40.0), 135.0), ((256.0, 256.0), (1e-5, 1e-5), 0.0), ((100.0, 90.0), (60.0, 60.0), 179.0)]
+    for e in ells:
+        out["ellipses"].append([list(e[0]), list(e[1]), e[2]])
+        out["normalize"].append([float(v) for v in ns["normalize_ellipse"](e, 512, 384)])
+        out["vertices"].append(ns["calculate_ellipse_vertices"](e).tolist())
+        pts = rng.uniform(0, 512, size=(12, 2))
+        out["inside"].append([[float(p[0]), float(p[1]), bool(ns["is_point_in_ellipse"](p, e))] for p in pts])
+        tp = rng.uniform(0, 512, size=(3, 2)).tolist()
+        m = ns["move_ellipse"](e, tp)
+        out["move"].append({"points": tp, "out": [list(m[0]), list(m[1]), m[2]]})
+        for rt in (0, 1, 2):
+            for f in (1.0, 0.5, 1.7, 6.0, 0.05):
+                _Gr.warnings = []
+                r, rf = ns["resize_blob_func"](e, f, 512, 512, rt)
+                out["resize"].append({"ellipse": len(out["ellipses"]) - 1, "factor": f, "type": rt,
+                                      "out": [list(r[0]), list(r[1]), r[2]], "factor_out": float(rf),
+                                      "too_big": any("too big" in w for w in _Gr.warnings),
+                                      "too_small": any("too small" in w for w in _Gr.warnings)})
+        for deg in (0.0, 45.0, 170.0, -30.0):
+            r, _ = ns["rotate_blob_func"](e, deg)
+            out["rotate"].append({"ellipse": len(out["ellipses"]) - 1, "deg": deg, "out": [list(r[0]), list(r[1]), r[2]]})
+    img = rng.integers(0, 256, size=(24, 32, 3)).astype(np.uint8)
+    mask = np.zeros((24, 32), np.uint8)
+    mask[5:14, 9:21] = 255
+    mask[10:18, 15:25] = 128
+    mask3 = np.stack([mask, mask, np.zeros_like(mask)], -1)
+    comp = np.array(ns["composite_mask_and_image"](mask, img, masked_color=[255, 255, 255]))
+    comp3 = np.array(ns["composite_mask_and_image"](mask3, img, masked_color=[0, 0, 0]))
+    obj = np.array(ns["get_object_region_from_mask"](mask, img))
+    out["image"] = img.tolist()
+    out["mask"] = mask.tolist()
+    out["composite_white"] = comp.tolist()
+    out["composite_rgbmask_black"] = comp3.tolist()
+    out["object_region"] = obj.tolist()
+    with open(os.path.join(OUT, "blob_edit.json"), "w") as f:
+        json.dump(out, f)
+    print("blob edit:", len(out["resize"]), "resize cases,", sum(r["too_big"] for r in out["resize"]), "too big,",
+          sum(r["too_small"] for r in out["resize"]), "too small")
+
+
 def golden_clip_text():
     """CLIP text tower (transformers, third-party; call site pipe:599-611 incl. the clip_skip branch)."""
     from transformers import CLIPTextConfig, CLIPTextModel
@@ -358,6 +428,7 @@ def golden_lora_keys():
 if __name__ == "__main__":
     check_full_schema()
     golden_lora_keys()
+    golden_blob_edit()
     golden_clip_text()
     golden_vae()
     golden_splat()
