@@ -26,6 +26,7 @@ class BcGemm(C.Structure):
         ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("conv_nopad_lo", C.c_int),
         ("W", C.c_void_p), ("ldw", C.c_int),
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int), ("rows_per_batch", C.c_int),
+        ("rowvec_idx", C.c_void_p), ("rowvec_step", C.c_int),
         ("act", C.c_int), ("colscale", C.c_void_p), ("alpha", C.c_float),
         ("alpha_dev", C.c_void_p), ("alpha_idx", C.c_void_p), ("alpha_bstride", C.c_int),
         ("R", C.c_void_p), ("ldr", C.c_int),
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "bc_assemble_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_timestep_embedding_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "bc_cfg_scheduler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -78,13 +78,14 @@ __global__ void assemble_kernel(const float* __restrict__ latents, int Blat, con
 }
 
 // embeddings.py:27-78: [cos(t*f_k) | sin(t*f_k)], f_k = exp(-ln(10000) * k / half)
+// rows_per_step > 0: row r belongs to step r / rows_per_step of the table (all steps of an edit at once)
 __global__ void temb_kernel(const float* __restrict__ t_table, const int* __restrict__ t_idx, float t_value, int rows,
-                            int dim, h16* __restrict__ out) {
+                            int dim, int rows_per_step, h16* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * dim) return;
     const int r = i / dim, c = i - r * dim;
     const int halfd = dim / 2;
-    const float t = t_table ? t_table[t_idx ? *t_idx : 0] : t_value;
+    const float t = rows_per_step > 0 ? t_table[r / rows_per_step] : (t_table ? t_table[t_idx ? *t_idx : 0] : t_value);
     const int k = c < halfd ? c : c - halfd;
     const float freq = expf(-9.210340371976184f * (float)k / (float)halfd);
     const float a = t * freq;
@@ -270,7 +271,18 @@ extern "C" int bc_timestep_embedding(const float* t_table, const int* t_idx, flo
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BC_CHECK_ARG(out && rows > 0 && dim > 0 && dim % 2 == 0, "bc_timestep_embedding: bad args");
     hipLaunchKernelGGL(temb_kernel, dim3(bc_ceil_div(rows * dim, 256)), dim3(256), 0, stream, t_table, t_idx, t_value, rows,
-                       dim, reinterpret_cast<h16*>(out));
+                       dim, 0, reinterpret_cast<h16*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_timestep_embedding_table(const float* t_table, int nsteps, int rows_per_step, int dim, bc_half* out,
+                                           bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(t_table && out && nsteps > 0 && rows_per_step > 0 && dim > 0 && dim % 2 == 0, "bc_timestep_embedding_table: bad args");
+    const int rows = nsteps * rows_per_step;
+    hipLaunchKernelGGL(temb_kernel, dim3(bc_ceil_div(rows * dim, 256)), dim3(256), 0, stream, t_table, nullptr, 0.f, rows, dim,
+                       rows_per_step, reinterpret_cast<h16*>(out));
     BC_CHECK_LAUNCH();
     return 0;
 }

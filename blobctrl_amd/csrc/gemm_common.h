@@ -52,6 +52,10 @@ __device__ __forceinline__ float scalar_alpha(const BcGemm& p) {
     if (p.alpha_dev && p.alpha_bstride == 0) alpha *= p.alpha_dev[p.alpha_idx ? *p.alpha_idx : 0];
     return alpha;
 }
+// Row vector of this launch: a fixed pointer, or the block of the current denoise step inside a per-edit table.
+__device__ __forceinline__ const h16* rowvec_base(const BcGemm& p) {
+    return reinterpret_cast<const h16*>(p.rowvec) + (p.rowvec_idx ? (size_t)(*p.rowvec_idx) * p.rowvec_step : 0);
+}
 __device__ __forceinline__ float batch_alpha(const GemmArgs& g, int b) {
     const BcGemm& p = g.p;
     return p.alpha_dev[(p.alpha_idx ? *p.alpha_idx : 0) * p.alpha_bstride + b];
@@ -92,7 +96,7 @@ __device__ __forceinline__ float pre_act(const GemmArgs& g, float acc, int m, in
     if (p.bias) v += p.bias[ncol];
     if (p.rowvec) {
         int b = (int)fdiv((unsigned)m, g.div_rpb);
-        v += (float)reinterpret_cast<const h16*>(p.rowvec)[(size_t)b * p.ld_rowvec + ncol];
+        v += (float)rowvec_base(p)[(size_t)b * p.ld_rowvec + ncol];
     }
     return v;
 }
@@ -188,7 +192,7 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
         pix = m - b * (int)g.div_rpb.d;
     }
     if (p.rowvec) {
-        const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.rowvec) + (size_t)b * p.ld_rowvec + c.n_first);
+        const uint4 raw = bc_ld16(rowvec_base(p) + (size_t)b * p.ld_rowvec + c.n_first);
         const h16* rh = reinterpret_cast<const h16*>(&raw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];

@@ -81,6 +81,8 @@ class TrunkPlan:
         kw = {}
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], ld_rowvec=rowvec[1])
+            if len(rowvec) == 4:                       # per-edit table of all steps: (device step counter, elements per step)
+                kw.update(rowvec_idx=rowvec[2], rowvec_step=rowvec[3])
         if R is not None:
             kw.update(R=R.t, ldr=R.C)
         kw.update(self._r2(r2, Hout, Wout))
@@ -114,7 +116,7 @@ class TrunkPlan:
         Cin = x.C + (skip.C if skip is not None else 0)
         off, n = pw.temb_slices[p]
         assert n == Cout
-        rowvec = (self.tproj.data_ptr() + off * 2, pw.temb_total)
+        rowvec = (self.tproj.data_ptr() + off * 2, pw.temb_total) + getattr(self, "tproj_table", ())
         h = self.groupnorm(x, skip, p + "norm1", 1e-5, True)
         h = self.conv3x3(h, p + "conv1", Cout, rowvec=rowvec)
         h = self.groupnorm(h, None, p + "norm2", 1e-5, True)
@@ -210,6 +212,21 @@ class TrunkPlan:
         h = self.dense(sin, B, c0, "time_embedding.linear_1", te, act=_lib.ACT_SILU, kind="temb")
         h = self.dense(h, B, te, "time_embedding.linear_2", te, act=_lib.ACT_SILU, kind="temb")   # silu(emb)
         self.tproj = self.dense(h, B, te, "temb_all", pw.temb_total, kind="temb")
+
+    def record_time_table(self, t_table, nsteps, t_idx):
+        """The same three GEMMs over ALL steps of an edit at once (prologue): tproj [nsteps * B][temb_total]; the ResBlock
+        epilogues then pick the block of the current step through the device step counter (BcGemm.rowvec_idx), and no
+        time-embedding launch is left in the step."""
+        rec, pw, B = self.rec, self.pw, self.B
+        c0 = self.cfg.block_out_channels[0]
+        te = c0 * 4
+        rows = nsteps * B
+        sin = rec.empty(rows, c0)
+        rec.call("bc_timestep_embedding_table", _ptr(t_table), nsteps, B, c0, sin.data_ptr(), kind="temb", keep=(t_table, sin))
+        h = self.dense(sin, rows, c0, "time_embedding.linear_1", te, act=_lib.ACT_SILU, kind="temb")
+        h = self.dense(h, rows, te, "time_embedding.linear_2", te, act=_lib.ACT_SILU, kind="temb")
+        self.tproj = self.dense(h, rows, te, "temb_all", pw.temb_total, kind="temb")
+        self.tproj_table = (t_idx, B * pw.temb_total)
 
     # ------------------------------------------------------------------------------------------- forward
     def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,

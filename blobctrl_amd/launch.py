@@ -187,7 +187,7 @@ class Recorder:
         return c.value, s_.value, bm.value, bn.value
 
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
-             conv=None, bias=None, rowvec=None, ld_rowvec=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
+             conv=None, bias=None, rowvec=None, ld_rowvec=0, rowvec_idx=None, rowvec_step=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
@@ -210,6 +210,7 @@ class Recorder:
         g.bias = ptr(bias)
         g.rowvec = ptr(rowvec) if not isinstance(rowvec, int) else rowvec
         g.ld_rowvec, g.rows_per_batch = ld_rowvec, rows_per_batch
+        g.rowvec_idx, g.rowvec_step = ptr(rowvec_idx), rowvec_step
         g.act = act
         g.colscale = ptr(colscale)
         g.alpha = alpha

@@ -117,11 +117,17 @@ class StableDiffusionBlobNetPipeline:
         blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
         if P.collapse:
             blob.record_collapse(P.feat16)
+        # time-embedding path of every step, once per edit (read in the step through the device step counter)
+        temb_per_step = bool(os.environ.get("BC_TEMB_PER_STEP"))         # diagnostic: the four launches per net inside every step
+        if not temb_per_step:
+            unet_a.record_time_table(P.t_table, nsteps, P.step_idx)
+            blob.record_time_table(P.t_table, nsteps, P.step_idx)
 
         def record_unet(plan, residuals):
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, Bi, 0,
                      2 * B, h, w, unet_cin, 0, P.unet_in.data_ptr(), kind="assemble")
-            plan.record_time(P.t_table, P.step_idx)
+            if temb_per_step:
+                plan.record_time(P.t_table, P.step_idx)
             eps = plan.record_forward(P.unet_in, residuals)
             P.eps = eps
             g = P.guidance
@@ -148,7 +154,8 @@ class StableDiffusionBlobNetPipeline:
         else:
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
                      P.feat.data_ptr() if F > 0 else None, Bi, F, B, h, w, blob_cin, 0, P.blob_in.data_ptr(), kind="assemble")
-        blob.record_time(P.t_table, P.step_idx)
+        if temb_per_step:
+            blob.record_time(P.t_table, P.step_idx)
         residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx, B if per_request else 0),
                                         signal_residuals=True)
         rec.sid = 0
@@ -160,6 +167,8 @@ class StableDiffusionBlobNetPipeline:
         P.step_inactive = rec.begin("step_inactive")
         unet_i = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
         unet_i.ctx_kv = unet_a.ctx_kv
+        if not temb_per_step:
+            unet_i.tproj, unet_i.tproj_table = unet_a.tproj, unet_a.tproj_table
         record_unet(unet_i, None)
         P.eps_inactive = P.eps
         P.captured = False

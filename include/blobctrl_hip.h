@@ -67,6 +67,9 @@ typedef struct BcGemm {
     const bc_half* rowvec;   /* per-batch row vector [B][ld_rowvec] (time-embedding projection) or NULL */
     int ld_rowvec;
     int rows_per_batch;      /* H*W of the output (for rowvec / R2 / transposed-output indexing); 0 => M */
+    const int* rowvec_idx;   /* optional device step counter: the row vector is read at rowvec + *rowvec_idx * rowvec_step (a table
+                              * with one block of row vectors per denoise step, computed once per edit) */
+    int rowvec_step;         /* elements (bc_half) between the blocks of consecutive steps */
     int act;                 /* BC_ACT_* ; GEGLU: columns come in groups of 64 = 32 value | 32 gate, output has N/2 columns */
     const float*   colscale; /* [N] or NULL (DINOv2 LayerScale) */
     float alpha;             /* scalar multiplier (1.0f default) */
@@ -188,6 +191,9 @@ int bc_assemble_input(const float* latents, int Blat, const float* img_lat, cons
  * t = t_table[*t_idx] when t_table != NULL else t_value.  out [rows][dim] fp16. */
 int bc_timestep_embedding(const float* t_table, const int* t_idx, float t_value, int rows, int dim, bc_half* out,
                           bc_stream stream);
+/* The same for EVERY step of an edit at once: out [nsteps * rows_per_step][dim], row r uses t_table[r / rows_per_step].  With
+ * BcGemm.rowvec_idx the whole time-embedding path (embeddings.py:27-78, 576-588, resnet.py:343-350) then runs once per edit. */
+int bc_timestep_embedding_table(const float* t_table, int nsteps, int rows_per_step, int dim, bc_half* out, bc_stream stream);
 
 /* SiLU elementwise on fp16 (resnet.py:345 nonlinearity(temb)). */
 int bc_silu(const bc_half* x, bc_half* y, long long n, bc_stream stream);
