@@ -72,12 +72,13 @@ class TrunkPlan:
         return dict(R2=res_t, ldr2=res_t.shape[-1], r2_xmin=xmin, r2_bmod=self.res_bmod, out_w=W)
 
     def conv3x3(self, x: Act, wname, Cout, stride=1, up_to=None, rowvec=None, R=None, r2=None, out_f32=False,
-                kind="conv3x3"):
+                kind="conv3x3", out=None):
         rec, pw = self.rec, self.pw
         Hv, Wv = up_to if up_to is not None else (x.H, x.W)
         Hout, Wout = (Hv + 2 - 3) // stride + 1, (Wv + 2 - 3) // stride + 1
         M = self.B * Hout * Wout
-        out = rec.empty(self.B, Hout * Wout, Cout, dtype=torch.float32 if out_f32 else torch.float16)
+        if out is None:
+            out = rec.empty(self.B, Hout * Wout, Cout, dtype=torch.float32 if out_f32 else torch.float16)
         kw = {}
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], ld_rowvec=rowvec[1])
@@ -230,7 +231,7 @@ class TrunkPlan:
 
     # ------------------------------------------------------------------------------------------- forward
     def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,
-                       signal_residuals: bool = False):
+                       signal_residuals: bool = False, eps_out: Optional[torch.Tensor] = None):
         """x_in: [B, H*W, pad8(in_channels)] fp16.  UNet: returns eps fp32 [B, H*W, out_channels].
         BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx[, alpha_bstride]);
         alpha_bstride = B selects per-image scales alpha_dev[step * B + image] for a batch of independent requests)."""
@@ -323,7 +324,7 @@ class TrunkPlan:
                 feats_u.append(h)
         if not cfg.is_blobnet:
             n = self.groupnorm(h, None, "conv_norm_out", 1e-5, True)
-            eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out")
+            eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out", out=eps_out)
             return eps.t
         self.feat_shapes = ([(f.C, f.H, f.W) for f in feats_d], (feat_mid.C, feat_mid.H, feat_mid.W),
                             [(f.C, f.H, f.W) for f in feats_u])

@@ -47,20 +47,25 @@ class Segment:
         self.meta = []          # per call: dict(kind, flops, variant)
         self.sids = []          # per call: 0 = main stream, 1 = side stream
 
-    def run(self, stream: int, side: int = None):
-        """Replay on `stream`; launches recorded for the side stream go to `side` (default: same stream, i.e. serial)."""
+    @staticmethod
+    def _streams(stream, side, extra):
+        """Stream of every recorded stream id: 0 = `stream`, 1 = `side`, 2.. = `extra`; missing ones fall back to `stream`."""
+        return (stream, side if side is not None else stream) + tuple(e if e is not None else stream for e in extra) + (stream,) * 4
+
+    def run(self, stream: int, side: int = None, extra=()):
+        """Replay on `stream`; launches recorded for the side streams go to `side` / `extra` (default: same stream, i.e. serial)."""
         if self.graph is not None:
             _lib.check(_lib.load().bc_graph_launch(self.graph, stream), "bc_graph_launch")
             return
-        streams = (stream, side if side is not None else stream)
+        streams = self._streams(stream, side, extra)
         for fn, sid in zip(self.calls, self.sids):
             fn(streams[sid])
 
-    def capture(self, stream: int, side: int = None):
+    def capture(self, stream: int, side: int = None, extra=()):
         """Capture this segment into a hipGraph on `stream` (a non-default stream).  Side-stream work joins the capture
         through the recorded fork / signal / wait events and becomes parallel branches of the graph."""
         lib = _lib.load()
-        streams = (stream, side if side is not None else stream)
+        streams = self._streams(stream, side, extra)
         _lib.check(lib.bc_graph_begin(stream), "bc_graph_begin")
         try:
             for fn, sid in zip(self.calls, self.sids):
@@ -105,8 +110,8 @@ class Recorder:
         self.device = device
         self.seg: Optional[Segment] = None
         self.keep = []                      # keeps ctypes blocks / tensors alive
-        self._slab = [None, None]           # split-K scratch PER STREAM (the two branches run concurrently)
-        self._slab_elems = [0, 0]
+        self._slab = {}                     # split-K scratch PER STREAM id (the branches run concurrently)
+        self._slab_elems = {}
         info = (C.c_int * 4)()
         _lib.check(self.lib.bc_device_info(info), "bc_device_info")
         self.num_cu = info[0]
@@ -169,7 +174,7 @@ class Recorder:
         """Shared split-K scratch of the CURRENT stream: consumed by the reduce kernel that immediately follows on that
         stream, so one buffer per stream is enough."""
         sid = self.sid
-        if elems > self._slab_elems[sid]:
+        if elems > self._slab_elems.get(sid, 0):
             self._slab[sid] = torch.empty(elems, dtype=torch.float32, device=self.device)
             self._slab_elems[sid] = elems
 

@@ -45,7 +45,7 @@ def main():
         def run(seg):
             with torch.cuda.stream(pipe.stream):          # same stream as the replay: the counter must not run past the tables
                 P.step_idx.zero_()
-            seg.run(s, side)
+            seg.run(s, side, pipe._extra())
         print(f"one_stream={one_stream}: active step {timeit(lambda: run(P.step_active)):.3f} ms, "
               f"inactive (UNet only) {timeit(lambda: run(P.step_inactive)):.3f} ms; launches active "
               f"{len(P.step_active.calls)} inactive {len(P.step_inactive.calls)}", flush=True)
