@@ -124,13 +124,15 @@ class StableDiffusionBlobNetPipeline:
             unet_a.record_time_table(P.t_table, nsteps, P.step_idx)
             blob.record_time_table(P.t_table, nsteps, P.step_idx)
 
-        # CFG halves on two streams: for single edits (B = 1) only - larger batches fill the GPU with the batch-2B UNet
-        split_cfg = B == 1 and self.two_streams and not temb_per_step and not os.environ.get("BC_NO_SPLIT_CFG")
+        # CFG halves on two streams (opt-in, BC_SPLIT_CFG=1; single edits only - larger batches fill the GPU with the batch-2B UNet)
+        split_cfg = B == 1 and self.two_streams and not temb_per_step and bool(os.environ.get("BC_SPLIT_CFG"))
         P.split_cfg = split_cfg
         if split_cfg:
             # the uncond / cond halves of the UNet batch as two batch-B plans on their own streams (ids 0 and 2): more concurrent
             # kernels for a GPU that one batch-2 UNet does not fill, at the price of reading the UNet weights twice per step
-            # (measured, same box, interleaved: 11.56 vs 11.73 ms per active step; 1108 instead of 725 launches)
+            # (measured, same box, interleaved: 11.56 vs 11.73 ms per active step, +2-3 % edits/s; 1108 instead of 725 launches.
+            #  Not the default: it trades per-kernel efficiency - every self-attention then runs at batch 1, the 64x64-tile GEMM
+            #  becomes the largest kernel of the step - for concurrency, a gain inside the box-to-box spread)
             half_time = TrunkPlan(rec, self.unet_w, self.unet_cfg, B, H, W)
             half_time.record_time_table(P.t_table, nsteps, P.step_idx)
             P.eps_all = rec.zeros(2 * B, H * W, self.unet_cfg.out_channels, dtype=f32)
