@@ -308,6 +308,27 @@ def test_attention(rec, B, heads, d, Nq, Nkv):
     close(out, ref, rtol=2e-3, atol=3e-3, what=f"attention d={d} Nq={Nq} Nkv={Nkv}")
 
 
+def test_attention_large_ragged_uses_128_vgpr_build(rec):
+    """B=2, 8 heads, d=40, 8450 tokens (a 65 x 130 canvas): the grid is large enough for the 128-VGPR (4 waves per SIMD) build, and
+    8450 % 64 != 0 sends its last tile through the masked tail - the path where that build keeps its few register spills."""
+    B, heads, d, N = 2, 8, 40, 8450
+    Cc = heads * d
+    q, k, v = (g(s_, B, N, Cc).half().cuda() for s_ in (1, 2, 3))
+    ldvt = (N + 63) // 64 * 64
+    vt = torch.zeros(B, Cc, ldvt, dtype=torch.float16, device="cuda")
+    vt[:, :, :N] = v.transpose(1, 2)
+    out = run(rec, lambda: rec.attention(q, k, vt, rec.empty(B, N, Cc), B, heads, d, N, N, Cc, Cc, ldvt, Cc,
+                                         N * Cc, N * Cc, Cc * ldvt, N * Cc, d ** -0.5))
+    worst = 0.0
+    for b in range(B):                                   # fp32 reference on the GPU, one (batch, head) at a time
+        for hh in range(heads):
+            sl = slice(hh * d, (hh + 1) * d)
+            qf, kf, vf = q[b, :, sl].float(), k[b, :, sl].float(), v[b, :, sl].float()
+            ref = torch.softmax(qf @ kf.t() * d ** -0.5, -1) @ vf
+            worst = max(worst, float((out[b, :, sl].float() - ref).abs().max()))
+    assert worst < 2e-3, f"max abs err {worst:.3e}"
+
+
 def test_attention_online_softmax_rescale(rec):
     """Force the running-max rescale: a late key tile carries a much larger score than the early ones."""
     B, heads, d, N = 1, 2, 40, 256
