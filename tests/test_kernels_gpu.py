@@ -110,6 +110,44 @@ def test_gemm_concat_sources(rec, C1, C2, N):
     close(out, ref, what="concat")
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", ["dense", "dense_sk3", "concat", "conv1", "conv2", "ups", "transposed"])
+def test_every_fast_tile_configuration(rec, cfg, mode):
+    """Each compiled (tile shape, stage count) x operand mode of the fast kernel on ragged M / N (300 x 200), a K loop shorter than
+    the deepest LDS ring (3 k-steps) and a 3-way split-K - the planner / tuner may pick any of them for a production shape."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv3x3
+    if mode in ("dense", "dense_sk3", "concat", "transposed"):
+        M, N, K = 300, 200, 640 if mode == "dense_sk3" else 192
+        A, W, b = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N)
+        ref = A.half().float() @ W.half().float().t() + b
+        if mode == "concat":
+            out = run(rec, lambda: rec.gemm(A=h(A[:, :128].contiguous()), A2=h(A[:, 128:].contiguous()), C1=128, lda=128, lda2=64,
+                                            W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), tile_cfg=cfg, splitk=1))
+        elif mode == "transposed":
+            out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.zeros(3, N, 104), bias=b.cuda(),
+                                            out_mode=_lib.OUT_F16_T, ldc=104, rows_per_batch=100, tile_cfg=cfg, splitk=1))
+            out, ref = out[:, :, :100], ref.view(3, 100, N).transpose(1, 2)
+        else:
+            out = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), tile_cfg=cfg,
+                                            splitk=3 if mode == "dense_sk3" else 1))
+        close(out, ref, what=f"{mode} cfg {cfg}")
+        return
+    B, Cc, Co, H, Wd = 2, 64, 72, 9, 11
+    x, w, b = g(1, B, Cc, H, Wd), g(2, Co, Cc, 3, 3) / math.sqrt(9 * Cc), g(3, Co)
+    if mode == "ups":
+        Hv, Wv, stride = 2 * H, 2 * Wd, 1
+        src = F.interpolate(x.half().float(), size=(Hv, Wv), mode="nearest")
+    else:
+        Hv, Wv, stride = H, Wd, 2 if mode == "conv2" else 1
+        src = x.half().float()
+    Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=B * Ho * Wo, N=Co, K=9 * Cc, out=rec.empty(B, Ho * Wo, Co),
+                                    bias=b.cuda(), conv=dict(Cin=Cc, Hin=H, Win=Wd, Hv=Hv, Wv=Wv, Hout=Ho, Wout=Wo, stride=stride),
+                                    tile_cfg=cfg, splitk=1))
+    close(from_nhwc(out, B, Ho, Wo), F.conv2d(src, w.half().float(), b, stride=stride, padding=1), what=f"{mode} cfg {cfg}")
+
+
 def test_gemm_transposed_and_f32_out(rec):
     from blobctrl_amd import _lib
     B, T, N, K = 2, 77, 80, 64
