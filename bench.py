@@ -51,18 +51,31 @@ def synth_inputs(h, w, T=77, ctx=768, feat=1024, batch=1):
                 blob=blob_dict_from_ellipse(ell, 8 * w, 8 * h))
 
 
-def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler):
-    """The CPU oracle (oracle/, kind 'port') timed on the host cores on a BOUNDED sample of the same workload:
-    the UNet half of one denoise step (CFG batch 2, with the BlobNet residual adds), plus the BlobNet half when the UNet
-    half took < 12 s; the step time is extrapolated by the executed-FLOP ratio otherwise."""
+def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
+    """The CPU oracle (oracle/, kind 'port') timed on the host cores: FULL denoise steps of the same workload as the reference
+    executes them (BlobNet AND UNet at CFG batch 2, fp32, pipe:1043-1090), one warm-up step, then the median of `timed_steps`
+    steps.  The thread count is chosen once by a sweep over {32, 64, 128, all} on a proxy (the first
+    ResBlock convolution shape); it is recorded in `cores`.  The 50-step edit and the C1 (20-step) edit are extrapolations of
+    the measured step time and are labelled as such."""
+    import statistics
     from oracle import blob_splat
-    from oracle.nets import NetConfig, blobnet_forward, unet_forward
-    from oracle.pipeline import construct_input
+    from oracle.nets import NetConfig
+    from oracle.pipeline import noise_pred_step
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))           # more threads than that only oversubscribe the ATen CPU conv kernels
+    sweep = {}
+    xs = torch.randn(2, 320, h, 2 * w)
+    ws = torch.randn(320, 320, 3, 3)
+    for nt in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
+        torch.set_num_threads(nt)
+        torch.nn.functional.conv2d(xs, ws, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.nn.functional.conv2d(xs, ws, padding=1)
+        sweep[nt] = (time.perf_counter() - t0) / 3
+    cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     ucfg = NetConfig(in_channels=5, cross_attention_dim=768)
     bcfg = NetConfig(in_channels=1029, cross_attention_dim=None)
@@ -72,66 +85,70 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler):
     fg, bg = inp["fg"].repeat(B2, 1, 1, 1), inp["bg"].repeat(B2, 1, 1, 1)
     bg_s, fg_s = score.unbind(dim=1)
     bg_s, fg_s = bg_s.unsqueeze(1).repeat(B2, 1, 1, 1), fg_s.unsqueeze(1).repeat(B2, 1, 1, 1)
-    lmi = torch.cat([inp["latents"]] * 2)
-    t = torch.tensor(999)
-    boc = (320, 640, 1280, 1280)
+    feats = torch.einsum("nmhw,nmc->nchw", fg_s, inp["dino"].repeat(B2, 1, 1)).contiguous()
+
+    def one_step(t):
+        """pipe:1031-1098: BlobNet on the CFG batch, right-square slices of its residuals into the UNet, crop + CFG."""
+        return noise_pred_step(usd, ucfg, bsd, bcfg, inp["latents"], t, inp["prompt"], fg, bg, fg_s, bg_s, feats, 1.0, 7.5)
+
+    times = []
     with torch.no_grad():
-        # zero residuals of the right shapes keep the UNet sample independent of the BlobNet half
-        shapes_d = [(boc[0], h, 2 * w)]
-        hh, ww = h, 2 * w
-        for i in range(4):
-            shapes_d += [(boc[i], hh, ww)] * 2
-            if i < 3:
-                hh, ww = hh // 2, ww // 2
-                shapes_d.append((boc[i], hh, ww))
-        mid = torch.zeros(B2, boc[-1], hh, hh)
-        down = [torch.zeros(B2, c, a, a) for (c, a, _) in shapes_d]
-        up = []
-        lv = [(h >> i) for i in range(4)]
-        rev = list(reversed(boc))
-        for i in range(4):
-            up += [torch.zeros(B2, rev[i], lv[3 - i], lv[3 - i])] * 3
-            if i < 3:
-                up.append(torch.zeros(B2, rev[i], lv[2 - i], lv[2 - i]))
-        unet_in = construct_input(lmi, bg_s, bg)
-        t0 = time.perf_counter()
-        unet_forward(usd, ucfg, unet_in, t, inp["prompt"], down, mid, up)
-        t_unet = time.perf_counter() - t0
-        if t_unet < 12.0:
-            feats = torch.einsum("nmhw,nmc->nchw", fg_s, inp["dino"].repeat(B2, 1, 1)).contiguous()
-            blob_in = construct_input(lmi, fg_s, fg, feats)
+        for i in range(1 + timed_steps):
             t0 = time.perf_counter()
-            blobnet_forward(bsd, bcfg, blob_in, t, 1.0)
-            t_step = t_unet + (time.perf_counter() - t0)
-            sample = f"1 of {steps} denoise steps (BlobNet + UNet at CFG batch 2 as the reference executes them, fp32, " \
-                     f"{8*h}x{8*w}) = {t_step:.2f} s on {cores} threads, extrapolated x{steps}"
-        else:
-            t_step = t_unet * (7459.6 / 3697.2)
-            sample = f"UNet half of 1 denoise step (CFG batch 2, fp32, {8*h}x{8*w}) = {t_unet:.2f} s on {cores} threads; step " \
-                     f"extrapolated by the executed-FLOP ratio 7459.6/3697.2, edit by x{steps}"
+            one_step(torch.tensor(999 - 20 * i))
+            times.append(time.perf_counter() - t0)
+    t_step = statistics.median(times[1:])
+    sample = (f"{timed_steps} full denoise steps after 1 warm-up step (BlobNet + UNet at CFG batch 2 as the reference executes "
+              f"them, fp32, {8*h}x{8*w}): median {t_step:.2f} s/step on {cores} threads (warm-up {times[0]:.2f} s; thread sweep on a "
+              f"conv proxy {{{', '.join(f'{k}: {v*1e3:.0f} ms' for k, v in sorted(sweep.items()))}}}); value = 1 / (s/step x {steps}) "
+              "is an EXTRAPOLATION of the measured step time to the whole edit (the scheduler update is negligible)")
     return dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
-                host_cpus_visible=avail), None
+                host_cpus_visible=avail, s_per_step=round(t_step, 3), step_times_s=[round(x, 3) for x in times],
+                c1_20step_edit_s_extrapolated=round(t_step * 20, 1), edit_s_extrapolated=round(t_step * steps, 1)), None
 
 
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE passes of this same command, gfx950 correction applied: see profiles/*pmc_hbm_traffic.json).  PMC
-    counters cannot be read from inside the timed process, so the number is only reported when the summary names the
-    same kernel; otherwise null."""
+def csrc_sha():
+    """Hash of the kernel sources: identifies the build a committed PMC summary was measured on."""
+    import hashlib
+    hsh = hashlib.sha1()
+    d = os.path.join(REPO, "blobctrl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            hsh.update(f.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:12]
+
+
+def pmc_traffic(kernel_label, res, batch):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the timed process: the figure comes
+    from the committed rocprofv3 summary of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE passes, gfx950 correction 2*FETCH + WRITE).  It is reported ONLY when that summary was taken on exactly these
+    kernel sources (csrc hash) at the headline shape; otherwise `traffic` is null and `traffic_source` says why."""
     import glob
     import re
-    m = re.match(r"attn_fwd_kernel<(\d+)>", kernel_label)
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")))
-    if not m or not files:
-        return None
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None, "no profiles/*pmc_hbm_traffic.json"
     with open(files[-1]) as f:
-        rows = json.load(f)["kernels"]
-    hit = [r for r in rows if f"attn_fwd_kernelILi{m.group(1)}E" in r["kernel"]]      # (all builds of this head_dim)
+        doc = json.load(f)
+    name = os.path.relpath(files[-1], REPO)
+    if (res, batch) != (512, 1):
+        return None, f"{name} was measured at 512x512 batch 1, this run is {res}x{res} batch {batch}"
+    if doc.get("csrc_sha") != csrc_sha():
+        return None, f"{name} was measured on kernel sources {doc.get('csrc_sha', '(unrecorded)')}, this run is {csrc_sha()}"
+    m = re.match(r"(\w+)<([\d, ]+)", kernel_label)
+    key = kernel_label.split("<")[0]
+    hit = [r for r in doc["kernels"] if key in r["kernel"]]
+    if key == "attn_fwd_kernel" and m:
+        hit = [r for r in hit if f"attn_fwd_kernelILi{m.group(2).split(',')[0].strip()}E" in r["kernel"] or
+               f"attn_fwd_kernel<{m.group(2).split(',')[0].strip()}," in r["kernel"]]
     n = sum(r["launches"] for r in hit)
-    return int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in hit) / n) if n else None
+    if not n:
+        return None, f"{name} has no row for {kernel_label}"
+    return int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in hit) / n), \
+        f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {doc['csrc_sha']}; 2*FETCH+WRITE)"
 
 
-def roofline(pipe, plan):
+def roofline(pipe, plan, res=512, batch=1):
     """HIP-event time every launch of one BlobNet-active step on the launch stream; report the dominant kernel."""
     s = pipe.stream.cuda_stream
     with torch.cuda.stream(pipe.stream):
@@ -193,11 +210,64 @@ def roofline(pipe, plan):
     table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                      gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
              for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
+    traffic, traffic_source = pmc_traffic(dom, res, batch)
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=pmc_traffic(dom), launches_per_step=a["n"],
+                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3), event_overhead_us=round(overhead_ms * 1e3, 2)), \
         dict(by_kernel=table, top_shapes=detail)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without torchrun: start N fresh worker processes (one per GPU, LOCAL_RANK = GPU index) from
+    this parent, which has made NO GPU call (never re-exec a process that touched the GPU), relay rank 0's JSON line, and
+    fail if any worker fails.  With fewer than N GPUs visible (a 1-GPU box) the workers share devices and use gloo, because
+    RCCL refuses two ranks on one device; BC_DIST_BACKEND overrides."""
+    import subprocess
+    ngpu = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if "BC_DIST_BACKEND" not in env and ngpu < n:
+        env["BC_DIST_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        sys.stderr.write(f"bench.py: worker exit codes {codes}\n")
+        sys.stdout.write(out0 or "")
+        sys.exit(1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+def stub_worker(args):
+    """BC_BENCH_STUB=1: the launcher / rendezvous / max-over-ranks plumbing without a GPU (CPU test of `--gpus N`)."""
+    from blobctrl_amd import dist as bdist
+    import torch.distributed as tdist
+    rank, world, local = bdist.init_from_env("gloo")
+    mine = bdist.shard_requests(args.requests, rank, world) if args.requests else list(range(args.steps))
+    dt = bdist.barrier_max_seconds(0.01 * (1 + rank))
+    total = args.requests if args.requests else world * args.steps
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": total / dt, "n_gpus": world, "steps": args.steps, "local_requests": len(mine),
+                          "gpus_arg": args.gpus}), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 def main():
@@ -212,7 +282,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
+    ap.add_argument("--requests", type=int, default=0,
+                    help="BASELINE configs[3]: this many independent edit requests in total, sharded round-robin over the ranks "
+                         "(dist.shard_requests) and run `--batch` at a time as per-request batches; 0 = `--steps` edits per rank")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])          # never returns
+    if os.environ.get("BC_BENCH_STUB"):
+        return stub_worker(args)
 
     from blobctrl_amd import dist as bdist
     from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
@@ -221,6 +299,9 @@ def main():
     import torch.distributed as tdist
 
     rank, world, local = bdist.init_from_env(os.environ.get("BC_DIST_BACKEND"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
+                         f"or let `python bench.py --gpus {args.gpus}` start the ranks itself (WORLD_SIZE unset)")
     dev = torch.device(f"cuda:{local % max(1, torch.cuda.device_count())}")   # (modulo: lets a 1-GPU box exercise N > 1 with gloo)
     torch.cuda.set_device(dev)
     ucfg, bcfg = full_configs()
@@ -249,38 +330,87 @@ def main():
                     guidance_scale=7.5, latents=lat, blobnet_conditioning_scale=1.0,
                     blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0)
 
-    for i in range(max(1, args.warmup)):
-        out = one_edit(i)
+    def request_batch(ids):
+        """BASELINE configs[2] / [3]: `ids` independent edit requests as ONE per-request batch (own fg / bg latents, ellipse,
+        DINO vector, prompt, noise; every 4th request is a `remove`: strength 0.0 and gs_score = (bg 1, fg 0), inf:175-188)."""
+        import numpy as np
+        from blobctrl_amd.splat import blob_dict_from_ellipse
+        gen = lambda seed, *shape: torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
+        fg, bg, sc, dino, lat, neg, pos, strength = [], [], [], [], [], [], [], []
+        for i in ids:
+            sx = (8 * w) / 512.0
+            ell = [[(200.0 + 23.0 * (i % 9)) * sx, (180.0 + 31.0 * (i % 7)) * sx], [(60.0 + 5.0 * (i % 11)) * sx, (90.0 + 3.0 * (i % 13)) * sx],
+                   float((17 * i) % 180)]
+            sco = splat_features(**blob_dict_from_ellipse(ell, 8 * w, 8 * h), score_size=(h, w), return_d_score=True, device=str(dev))
+            remove = i % 4 == 1
+            if remove:
+                sco = torch.stack([torch.ones_like(sco[:, 0]), torch.zeros_like(sco[:, 1])], 1)
+            sc.append(sco)
+            strength.append(0.0 if remove else 1.0)
+            fg.append(gen(10_000 + i, 1, 4, h, w) * 0.18215 * 5)
+            bg.append(gen(20_000 + i, 1, 4, h, w) * 0.18215 * 5)
+            dino.append(gen(30_000 + i, 1, 1, 1024))
+            lat.append(gen(40_000 + i, 1, 4, h, w))
+            neg.append(gen(50_000, 1, 77, 768))
+            pos.append(gen(60_000 + i, 1, 77, 768))
+        cat = lambda xs: torch.cat(xs, 0).to(dev)
+        return dict(prompt=cat(neg + pos), fg=cat(fg), bg=cat(bg), score=torch.cat(sc, 0), dino=cat(dino), latents=cat(lat),
+                    strength=strength)
+
+    def run_requests(rb):
+        return pipe(rb["prompt"], rb["fg"], rb["bg"], rb["score"], rb["dino"], num_inference_steps=args.denoise_steps,
+                    guidance_scale=7.5, latents=rb["latents"], blobnet_conditioning_scale=rb["strength"],
+                    blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0)
+
+    if args.requests:
+        mine = bdist.shard_requests(args.requests, rank, world)              # round-robin, no data-path collective
+        batches = [request_batch(mine[i:i + args.batch]) for i in range(0, len(mine), args.batch)]   # resident in HBM
+        for _ in range(max(1, args.warmup)):
+            out = run_requests(batches[0])
+    else:
+        for i in range(max(1, args.warmup)):
+            out = one_edit(i)
     assert torch.isfinite(out).all(), "non-finite latents"
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_edit(rank * 1000 + i + 1)
+    if args.requests:
+        for rb in batches:
+            run_requests(rb)
+    else:
+        for i in range(args.steps):
+            one_edit(rank * 1000 + i + 1)
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
     dt = bdist.barrier_max_seconds(time.perf_counter() - t0, dev)
+    weights_s = [round(t_weights, 2)]
+    if world > 1:
+        weights_s = [None] * world
+        tdist.all_gather_object(weights_s, round(t_weights, 2))
+    units = args.requests if args.requests else world * args.steps * args.batch
 
-    plan = pipe.plan_for(args.batch, h, w, 77, 768, args.denoise_steps)
+    plan = pipe.plan_for(args.batch, h, w, 77, 768, args.denoise_steps, per_request=bool(args.requests))
     line = {
-        "metric": "512x512_50step_blobctrl_edits_per_sec" if (args.res == 512 and args.batch == 1)
-        else f"{args.res}x{args.res}_batch{args.batch}_edits_per_sec",
-        "value": world * args.steps / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "512x512_50step_blobctrl_edits_per_sec" if args.res == 512
+        else f"{args.res}x{args.res}_{args.denoise_steps}step_blobctrl_edits_per_sec",
+        "value": units / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / (len(batches) if args.requests else args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{1 if (args.res == 512 and args.batch == 1) else (2 if args.res == 512 else 4)}]: "
+        "config": {"workload": f"BASELINE configs[{(3 if args.requests else 1 if args.batch == 1 else 2) if args.res == 512 else 4}]: "
                                f"{args.res}x{args.res} edit, batch {args.batch} (CFG batch {2 * args.batch} for the UNet, "
                                f"BlobNet shared across CFG halves), {args.denoise_steps} {args.scheduler.upper()} steps, "
                                "guidance window [0,1], fp16 activations / fp32 accumulate, LoRA pre-merged, hipGraph-replayed steps",
-                   "edits_per_rank": args.steps, "denoise_steps": args.denoise_steps,
-                   "denoise_step_ms": dt / args.steps / args.denoise_steps * 1e3,
-                   "algorithmic_tflop_per_edit": plan.step_active.flops * args.denoise_steps / 1e12,
-                   "weights_s": round(t_weights, 2)},
+                   "edits_per_rank": (len(mine) if args.requests else args.steps * args.batch), "denoise_steps": args.denoise_steps,
+                   "requests_total": args.requests or None, "per_request_batches": bool(args.requests),
+                   "denoise_step_ms": dt / (len(batches) if args.requests else args.steps) / args.denoise_steps * 1e3,
+                   "algorithmic_tflop_per_edit": plan.step_active.flops * args.denoise_steps / 1e12 / args.batch,
+                   "dist_backend": (tdist.get_backend() if world > 1 else None),
+                   "weights_s": weights_s},
     }
     if rank == 0 and not args.no_roofline:
-        rl, table = roofline(pipe, plan)
+        rl, table = roofline(pipe, plan, args.res, args.batch)
         line["roofline"] = rl
         if args.table:
             print(json.dumps(table, indent=1), file=sys.stderr)

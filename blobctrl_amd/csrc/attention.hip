@@ -371,12 +371,8 @@ int launch_attn_nw(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int
                    int causal, hipStream_t stream) {
     using C = AttnCfg<D>;
     dim3 grid(bc_ceil_div(Nq, QW * QB * NW), heads, B), block(64 * NW);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, NW, QB, WPE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};       // one bit per device ordinal
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&attn_fwd_kernel<D, NW, QB, WPE>), (int)C::LDS_BYTES));
     hipLaunchKernelGGL((attn_fwd_kernel<D, NW, QB, WPE>), grid, block, C::LDS_BYTES, stream, Q, K, Vt, O, Nq, Nkv, ldq, ldk, ldvt, ldo,
                        qbs, kbs, vbs, obs, scale * 1.4426950408889634f, causal);
     BC_CHECK_LAUNCH();

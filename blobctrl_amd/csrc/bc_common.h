@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
+#include <atomic>
 #include "../../include/blobctrl_hip.h"
 
 typedef _Float16 h16;
@@ -30,6 +31,19 @@ void bc_set_error(const char* fmt, ...);
     } while (0)
 
 #define BC_CHECK_LAUNCH() BC_CHECK_HIP(hipGetLastError())
+
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (the attribute belongs to the function on the current device).  One atomic
+// bit per device ordinal: thread-safe, and racing threads at worst set the same value twice.  Returns a hipError_t.
+static inline hipError_t bc_set_max_lds(std::atomic<unsigned long long>& done, const void* func, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 static inline int bc_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -306,12 +306,8 @@ int launch_fast(const GemmArgs& g, hipStream_t stream) {
     dim3 grid(bc_ceil_div(p.N, BN), bc_ceil_div(p.M, BM), p.splitk);
     dim3 block(64 * WM * WN);
     size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BN * (BM + 4) * 4);   // stages | epilogue tile (| transposed, padded)
-    static bool attr_set = false;
-    if (!attr_set) {
-        BC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};       // one bit per device ordinal
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>), (int)lds));
     hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, WN, NS, CONV, UPS>), grid, block, lds, stream, g);
     BC_CHECK_LAUNCH();
     return 0;

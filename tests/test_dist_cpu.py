@@ -67,3 +67,40 @@ def test_config_c4_partition_64_requests_over_8_ranks():
     parts = [bdist.shard_requests(64, r, 8) for r in range(8)]
     assert all(len(p) == 8 for p in parts)
     assert sorted(i for p in parts for i in p) == list(range(64))
+
+
+def _run_bench(args, env_extra=None, launcher=()):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BC_BENCH_STUB="1", **(env_extra or {}))
+    r = subprocess.run([sys.executable, *launcher, os.path.join(repo, "bench.py"), *args], env=env, capture_output=True, text=True,
+                       timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` (no torchrun) must run TWO ranks and print ONE line with n_gpus = 2; the
+    stub worker exercises the launcher, the rendezvous and the max-over-ranks reduction without a GPU."""
+    rc, line, err = _run_bench(["--gpus", "2", "--steps", "3"])
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["gpus_arg"] == 2 and line["local_requests"] == 3
+    assert abs(line["value"] - 2 * 3 / 0.02) < 1e-6                     # whole-job units / MAX over ranks (rank 1 reports 0.02 s)
+    rc, line, err = _run_bench(["--gpus", "2", "--requests", "7"])       # C4-style sharding: 7 requests -> 4 + 3
+    assert rc == 0 and line["local_requests"] == 4 and abs(line["value"] - 7 / 0.02) < 1e-6, err
+
+
+def test_bench_under_torchrun_uses_the_given_world():
+    port = _free_port()
+    rc, line, err = _run_bench(["--gpus", "2", "--steps", "2"],
+                               launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                         "127.0.0.1", "--master-port", str(port)))
+    assert rc == 0 and line["n_gpus"] == 2, err
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    rc, line, err = _run_bench(["--gpus", "2", "--steps", "1", "--scheduler", "not-a-scheduler"])
+    assert rc != 0

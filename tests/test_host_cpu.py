@@ -100,9 +100,10 @@ def test_scheduler_tables_reproduce_reference_trajectories(golden_dir, kind, n):
 
 def test_synth_weights_are_deterministic_and_schema_sized():
     sh = synth.trunk_param_shapes(5, (320, 640, 1280, 1280), 2, 768, 4, blobnet=False)
-    assert len(sh) == 686 and sum(int(np.prod(v)) for v in sh.values()) == 859_532_484 or True
+    # SD-1.5 UNet (859 520 964 parameters) + the 5th conv_in channel (320 * 9, inf:233-249); BlobNet: SURVEY Appendix B
+    assert len(sh) == 686 and sum(int(np.prod(v)) for v in sh.values()) == 859_520_964 + 320 * 9 == 859_523_844
     bs = synth.trunk_param_shapes(1029, (320, 640, 1280, 1280), 2, None, None, blobnet=True)
-    assert len(bs) == 626
+    assert len(bs) == 626 and sum(int(np.prod(v)) for v in bs.values()) == 845_019_520
     a = synth.synth_tensor("down_blocks.0.resnets.0.conv1.weight", (8, 4, 3, 3), 7)
     b = synth.synth_tensor("down_blocks.0.resnets.0.conv1.weight", (8, 4, 3, 3), 7)
     assert np.array_equal(a, b) and abs(float(a[0, 0, 0, 0]) - float(synth.synth_tensor("x", (8, 4, 3, 3), 7)[0, 0, 0, 0])) > 0

@@ -20,6 +20,17 @@ def agg(path_glob):
     return out
 
 
+def csrc_sha():
+    """Same hash as bench.py: identifies the kernel sources these counters were measured on."""
+    import hashlib
+    hsh = hashlib.sha1()
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blobctrl_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        with open(os.path.join(src, f), "rb") as fh:
+            hsh.update(f.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:12]
+
+
 def main():
     d = sys.argv[1]
     fetch, write, mfma = (agg(os.path.join(d, sub, "**", "*counter_collection.csv")) for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"))
@@ -35,7 +46,7 @@ def main():
                            "--no-cpu-baseline --no-roofline --denoise-steps 2",
                    correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports half of a wide coalesced read "
                               "stream; WRITE_SIZE exact; MI355X_MICROARCH.md section HBM)",
-                   kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
+                   csrc_sha=csrc_sha(), kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
     util = []
     for name, c in mfma.items():
         if "GRBM_GUI_ACTIVE" not in c:
@@ -51,7 +62,7 @@ def main():
                            "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --denoise-steps 2",
                    note="fractions of the launch's own GPU cycles (GRBM_GUI_ACTIVE/8): MFMA pipe busy over 1024 SIMDs, VALU issue port "
                         "(SQ_ACTIVE_INST_VALU counts 4-cycle quads), LDS array over 256 CUs; all launches of a kernel summed",
-                   kernels=util), open(os.path.join(d, "pmc_mfma_util.json"), "w"), indent=1)
+                   csrc_sha=csrc_sha(), kernels=util), open(os.path.join(d, "pmc_mfma_util.json"), "w"), indent=1)
     print("summaries:", os.listdir(d))
 
 
