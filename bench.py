@@ -112,7 +112,7 @@ def csrc_sha():
     import hashlib
     hsh = hashlib.sha1()
     d = os.path.join(REPO, "blobctrl_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))):
         with open(os.path.join(d, f), "rb") as fh:
             hsh.update(f.encode() + b"\0" + fh.read())
     return hsh.hexdigest()[:12]

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("BLOBCTRL_HIP_LIB") or os.path.join(_HERE, "libblobctr
 A_DENSE, A_CONV3X3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
-TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64"]
+TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160"]
+TILE_HALO = 8
 
 
 class BcGemm(C.Structure):
@@ -33,6 +34,7 @@ class BcGemm(C.Structure):
         ("R2", C.c_void_p), ("ldr2", C.c_int), ("r2_xmin", C.c_int), ("r2_bmod", C.c_int), ("out_w", C.c_int),
         ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
         ("splitk", C.c_int), ("slab", C.c_void_p), ("gn_part", C.c_void_p), ("tile_cfg", C.c_int),
+        ("a_affine", C.c_void_p), ("a_act", C.c_int),
     ]
 
 
@@ -44,6 +46,7 @@ _SIGNATURES = {
     "bc_sizeof_gemm": (C.c_int, []),
     "bc_gemm_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bc_conv_halo_eligible": (C.c_int, [C.c_int] * 8),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

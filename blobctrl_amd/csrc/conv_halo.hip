@@ -1,0 +1,378 @@
+// 3x3 / stride-1 / pad-1 convolution with an LDS-RESIDENT INPUT HALO TILE and the GroupNorm(+SiLU) of its input fused into the
+// staging path (gfx950, v_mfma_f32_16x16x32_f16).
+//
+// Replaces, for the ResBlock convolutions of the hot path (D/models/resnet.py:327-341 norm1 -> nonlinearity -> conv1 and
+// :351-366 norm2 -> nonlinearity -> conv2, with the torch.cat([h, skip], 1) of unet_2d_blocks.py:2559,2719 in front of norm1):
+// the separate GroupNorm-apply pass over the activation AND the implicit-GEMM kernel that re-gathered every input pixel nine times.
+//
+// Work decomposition
+//   workgroup = 8 x 16 output pixels (BM = 128 rows) x BN = 160 output channels, 8 waves.
+//   K loop    = input channels in chunks of 64; per chunk the (8+2) x (16+2) pixel halo of the input is brought into LDS ONCE
+//               (LDS-DMA of the raw fp16 rows, then a register pass  y = silu?(a[b][c] * x + b[b][c])  that writes the swizzled
+//               operand image; out-of-image pixels are written as zeros AFTER the activation = the convolution's zero padding)
+//               and serves all nine taps; only the weights stream per tap (LDS-DMA, 3-stage ring, counted vmcnt, raw s_barrier).
+//               LDS-DMA pieces per MFMA are ~0.45x the implicit-GEMM kernel's, and the 9x re-read of the input from L2 is gone.
+//   waves     = 2 (pixel halves) x 2 (channel halves) x 2 (K halves of every 64-channel chunk); wave tile 64 x 80 = 4 x 5 MFMA tiles,
+//               9 ds_read_b128 per 20 MFMAs; the two K halves are summed through LDS in the epilogue.
+//   split-K   = over channel chunks (grid.z), fp32 slabs + the shared reducer (gemm.hip), for the low-resolution levels.
+// Swizzle: 16-byte chunk c of a 128-byte operand row is stored at chunk c ^ (((r >> 1) & 3) << 1) with r = halo x (A image) or
+// weight row (B image): with the 16x16x32 fragment map (lane -> row l & 15, chunk l >> 4) every ds_read_b128 lane group then
+// touches 16 distinct 16-byte slots of the 256-byte bank row.
+#include <stdlib.h>
+#include <type_traits>
+#include "gemm_common.h"
+
+using namespace bcg;
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_line_h[4] = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+constexpr int TW = 16, TH = 8;
+constexpr int HBM = TW * TH;                    // 128 output pixels per workgroup
+constexpr int HBN = 160;                        // output channels per workgroup
+constexpr int HSTR = TW + 2;                    // halo row stride (pixels)
+constexpr int HPIX = (TH + 2) * HSTR;           // 180 halo pixels
+constexpr int HALO_BYTES = HPIX * 128;          // one 64-channel chunk of the halo (swizzled operand image)
+constexpr int RAW_PIECES = 24;                  // raw landing area: 24 x 1 KiB = 192 pixel slots
+constexpr int RAW_BYTES = RAW_PIECES * 1024;
+constexpr int B_PIECES = HBN / 8;               // 20 x 1 KiB per weight stage (one tap of one chunk)
+constexpr int STAGE_BYTES = HBN * 128;
+constexpr int MAX_CH = 40;                      // channel chunks per workgroup (the affine table of the chunk range lives in LDS)
+constexpr int OFF_HALO = 0;
+constexpr int OFF_RAW = 2 * HALO_BYTES;
+constexpr int OFF_B = OFF_RAW + RAW_BYTES;
+constexpr int OFF_AB = OFF_B + 3 * STAGE_BYTES;
+constexpr int LDS_TOTAL = OFF_AB + MAX_CH * 64 * 8;
+constexpr int TS = HBN + 4;                     // epilogue tile row stride (floats)
+constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
+static_assert(OFF_SCR + 24 * HBN * 2 * 4 <= LDS_TOTAL, "epilogue scratch does not fit");
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+template <int N>
+__device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void wait_vm(int n) {      // n is wave-uniform
+    switch (n) {
+        case 0: wait_vm_c<0>(); break;
+        case 2: wait_vm_c<2>(); break;
+        case 1: wait_vm_c<1>(); break;
+        case 3: wait_vm_c<3>(); break;
+        case 4: wait_vm_c<4>(); break;
+        case 5: wait_vm_c<5>(); break;
+        default: wait_vm_c<6>(); break;
+    }
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+template <bool AFFINE>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BcGemm& p = g.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave & 1, wm = (wave >> 1) & 1, wn = wave >> 2;
+
+    const int plane = gridDim.x * gridDim.y;
+    const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
+    const int lin = lin3 % plane;
+    const int split = lin3 / plane;
+    const int tile = lin / (int)gridDim.x;               // an XCD owns a contiguous band of pixel tiles, all their column tiles
+    const int n0 = (lin % (int)gridDim.x) * HBN;
+    const int b = tile / g.halo_tpi;
+    const int tin = tile - b * g.halo_tpi;
+    const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
+    const int H = p.Hin, W = p.Win;
+
+    const int c_begin = split * g.halo_cps;
+    const int nch = min(g.halo_nch, c_begin + g.halo_cps) - c_begin;
+    const int NT = nch * 9;
+
+    const h16* __restrict__ A1 = reinterpret_cast<const h16*>(p.A);
+    const h16* __restrict__ A2 = reinterpret_cast<const h16*>(p.A2);
+    const h16* __restrict__ Wt = reinterpret_cast<const h16*>(p.W);
+    const h16* zero = reinterpret_cast<const h16*>(g_zero_line_h);
+
+    // ---- this lane's three halo slots: the 16 bytes it brings in by LDS-DMA are the 16 bytes it later transforms ----
+    const int sub = tid & 7;                                  // 8-channel sub-chunk of the 64-channel chunk
+    int pix[3];                                               // input pixel index (b, gy, gx) or -1
+    int hdst[3];                                              // byte offset in the swizzled halo image, or -1 (slot beyond the halo)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int hp = (tid >> 3) + 64 * q;
+        const int hy = hp / HSTR, hx = hp - hy * HSTR;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool in_halo = hp < HPIX;
+        const bool in_img = in_halo && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        pix[q] = in_img ? (b * H + gy) * W + gx : -1;
+        hdst[q] = in_halo ? hp * 128 + ((sub ^ (((hx >> 1) & 3) << 1)) << 4) : -1;
+    }
+    // ---- weight pieces of this wave (1 KiB = 8 rows x 128 B; waves 0-3 carry three, waves 4-7 two) ----
+    const int LB = wave < 4 ? 3 : 2;
+    int woff[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = (wave + 8 * q) * 8 + (lane >> 3);
+        const int cs = (lane & 7) ^ (((n >> 1) & 3) << 1);
+        woff[q] = (n0 + n) * p.ldw + cs * 8;
+    }
+    // ---- fragment read offsets ----
+    int a_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int hx = (lane & 15) + kx;
+        const int ch = 4 * kg + (lane >> 4);
+        a_off[kx] = (wm * 4) * HSTR * 128 + hx * 128 + ((ch ^ (((hx >> 1) & 3) << 1)) << 4);
+    }
+    const int nl = wn * 80 + (lane & 15);
+    const int b_off = OFF_B + nl * 128 + (((4 * kg + (lane >> 4)) ^ (((nl >> 1) & 3) << 1)) << 4);
+
+    auto issue_a = [&](int cl) {                              // raw rows of chunk c_begin + cl -> landing area
+        const int k0 = (c_begin + cl) * 64;
+        const bool second = A2 != nullptr && k0 >= p.C1;      // wave-uniform (C1 % 64 == 0)
+        const h16* src = second ? A2 : A1;
+        const long long stride = second ? p.lda2 : p.lda;
+        const int kin = (second ? k0 - p.C1 : k0) + sub * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const h16* s = pix[q] >= 0 ? src + (long long)pix[q] * stride + kin : zero;
+            glds16(s, smem + OFF_RAW + (wave + 8 * q) * 1024);
+        }
+    };
+    auto issue_b = [&](int kt, int stage) {                   // weights of flattened (chunk, tap) index kt -> ring stage
+        const int cl = kt / 9, tap = kt - cl * 9;
+        const int koff = tap * p.Cin + (c_begin + cl) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < LB) glds16(Wt + woff[q] + koff, smem + OFF_B + stage * STAGE_BYTES + (wave + 8 * q) * 1024);
+    };
+    const unsigned raw_addr = (unsigned)(size_t)(lptr_t)(smem) + tid * 16;      // LDS byte address of this lane's slot 0 (minus OFF_RAW)
+    const unsigned ab_base = (unsigned)(size_t)(lptr_t)(smem) + OFF_AB + sub * 64;   // this lane's 8 (a, b) pairs inside a chunk
+    auto transform = [&](auto qc, int cl, char* dst_buf) {   // landing area -> operand image (chunk cl), this lane's slot q
+        constexpr int q = decltype(qc)::value;
+        if (hdst[q] < 0) return;
+        // Inline asm: hipcc otherwise puts `s_waitcnt vmcnt(0)` in front of a ds_read it cannot prove disjoint from the LDS-DMA
+        // writes in flight (it does not see the counted waits), which would drain the weight ring at every slice.  The lane's slot
+        // IS complete (see the wait accounting in the tap loop).
+        uint4 raw;
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(raw_addr), "n"(OFF_RAW + 8192 * q) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (AFFINE) {
+            const unsigned ab_addr = ab_base + cl * 512;            // (64 channels x (a, b) x 4 bytes per chunk)
+            float4 t0, t1, t2, t3;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                         "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ab_addr) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float aa[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z};
+            const float bb[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
+            const h16* xin = reinterpret_cast<const h16*>(&raw);
+            uint4 outraw;
+            h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = fmaf((float)xin[j], aa[j], bb[j]);
+                if (p.a_act == BC_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                o[j] = (h16)v;
+            }
+            if (pix[q] < 0) outraw = make_uint4(0u, 0u, 0u, 0u);      // zero padding is applied AFTER norm + activation
+            raw = outraw;
+        }
+        // (inline asm for the same reason as the reads: a plain LDS store is ordered behind every LDS-DMA in flight by hipcc)
+        const u32x4v rv = {raw.x, raw.y, raw.z, raw.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(lptr_t)(dst_buf) + (unsigned)hdst[q]), "v"(rv) : "memory");
+    };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+
+    // ---- prologue: affine table of this chunk range -> LDS, first halo chunk, first two weight stages ----
+    if (AFFINE) {
+        const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
+        float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
+        for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
+    }
+    issue_a(0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    wait_vm(2 * LB);                                          // my three halo slots have landed (weights may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // affine table visible
+    asm volatile("" ::: "memory");
+    transform(Q0{}, 0, smem + OFF_HALO);
+    transform(Q1{}, 0, smem + OFF_HALO);
+    transform(Q2{}, 0, smem + OFF_HALO);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    f32x4v acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    for (int cl = 0; cl < nch; ++cl) {
+        const bool has_next = cl + 1 < nch;
+        const char* hb = smem + OFF_HALO + (cl & 1) * HALO_BYTES;
+        char* hb_next = smem + OFF_HALO + ((cl + 1) & 1) * HALO_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kt = cl * 9 + tap;
+            // Counted wait: the weights of THIS tap must have landed; what may stay in flight is whatever this wave issued after
+            // them, in order: the next tap's stage, and (taps 1 and 2) the raw halo rows of the next chunk issued during tap 0.
+            int pend = (kt + 1 < NT) ? LB : 0;
+            if ((tap == 1 || tap == 2) && has_next) pend += 3;
+            wait_vm(pend);
+            __builtin_amdgcn_s_barrier();                     // stage `tap % 3` complete for every wave; stage (tap + 2) % 3 is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < NT) issue_b(kt + 2, (tap + 2) % 3);
+            if (tap == 0 && has_next) issue_a(cl + 1);        // (the landing area was consumed during the previous chunk)
+            const int ky = tap / 3, kx = tap - ky * 3;
+            h16x8 fa[4], fb[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *reinterpret_cast<const h16x8*>(hb + a_off[kx] + (i + ky) * HSTR * 128);
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + (tap % 3) * STAGE_BYTES + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            // next chunk's operand image, one 16-byte slot per lane at a time, spread over taps 3..8; the two waves that share a
+            // SIMD (w, w + 4) take alternate taps so one of them is always in its MFMAs.  The landing area is complete for every
+            // lane that reads its OWN slot once its tap-3 wait has passed (raw rows are older than the tap-3 weights).
+            if (has_next && tap >= 3 && ((tap - 3) & 1) == wn) {
+                if (tap < 5) transform(Q0{}, cl + 1, hb_next);
+                else if (tap < 7) transform(Q1{}, cl + 1, hb_next);
+                else transform(Q2{}, cl + 1, hb_next);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------ epilogue
+    __syncthreads();
+    float* tilef = reinterpret_cast<float*>(smem);
+    const int er = (wm * 4) * 16 + (lane >> 4) * 4, ec = wn * 80 + (lane & 15);
+    if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + j * 16] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + j * 16] += acc[i][j][r];
+    }
+    __syncthreads();
+
+    // row-major pass: 24 rows x 20 eight-column chunks per sweep (480 of the 512 threads)
+    const int col8 = tid % 20, row0 = tid / 20;
+    const bool act = tid < 480;
+    const int rpb = (int)g.div_rpb.d;
+    if (p.splitk > 1) {
+        if (act) {
+            float* slab = p.slab + (size_t)split * p.M * p.N;
+            for (int row = row0; row < HBM; row += 24) {
+                const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
+                const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
+                float* dst = slab + (size_t)m * p.N + n0 + col8 * 8;
+                *reinterpret_cast<float4*>(dst) = lo;
+                *reinterpret_cast<float4*>(dst + 4) = hi;
+            }
+        }
+        return;
+    }
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    if (act) {
+        const float alpha = scalar_alpha(p);
+        Cols8 cols;
+        cols8_init(g, cols, n0 + col8 * 8, n0 + col8 * 8, false, alpha);
+        const float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int row = row0; row < HBM; row += 24) {
+            const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
+            const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            epi8_store(g, cols, v, gt, m, gs, gq);
+        }
+    }
+    if (p.gn_part) {
+        float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                scr[(row0 * HBN + col8 * 8 + j) * 2] = gs[j];
+                scr[(row0 * HBN + col8 * 8 + j) * 2 + 1] = gq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < HBN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 24; ++r) {
+                s += scr[(r * HBN + tid) * 2];
+                q += scr[(r * HBN + tid) * 2 + 1];
+            }
+            float* dst = p.gn_part + (((size_t)b * g.halo_tpi + tin) * g.n_out + n0 + tid) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+}
+
+}  // namespace
+
+// Eligibility of the halo kernel for a conv problem (the host-side planners mirror this).
+int bc_conv_halo_ok(const BcGemm& p) {
+    if (p.a_mode != BC_A_CONV3X3 || p.stride != 1 || p.conv_nopad_lo) return 0;
+    if (p.Hv != p.Hin || p.Wv != p.Win || p.Hout != p.Hin || p.Wout != p.Win) return 0;
+    if (p.Cin % 64 != 0 || p.N % HBN != 0 || p.Wout % TW != 0 || p.Hout % TH != 0) return 0;
+    if (p.A2 && (p.C1 % 64 != 0)) return 0;
+    return 1;
+}
+
+int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
+    BcGemm& p = g.p;
+    g.halo_tx = p.Wout / TW;
+    g.halo_tpi = g.halo_tx * (p.Hout / TH);
+    g.halo_nch = p.Cin / 64;
+    int sk = std::max(1, std::min(p.splitk, g.halo_nch));
+    g.halo_cps = bc_ceil_div(g.halo_nch, sk);
+    p.splitk = bc_ceil_div(g.halo_nch, g.halo_cps);
+    BC_CHECK_ARG(g.halo_cps <= MAX_CH, "bc_gemm(halo conv): %d channel chunks per split exceed %d (raise splitk)", g.halo_cps, MAX_CH);
+    BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(halo conv): splitk=%d needs a slab", p.splitk);
+    const int B = p.M / (p.Hout * p.Wout);
+    dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    static std::atomic<unsigned long long> set_a{0}, set_p{0};
+    if (p.a_affine) {
+        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_halo_kernel<true>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_halo_kernel<true>), grid, dim3(512), LDS_TOTAL, stream, g);
+    } else {
+        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_halo_kernel<false>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_halo_kernel<false>), grid, dim3(512), LDS_TOTAL, stream, g);
+    }
+    BC_CHECK_LAUNCH();
+    return 0;
+}

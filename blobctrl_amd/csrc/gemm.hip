@@ -403,6 +403,14 @@ extern "C" int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* s
     return 0;
 }
 
+extern "C" int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, int Hout, int Wout, int stride) {
+    BcGemm p = {};
+    p.a_mode = BC_A_CONV3X3; p.Cin = Cin; p.C1 = C1; p.N = N; p.Hin = p.Hv = Hin; p.Win = p.Wv = Win; p.Hout = Hout; p.Wout = Wout;
+    p.stride = stride;
+    p.A2 = C1 > 0 ? reinterpret_cast<const bc_half*>(&p) : nullptr;       // (only tested for non-null)
+    return bc_conv_halo_ok(p);
+}
+
 extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BC_CHECK_ARG(pp != nullptr, "bc_gemm: null params");
@@ -425,7 +433,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         const int pads = p.conv_nopad_lo ? 1 : 2;
         BC_CHECK_ARG(p.Hout == (p.Hv + pads - 3) / p.stride + 1 && p.Wout == (p.Wv + pads - 3) / p.stride + 1,
                      "bc_gemm: conv output size %dx%d inconsistent with input %dx%d stride %d", p.Hout, p.Wout, p.Hv, p.Wv, p.stride);
-        BC_CHECK_ARG(p.A2 == nullptr, "bc_gemm: conv mode takes a single source");
+        BC_CHECK_ARG(p.A2 == nullptr || p.tile_cfg == BC_TILE_HALO, "bc_gemm: conv mode takes a single source (except BC_TILE_HALO)");
         p.rows_per_batch = p.Hout * p.Wout;
         if (p.out_w <= 0) p.out_w = p.Wout;
         g.fast_k = (p.Cin % BK == 0);
@@ -457,7 +465,18 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     } else {
         BC_CHECK_ARG(p.ldc >= g.n_out, "bc_gemm: ldc=%d < n_out=%d", p.ldc, g.n_out);
     }
+    const bool halo = p.tile_cfg == BC_TILE_HALO;
+    if (halo) {
+        if (p.lda <= 0 || !p.A2) p.lda = p.A2 ? p.C1 : p.Cin;
+        if (p.A2 && p.lda2 <= 0) p.lda2 = p.Cin - p.C1;
+        BC_CHECK_ARG(bc_conv_halo_ok(p), "bc_gemm: BC_TILE_HALO needs a 3x3 stride-1 pad-1 convolution with Cin%%64==0, N%%160==0, "
+                                         "Wout%%16==0, Hout%%8==0 (Cin=%d N=%d %dx%d)", p.Cin, p.N, p.Hout, p.Wout);
+        BC_CHECK_ARG(!p.a_affine || p.a_act == BC_ACT_NONE || p.a_act == BC_ACT_SILU, "bc_gemm: a_act must be NONE or SILU");
+    } else {
+        BC_CHECK_ARG(p.a_affine == nullptr, "bc_gemm: a_affine (fused GroupNorm prologue) is only available on BC_TILE_HALO");
+    }
     g.nk = bc_ceil_div(p.K, BK);
+    if (halo) g.nk = p.Cin / BK;                    // split-K counts 64-channel chunks (each covers the nine taps)
     if (p.splitk > g.nk) p.splitk = g.nk;
     if (p.splitk > 1) BC_CHECK_ARG(p.slab != nullptr, "bc_gemm: splitk=%d needs a slab", p.splitk);
     g.kt_per_split = bc_ceil_div(g.nk, p.splitk);
@@ -477,7 +496,9 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     static const bool force_generic = getenv("BC_GEMM_GENERIC") != nullptr;
     static const int force_tile = getenv("BC_GEMM_TILE") ? atoi(getenv("BC_GEMM_TILE")) : 0;
     if (force_generic) fast_ok = false;
-    {
+    if (halo) {
+        g.cfg = BC_TILE_HALO; g.bm = 128; g.bn = 160;
+    } else {
         int cfg = (force_tile > 0 && force_tile < BC_TILE_COUNT) ? force_tile : p.tile_cfg;
         int sk = p.splitk, bm = 0, bn = 0;
         int rc0 = bc_gemm_plan(p.M, p.N, p.K, fast_ok ? 1 : 0, &cfg, &sk, &bm, &bn);
@@ -492,11 +513,11 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
                        p.act == BC_ACT_NONE && !p.rowvec && !p.colscale && !p.R && !p.R2;
     if (p.gn_part) {
         const int slab_rows = p.splitk > 1 ? SK_ROWS : g.bm;
-        BC_CHECK_ARG((fast_ok || p.splitk > 1) && g.vec_epilogue && p.N % 4 == 0 && p.rows_per_batch % slab_rows == 0 &&
+        BC_CHECK_ARG((fast_ok || halo || p.splitk > 1) && g.vec_epilogue && p.N % 4 == 0 && p.rows_per_batch % slab_rows == 0 &&
                          p.M % p.rows_per_batch == 0,
                      "bc_gemm: fused GroupNorm partials need the fast path or split-K, fp16 row-major output and rows_per_batch%%%d==0", slab_rows);
     }
-    int rc = fast_ok ? bc_gemm_fast_try(g, stream) : -1;
+    int rc = halo ? bc_conv_halo_launch(g, stream) : fast_ok ? bc_gemm_fast_try(g, stream) : -1;
     if (rc > 0) return rc;
     if (rc < 0) {
         BC_CHECK_ARG(!p.gn_part || p.splitk > 1, "bc_gemm: fused GroupNorm partials are only produced by the fast path or the split-K reducer");

@@ -40,6 +40,8 @@ struct GemmArgs {
     int bm, bn;          // its tile shape
     int vec_epilogue;    // 1: LDS-staged 16-byte epilogue is legal (fp16 row-major output, widths % 8 == 0)
     int vec_transposed;  // 1: BC_OUT_F16_T with rows_per_batch % 8 == 0 and ldc % 8 == 0: 16-byte stores along the token axis
+    int halo_tx, halo_tpi;   // halo conv: pixel tiles per image row / per image
+    int halo_nch, halo_cps;  // halo conv: 64-channel chunks in total / per split
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
@@ -298,3 +300,6 @@ __device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, cons
 
 // gemm_fast.hip: returns 0 when it launched the GEMM, -1 when the problem is outside its fast path, >0 on error.
 int bc_gemm_fast_try(const bcg::GemmArgs& g, hipStream_t stream);
+// conv_halo.hip: LDS-resident input-halo 3x3 convolution with the fused GroupNorm prologue (BC_TILE_HALO).
+int bc_conv_halo_ok(const BcGemm& p);
+int bc_conv_halo_launch(bcg::GemmArgs& g, hipStream_t stream);

@@ -10,6 +10,7 @@ the reference op list: channel-concat folded into the GroupNorm / shortcut loade
 following conv's gather, bias / time-embedding / residual / BlobNet right-half add / conditioning scale / GEGLU folded
 into GEMM epilogues, V produced transposed by its projection GEMM, q|k projections fused, all 22 time_emb_proj fused.
 """
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -71,8 +72,13 @@ class TrunkPlan:
         xmin = 0 if W == H else W - H
         return dict(R2=res_t, ldr2=res_t.shape[-1], r2_xmin=xmin, r2_bmod=self.res_bmod, out_w=W)
 
+    def halo_ok(self, Cin, C1, Cout, H, W):
+        """The LDS-resident input-halo convolution with the fused GroupNorm prologue (conv_halo.hip) can run this layer."""
+        return not os.environ.get("BC_NO_HALO") and bool(self.rec.lib.bc_conv_halo_eligible(Cin, C1, Cout, H, W, H, W, 1))
+
     def conv3x3(self, x: Act, wname, Cout, stride=1, up_to=None, rowvec=None, R=None, r2=None, out_f32=False,
-                kind="conv3x3", out=None):
+                kind="conv3x3", out=None, x2: Optional[Act] = None, affine=None, halo=False):
+        """`halo=True`: conv_halo.hip on the channel-concat (x | x2) with `affine` = (ab tensor, activation) applied while staging."""
         rec, pw = self.rec, self.pw
         Hv, Wv = up_to if up_to is not None else (x.H, x.W)
         Hout, Wout = (Hv + 2 - 3) // stride + 1, (Wv + 2 - 3) // stride + 1
@@ -87,9 +93,18 @@ class TrunkPlan:
         if R is not None:
             kw.update(R=R.t, ldr=R.C)
         kw.update(self._r2(r2, Hout, Wout))
-        rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * x.C, out=out,
+        Cin = x.C + (x2.C if x2 is not None else 0)
+        if halo:
+            kw.update(tile_cfg=_lib.TILE_HALO, lda=x.C)
+            if x2 is not None:
+                kw.update(A2=x2.t, C1=x.C, lda2=x2.C)
+            if affine is not None:
+                kw.update(a_affine=affine[0], a_act=affine[1])
+        else:
+            assert x2 is None and affine is None
+        rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * Cin, out=out,
                  out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,
-                 conv=dict(Cin=x.C, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
+                 conv=dict(Cin=Cin, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
                  bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, want_gn=not out_f32, **kw)
         return Act(out, Cout, Hout, Wout)
 
@@ -102,6 +117,17 @@ class TrunkPlan:
         rec.gemm(A=x_t, W=pw.h[wkey or (wname + ".weight")], M=M, N=N, K=K, out=out,
                  bias=pw.f[wname + ".bias"] if bias else None, kind=kind, **kw)
         return out
+
+    def gn_conv(self, x: Act, x2: Optional[Act], norm, eps, wname, Cout, **kw):
+        """GroupNorm(x | x2) -> SiLU -> conv3x3 (resnet.py:327-341, 351-366).  Fused (statistics -> per-channel affine; normalise +
+        SiLU inside the convolution's halo staging) when the layer fits conv_halo.hip, else GroupNorm pass + implicit GEMM."""
+        pw = self.pw
+        C2 = x2.C if x2 is not None else 0
+        if self.halo_ok(x.C + C2, C2 and x.C, Cout, x.H, x.W):
+            ab = self.rec.gn_affine(x.t, x.C, x2.t if x2 is not None else None, C2, self.B, x.H * x.W, self.G, eps,
+                                    pw.f[norm + ".weight"], pw.f[norm + ".bias"])
+            return self.conv3x3(x, wname, Cout, x2=x2, affine=(ab, _lib.ACT_SILU), halo=True, **kw)
+        return self.conv3x3(self.groupnorm(x, x2, norm, eps, True), wname, Cout, **kw)
 
     def groupnorm(self, x: Act, x2: Optional[Act], name, eps, silu):
         pw = self.pw
@@ -118,9 +144,7 @@ class TrunkPlan:
         off, n = pw.temb_slices[p]
         assert n == Cout
         rowvec = (self.tproj.data_ptr() + off * 2, pw.temb_total) + getattr(self, "tproj_table", ())
-        h = self.groupnorm(x, skip, p + "norm1", 1e-5, True)
-        h = self.conv3x3(h, p + "conv1", Cout, rowvec=rowvec)
-        h = self.groupnorm(h, None, p + "norm2", 1e-5, True)
+        h = self.gn_conv(x, skip, p + "norm1", 1e-5, p + "conv1", Cout, rowvec=rowvec)
         M = self.B * x.H * x.W
         if (p + "conv_shortcut.weight") in pw.h:
             kw = {}
@@ -130,7 +154,7 @@ class TrunkPlan:
         else:
             assert skip is None and Cin == Cout
             sc = x
-        return self.conv3x3(h, p + "conv2", Cout, R=sc, r2=r2)
+        return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2)
 
     def transformer(self, p, x: Act, r2=None):
         """transformer_2d.py:479-527 + attention.py:421-541 (one BasicTransformerBlock)."""

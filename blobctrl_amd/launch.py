@@ -194,7 +194,8 @@ class Recorder:
     def gemm(self, *, A, W, M, N, K, out=None, out_mode=_lib.OUT_F16, ldc=None, A2=None, C1=0, lda=None, lda2=0,
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rowvec_idx=None, rowvec_step=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
-             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None):
+             out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None,
+             a_affine=None, a_act=_lib.ACT_NONE):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -203,8 +204,9 @@ class Recorder:
         g.A2 = ptr(A2)
         g.a_mode = _lib.A_CONV3X3 if conv else _lib.A_DENSE
         g.M, g.N, g.K = M, N, K
-        g.lda = lda if lda is not None else K
+        g.lda = lda if lda is not None else (K if not conv else 0)
         g.lda2, g.C1 = lda2, C1
+        g.a_affine, g.a_act = ptr(a_affine), a_act
         if conv:
             g.Cin, g.Hin, g.Win = conv["Cin"], conv["Hin"], conv["Win"]
             g.Hv, g.Wv = conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])
@@ -238,7 +240,19 @@ class Recorder:
             fast = fast and C1 % 64 == 0
         if os.environ.get("BC_GEMM_GENERIC"):
             fast = False
-        cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
+        if tile_cfg == _lib.TILE_HALO:
+            # LDS-resident input-halo convolution (conv_halo.hip): split-K counts 64-channel chunks; fill ~one workgroup per CU
+            nch = conv["Cin"] // 64
+            base = (M // 128) * (N // 160)
+            if splitk is None:
+                target = int(os.environ.get("BC_HALO_CTAS", "256"))
+                splitk = 1 if base * 3 >= target * 2 else max(1, min(nch // 2, -(-target // base)))
+            cps = -(-nch // max(1, splitk))
+            cfg, sk, bm, bn = _lib.TILE_HALO, -(-nch // cps), 128, 160
+            fast, mode = True, "halo"
+        else:
+            assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO"
+            cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
         g.splitk = sk
         g.tile_cfg = cfg
         if sk > 1:
@@ -266,8 +280,8 @@ class Recorder:
             if rc:
                 _lib.check(rc, "bc_gemm")
 
-        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part))
-        variant = ("gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
+        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part, a_affine))
+        variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
         self._push(fn, kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out
@@ -319,6 +333,43 @@ class Recorder:
         self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"), variant="gn_apply_fused_kernel",
                    shape=("gn", B, HW, Cc), bytes_=nbytes)
         return out
+
+    def gn_affine(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta):
+        """Per-(image, channel) affine (rstd*gamma, beta - mean*rstd*gamma) of GroupNorm over the channel-concat (x1 | x2), from the
+        producers' per-channel partial statistics: ab [B][C1+C2][2] fp32.  The consumer convolution applies it (and SiLU) while it
+        stages its input halo (BcGemm.a_affine), so the normalised activation never goes through HBM."""
+        lib = self.lib
+        c2 = C2 if x2 is not None else 0
+        Cc = C1 + c2
+        ab = self.empty(B, Cc, 2, dtype=torch.float32)
+        stats_calls, srcs = [], []
+        for x, c in ((x1, C1), (x2, c2)):
+            if x is None:
+                srcs.append((None, 0))
+                continue
+            hit = self.parts.get(x.data_ptr())
+            if hit is not None and hit[0].shape[2] == c:
+                srcs.append((hit[0], hit[1]))
+            else:
+                nslab = (HW + 127) // 128
+                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
+                stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
+                srcs.append((part, nslab))
+        (pa1, ns1), (pa2, ns2) = srcs
+        pp1, pp2, pab, pg, pb = ptr(pa1), ptr(pa2), ptr(ab), ptr(gamma), ptr(beta)
+
+        def fn(stream):
+            rc = 0
+            for (px, c, pp, ns) in stats_calls:
+                rc = rc or lib.bc_gn_stats(px, c, B, HW, pp, ns, stream)
+            rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
+            if rc:
+                _lib.check(rc, "gn_affine")
+
+        self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta))
+        self._push(fn, "gn_finalize", variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc),
+                   bytes_=sum(B * HW * c * 2 for (_, c, _, _) in stats_calls))
+        return ab
 
     def layernorm(self, x, rows, Cc, gamma, beta, eps, out=None, ldx=None, ldy=None):
         lib = self.lib

@@ -46,10 +46,11 @@ enum { BC_OUT_F16 = 0, BC_OUT_F16_T = 1, BC_OUT_F32 = 2 };
 typedef struct BcGemm {
     /* ---- A operand ---- */
     const bc_half* A;        /* DENSE: [M][lda] rows; CONV3X3: NHWC image [B][Hin][Win][Cin] */
-    const bc_half* A2;       /* DENSE only, optional second source: columns k >= C1 come from A2[m][k - C1] (channel concat) */
+    const bc_half* A2;       /* optional second source (DENSE, or CONV3X3 on BC_TILE_HALO): columns / channels k >= C1 come from
+                              * A2[..][k - C1] (channel concat) */
     int a_mode;              /* BC_A_* */
     int M, N, K;             /* GEMM dims; CONV3X3: M = B*Hout*Wout, K = 9*Cin; weights are [N][ky][kx][Cin] */
-    int lda, lda2;           /* DENSE row strides (elements) */
+    int lda, lda2;           /* DENSE row strides (elements); CONV3X3 on BC_TILE_HALO: pixel strides of A / A2 (0 = Cin) */
     int C1;                  /* DENSE with A2: split point (multiple of 8); else ignored */
     int Cin;                 /* CONV3X3: input channels (multiple of 8) */
     int Hin, Win;            /* CONV3X3: stored input image size */
@@ -95,13 +96,26 @@ typedef struct BcGemm {
     float* gn_part;
     /* ---- tile configuration: 0 = library heuristic, else one of BC_TILE_* (see bc_gemm_plan) ---- */
     int tile_cfg;
+    /* ---- A-operand prologue (BC_TILE_HALO only): the GroupNorm(+SiLU) in front of a ResBlock convolution
+     *      (D/models/resnet.py:327-328,351-363) applied while the input halo tile is staged:
+     *      a := act( A[.., k] * a_affine[b][k][0] + a_affine[b][k][1] ), k over the channel concat (A | A2), a_affine fp32
+     *      [B][Cin][2] as written by bc_gn_finalize; zero padding applies to the activated value.  NULL = plain convolution. ---- */
+    const float* a_affine;
+    int a_act;               /* BC_ACT_NONE or BC_ACT_SILU */
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);
 int bc_sizeof_gemm(void);            /* sizeof(BcGemm), lets FFI bindings verify their struct mirror */
 /* Tile configurations of the LDS-DMA fast path (block tile BM x BN, waves, LDS stages). */
 enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_128x128_S2 = 3, BC_TILE_256x64_S2 = 4,
-       BC_TILE_256x64_S3 = 5, BC_TILE_128x64 = 6, BC_TILE_64x64 = 7, BC_TILE_COUNT = 8 };
+       BC_TILE_256x64_S3 = 5, BC_TILE_128x64 = 6, BC_TILE_64x64 = 7, BC_TILE_COUNT = 8,
+       /* LDS-resident input-halo convolution (conv_halo.hip): 3x3 / stride 1 / pad 1, Cin % 64 == 0, N % 160 == 0, Wout % 16 == 0,
+        * Hout % 8 == 0; workgroup = 8 x 16 pixels x 160 channels; takes two channel-concatenated sources (A | A2, C1 % 64 == 0,
+        * lda / lda2 = their pixel strides) and the fused GroupNorm prologue (a_affine); splitk counts 64-channel chunks.  Never
+        * chosen by BC_TILE_AUTO: callers ask for it (bc_conv_halo_eligible). */
+       BC_TILE_HALO = 8 };
+/* 1 when a convolution can run on BC_TILE_HALO. */
+int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, int Hout, int Wout, int stride);
 /* Resolve the plan for a GEMM: in/out *tile_cfg (AUTO -> heuristic choice), in/out *splitk (<= 0 -> heuristic), out *bm,
  * *bn = tile shape (bm is the slab height of gn_part).  `fast` = 1 when the problem meets the fast-path conditions
  * (K % 64 == 0, conv Cin % 64 == 0, concat split % 64 == 0); otherwise only 128x128 / 256x64 generic tiles exist. */

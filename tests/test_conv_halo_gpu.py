@@ -1,0 +1,105 @@
+"""Parity of the LDS-resident input-halo convolution with the fused GroupNorm(+SiLU) prologue (conv_halo.hip, BC_TILE_HALO)
+against a plain PyTorch fp32 statement of resnet.py:327-341 / 351-366 (torch.cat -> GroupNorm -> SiLU -> conv3x3 [+ bias, time
+embedding row vector, residual, BlobNet right-half residual]) computed on the CPU from the same fp16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import g  # noqa: E402
+from tests.test_kernels_gpu import close, h, rec, run  # noqa: E402,F401
+
+
+def nhwc(x):            # [B,C,H,W] fp32 -> token-major fp16 on the GPU
+    B, C, H, W = x.shape
+    return h(x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous())
+
+
+def from_nhwc(t, B, H, W):
+    return t.float().cpu().view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def conv_ref(x, w, b):
+    return F.conv2d(x.half().float(), w.half().float(), b, padding=1)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,sk", [(1, 8, 16, 64, 160, 1), (2, 16, 32, 128, 320, 1), (1, 24, 16, 192, 160, 1),
+                                               (2, 8, 16, 256, 160, 2), (1, 8, 32, 640, 320, 5), (1, 16, 16, 320, 160, None)])
+def test_halo_conv_plain(rec, B, H, W, Cin, Cout, sk):
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv3x3
+    x, w, b = g(1, B, Cin, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
+    M = B * H * W
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
+                                    conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
+                                    tile_cfg=_lib.TILE_HALO, splitk=sk))
+    close(from_nhwc(out, B, H, W), conv_ref(x, w, b), what=f"halo conv {B}x{Cin}->{Cout}@{H}x{W} sk={sk}")
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,sk,silu", [(2, 16, 16, 128, 0, 160, 1, True), (1, 8, 32, 64, 128, 320, 1, True),
+                                                       (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False)])
+def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, sk, silu):
+    """GroupNorm statistics from a standalone pass -> bc_gn_finalize -> affine applied in the halo staging (zero padding AFTER the
+    activation), two channel-concatenated sources, and the whole ResBlock epilogue: bias + time-embedding row vector + residual +
+    BlobNet right-half residual + GroupNorm partials of the output."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv3x3
+    Cin, G = C1 + C2, 8
+    x1 = g(1, B, C1, H, W) * 1.7 + 0.3
+    x2 = g(4, B, C2, H, W) * 0.6 - 0.2 if C2 else None
+    w, b = g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
+    gamma, beta = 1.0 + 0.2 * g(5, Cin), 0.3 * g(6, Cin)
+    temb, R, R2 = g(7, B, Cout), g(8, B, Cout, H, W), g(9, 1, Cout, H, W)
+    M, HW = B * H * W, H * W
+    xcat = torch.cat([x1, x2], 1) if C2 else x1
+
+    def fn():
+        t1, t2 = nhwc(x1), (nhwc(x2) if C2 else None)
+        ab = rec.gn_affine(t1, C1, t2, C2, B, HW, G, 1e-5, gamma.cuda(), beta.cuda())
+        kw = dict(A2=t2, C1=C1, lda2=C2) if C2 else {}
+        out = rec.gemm(A=t1, lda=C1, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
+                       conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=HW, tile_cfg=_lib.TILE_HALO,
+                       splitk=sk, a_affine=ab, a_act=_lib.ACT_SILU if silu else _lib.ACT_NONE, rowvec=h(temb), ld_rowvec=Cout,
+                       R=nhwc(R), ldr=Cout, R2=nhwc(R2), ldr2=Cout, r2_xmin=W - H if W > H else 0, r2_bmod=1, out_w=W, want_gn=True,
+                       **kw)
+        return out, rec.parts[out.data_ptr()]
+    out, (part, nslab) = run(rec, fn)
+    xh = xcat.half().float()
+    y = F.group_norm(xh, G, gamma, beta, 1e-5)
+    y = F.silu(y) if silu else y
+    ref = F.conv2d(y.half().float(), w.half().float(), b, padding=1) + temb.half().float()[:, :, None, None] + R.half().float()
+    xmin = W - H if W > H else 0
+    ref[..., xmin:] += R2.half().float()[..., xmin:]
+    got = from_nhwc(out, B, H, W)
+    close(got, ref, rtol=4e-3, what=f"fused GN conv {C1}+{C2}->{Cout}@{H}x{W} sk={sk}")
+    # GroupNorm partials of the fp16-rounded output: per-channel sums over all slabs
+    s = part.float().cpu().sum(1)                                             # [B][Cout][2]
+    o = out.float().cpu().view(B, HW, Cout)
+    assert torch.allclose(s[..., 0], o.sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
+    assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
+
+
+def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec):
+    """The production shape family: 320 -> 320 @ 64 x 128, batch 2, against GroupNorm pass + implicit-GEMM kernel (both HIP)."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv3x3
+    B, H, W, C, G = 2, 64, 128, 320, 32
+    x, w, b = g(1, B, C, H, W), g(2, C, C, 3, 3) / math.sqrt(9 * C), g(3, C)
+    gamma, beta = 1.0 + 0.2 * g(5, C), 0.3 * g(6, C)
+    M, HW = B * H * W, H * W
+    conv = dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1)
+
+    def fn():
+        t = nhwc(x)
+        ab = rec.gn_affine(t, C, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda())
+        fused = rec.gemm(A=t, lda=C, W=h(pack_conv3x3(w)), M=M, N=C, K=9 * C, out=rec.empty(M, C), bias=b.cuda(), conv=conv,
+                         rows_per_batch=HW, tile_cfg=_lib.TILE_HALO, a_affine=ab, a_act=_lib.ACT_SILU)
+        y = rec.groupnorm(t, C, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda(), True)
+        plain = rec.gemm(A=y, W=h(pack_conv3x3(w)), M=M, N=C, K=9 * C, out=rec.empty(M, C), bias=b.cuda(), conv=conv,
+                         rows_per_batch=HW)
+        return fused, plain
+    fused, plain = run(rec, fn)
+    close(fused, plain, rtol=4e-3, what="fused vs unfused resblock conv")

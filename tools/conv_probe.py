@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""A/B probe of the ResBlock convolution path on the production shapes, one process, interleaved:
+  old = GroupNorm-apply pass (gn_apply_fused) + implicit-GEMM kernel (tuned tile / split-K)
+  new = gn_finalize (per-channel affine) + conv_halo.hip with the normalise + SiLU fused into the halo staging
+Reports microseconds per (GroupNorm + conv) pair and TFLOP/s of the convolution's 2*M*N*K."""
+import math
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+from blobctrl_amd import _lib  # noqa: E402
+from blobctrl_amd.launch import Recorder  # noqa: E402
+from tools.tune_gemm import time_launch  # noqa: E402
+
+dev = torch.device("cuda:0")
+rec = Recorder(dev)
+stream = torch.cuda.current_stream().cuda_stream
+# (B, H, W, C1, C2, Cout): UNet (B = 2) ResBlock convolutions of a 512^2 edit; BlobNet runs the same at B = 1
+SHAPES = [(2, 64, 128, 320, 0, 320), (2, 64, 128, 640, 320, 320), (2, 64, 128, 320, 320, 320), (1, 64, 128, 320, 0, 320),
+          (2, 32, 64, 640, 0, 640), (2, 32, 64, 320, 0, 640), (2, 32, 64, 1280, 640, 640), (1, 32, 64, 640, 0, 640),
+          (2, 16, 32, 1280, 0, 1280), (2, 16, 32, 1280, 1280, 1280), (1, 16, 32, 1280, 0, 1280),
+          (2, 8, 16, 1280, 0, 1280), (2, 8, 16, 1280, 1280, 1280), (1, 8, 16, 1280, 0, 1280)]
+only = os.environ.get("PROBE_ONLY")
+for (B, H, W, C1, C2, Co) in SHAPES:
+    Cin, HW, M = C1 + C2, H * W, B * H * W
+    x1 = torch.randn(B, HW, C1, device=dev, dtype=torch.float16)
+    x2 = torch.randn(B, HW, C2, device=dev, dtype=torch.float16) if C2 else None
+    wt = (torch.randn(Co, 9 * Cin, device=dev) / math.sqrt(9 * Cin)).half()
+    bias = torch.randn(Co, device=dev)
+    gamma, beta = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1)
+    flops = 2.0 * M * Co * 9 * Cin
+    # statistics of the inputs once (both paths read the same partials)
+    seg0 = rec.begin("stats")
+    rec.gn_affine(x1, C1, x2, C2, B, HW, 32, 1e-5, gamma, beta)
+    seg0.run(stream)
+    res = {}
+    seg = rec.begin("old")
+    y = rec.groupnorm(x1, C1, x2, C2, B, HW, 32, 1e-5, gamma, beta, True)
+    rec.gemm(A=y, W=wt, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW, want_gn=True)
+    old_variant = seg.meta[-1]["variant"] + str(seg.meta[-1]["shape"][-1])
+    segs = {"old": seg}
+    for sk in ([None] if not only else [int(v) for v in only.split(",")]) + ([1, 2, 4, 5, 10] if not only else []):
+        nch = Cin // 64
+        if sk is not None and (sk > nch or -(-nch // sk) > 40):
+            continue
+        s2 = rec.begin(f"halo_sk{sk}")
+        ab = rec.gn_affine(x1, C1, x2, C2, B, HW, 32, 1e-5, gamma, beta)
+        kw = dict(A2=x2, C1=C1, lda2=C2) if C2 else {}
+        rec.gemm(A=x1, lda=C1, W=wt, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW,
+                 tile_cfg=_lib.TILE_HALO, splitk=sk, a_affine=ab, a_act=_lib.ACT_SILU, want_gn=True, **kw)
+        segs[f"halo_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
+    for rnd in range(3):
+        for k, s in segs.items():
+            res.setdefault(k, []).append(time_launch(rec, s, stream, 10))
+    line = f"B{B} {H}x{W} {C1}+{C2}->{Co}: old[{old_variant}]"
+    for k, v in res.items():
+        us = sorted(v)[1]
+        line += f" | {k} {us:7.1f} us {flops / us / 1e6:6.0f} TF"
+    print(line, flush=True)

@@ -25,7 +25,7 @@ def csrc_sha():
     import hashlib
     hsh = hashlib.sha1()
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blobctrl_amd", "csrc")
-    for f in sorted(os.listdir(src)):
+    for f in sorted(x for x in os.listdir(src) if x.endswith((".hip", ".h"))):
         with open(os.path.join(src, f), "rb") as fh:
             hsh.update(f.encode() + b"\0" + fh.read())
     return hsh.hexdigest()[:12]
