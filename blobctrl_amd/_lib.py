@@ -35,6 +35,8 @@ class BcGemm(C.Structure):
         ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
         ("splitk", C.c_int), ("slab", C.c_void_p), ("gn_part", C.c_void_p), ("tile_cfg", C.c_int),
         ("a_affine", C.c_void_p), ("a_act", C.c_int),
+        ("a_part1", C.c_void_p), ("a_ns1", C.c_int), ("a_part2", C.c_void_p), ("a_ns2", C.c_int),
+        ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("a_groups", C.c_int), ("a_eps", C.c_float),
     ]
 
 

@@ -74,7 +74,10 @@ __device__ __forceinline__ void wait_vm(int n) {      // n is wave-uniform
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
-template <bool AFFINE>
+constexpr int FIN_MAX_CH = 720;                 // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
+
+// AFFINE: 0 = plain convolution, 1 = affine table from global memory (bc_gn_finalize ran), 2 = GroupNorm finalize in the prologue
+template <int AFFINE>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BcGemm& p = g.p;
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
     const int H = p.Hin, W = p.Win;
 
+    const int dbg = g.halo_dbg;                              // BC_HALO_DBG ablation bits (diagnostics only; results are wrong when set)
     const int c_begin = split * g.halo_cps;
     const int nch = min(g.halo_nch, c_begin + g.halo_cps) - c_begin;
     const int NT = nch * 9;
@@ -158,26 +162,36 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     };
     const unsigned raw_addr = (unsigned)(size_t)(lptr_t)(smem) + tid * 16;      // LDS byte address of this lane's slot 0 (minus OFF_RAW)
     const unsigned ab_base = (unsigned)(size_t)(lptr_t)(smem) + OFF_AB + sub * 64;   // this lane's 8 (a, b) pairs inside a chunk
-    auto transform = [&](auto qc, int cl, char* dst_buf) {   // landing area -> operand image (chunk cl), this lane's slot q
+    // Landing area -> operand image, this lane's slot q, in two halves so that the LDS latency hides behind the tap's MFMAs:
+    //   tr_issue  (top of the tap, BEFORE the fragment reads so hipcc's own counted lgkmcnt waits stay conservative): raw slot + the
+    //             chunk's 8 (a, b) pairs, no wait;
+    //   tr_finish (after the MFMAs): wait, normalise + activate, store the swizzled slot.
+    // Inline asm throughout: hipcc orders every plain LDS access it cannot prove disjoint behind ALL LDS-DMA writes in flight
+    // (`s_waitcnt vmcnt(0)`: it does not see the counted waits), which would drain the weight ring at every slice.  The lane's own
+    // slot IS complete (see the wait accounting in the tap loop).
+    struct Pending { u32x4v raw; f32x4v t0, t1, t2, t3; };
+    auto tr_issue = [&](auto qc, int cl, Pending& pd) {
         constexpr int q = decltype(qc)::value;
         if (hdst[q] < 0) return;
-        // Inline asm: hipcc otherwise puts `s_waitcnt vmcnt(0)` in front of a ds_read it cannot prove disjoint from the LDS-DMA
-        // writes in flight (it does not see the counted waits), which would drain the weight ring at every slice.  The lane's slot
-        // IS complete (see the wait accounting in the tap loop).
-        uint4 raw;
-        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(raw_addr), "n"(OFF_RAW + 8192 * q) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pd.raw) : "v"(raw_addr), "n"(OFF_RAW + 8192 * q) : "memory");
         if (AFFINE) {
             const unsigned ab_addr = ab_base + cl * 512;            // (64 channels x (a, b) x 4 bytes per chunk)
-            float4 t0, t1, t2, t3;
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-                         "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ab_addr) : "memory");
+                         "ds_read_b128 %3, %4 offset:48"
+                         : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
+        }
+    };
+    auto tr_finish = [&](auto qc, char* dst_buf, Pending& pd) {
+        constexpr int q = decltype(qc)::value;
+        if (hdst[q] < 0) return;
+        if (AFFINE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3)::"memory");
             __builtin_amdgcn_sched_barrier(0);
-            const float aa[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z};
-            const float bb[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
-            const h16* xin = reinterpret_cast<const h16*>(&raw);
-            uint4 outraw;
+            const float aa[8] = {pd.t0[0], pd.t0[2], pd.t1[0], pd.t1[2], pd.t2[0], pd.t2[2], pd.t3[0], pd.t3[2]};
+            const float bb[8] = {pd.t0[1], pd.t0[3], pd.t1[1], pd.t1[3], pd.t2[1], pd.t2[3], pd.t3[1], pd.t3[3]};
+            const u32x4v rawv = pd.raw;
+            const h16* xin = reinterpret_cast<const h16*>(&rawv);
+            u32x4v outraw;
             h16* o = reinterpret_cast<h16*>(&outraw);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -185,19 +199,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 if (p.a_act == BC_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                 o[j] = (h16)v;
             }
-            if (pix[q] < 0) outraw = make_uint4(0u, 0u, 0u, 0u);      // zero padding is applied AFTER norm + activation
-            raw = outraw;
+            if (pix[q] < 0) outraw = (u32x4v){0u, 0u, 0u, 0u};       // zero padding is applied AFTER norm + activation
+            pd.raw = outraw;
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // (inline asm for the same reason as the reads: a plain LDS store is ordered behind every LDS-DMA in flight by hipcc)
-        const u32x4v rv = {raw.x, raw.y, raw.z, raw.w};
-        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(lptr_t)(dst_buf) + (unsigned)hdst[q]), "v"(rv) : "memory");
+        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(lptr_t)(dst_buf) + (unsigned)hdst[q]), "v"(pd.raw) : "memory");
     };
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
 
     // ---- prologue: affine table of this chunk range -> LDS, first halo chunk, first two weight stages ----
-    if (AFFINE) {
+    if (AFFINE == 1) {
         const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
         float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
         for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
@@ -205,13 +220,76 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     issue_a(0);
     issue_b(0, 0);
     issue_b(1, 1);
+    if (AFFINE == 2) {
+        // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the producers' per-channel
+        // partials (fixed summation order: bit-reproducible).  Scratch = the two halo buffers (no LDS-DMA lands there).
+        const int cpg = p.Cin / p.a_groups;
+        const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
+        const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
+        const int c_lo = g_lo * cpg, nc = g_hi * cpg - c_lo;
+        float* scr = reinterpret_cast<float*>(smem + OFF_HALO);          // [8 waves][nc][2]
+        for (int cc = lane; cc < nc; cc += 64) {
+            const int c = c_lo + cc;
+            const bool second = p.A2 != nullptr && c >= p.C1;
+            const int ns = second ? p.a_ns2 : p.a_ns1;
+            const int Cs = second ? p.Cin - p.C1 : (p.A2 ? p.C1 : p.Cin);
+            const float* base = (second ? p.a_part2 : p.a_part1) + ((size_t)b * ns * Cs + (second ? c - p.C1 : c)) * 2;
+            double s = 0.0, q = 0.0;
+            for (int sl = wave; sl < ns; sl += 8) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)sl * Cs * 2);
+                s += v.x;
+                q += v.y;
+            }
+            scr[(wave * nc + cc) * 2] = (float)s;
+            scr[(wave * nc + cc) * 2 + 1] = (float)q;
+        }
+        __syncthreads();
+        float* stat = scr + 8 * nc * 2;                                   // [groups][2] = (mean, rstd)
+        for (int gi = g_lo + wave; gi < g_hi; gi += 8) {
+            double s = 0.0, q = 0.0;
+            for (int it = lane; it < cpg * 8; it += 64) {
+                const int w8 = it / cpg, cj = it - w8 * cpg;
+                s += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2];
+                q += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o);
+                q += __shfl_xor(q, o);
+            }
+            const double n = (double)g.div_rpb.d * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (lane == 0) {
+                stat[(gi - g_lo) * 2] = (float)mean;
+                stat[(gi - g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+            }
+        }
+        __syncthreads();
+        float* abt = reinterpret_cast<float*>(smem + OFF_AB);
+        for (int i = tid; i < nch * 64; i += 512) {
+            const int c = k_lo + i;
+            const int gi = c / cpg - g_lo;
+            const float a = stat[gi * 2 + 1] * p.a_gamma[c];
+            abt[i * 2] = a;
+            abt[i * 2 + 1] = p.a_beta[c] - stat[gi * 2] * a;
+        }
+        __syncthreads();                                                  // scratch is free again before the first halo is written
+    }
     wait_vm(2 * LB);                                          // my three halo slots have landed (weights may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // affine table visible
     asm volatile("" ::: "memory");
-    transform(Q0{}, 0, smem + OFF_HALO);
-    transform(Q1{}, 0, smem + OFF_HALO);
-    transform(Q2{}, 0, smem + OFF_HALO);
+    {
+        Pending p0, p1, p2;
+        tr_issue(Q0{}, 0, p0);
+        tr_issue(Q1{}, 0, p1);
+        tr_issue(Q2{}, 0, p2);
+        tr_finish(Q0{}, smem + OFF_HALO, p0);
+        tr_finish(Q1{}, smem + OFF_HALO, p1);
+        tr_finish(Q2{}, smem + OFF_HALO, p2);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     f32x4v acc[4][5];
@@ -231,31 +309,53 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             // them, in order: the next tap's stage, and (taps 1 and 2) the raw halo rows of the next chunk issued during tap 0.
             int pend = (kt + 1 < NT) ? LB : 0;
             if ((tap == 1 || tap == 2) && has_next) pend += 3;
+            if (dbg & (3 | 64)) pend = 0;
             wait_vm(pend);
-            __builtin_amdgcn_s_barrier();                     // stage `tap % 3` complete for every wave; stage (tap + 2) % 3 is free
+            if (!(dbg & 16)) __builtin_amdgcn_s_barrier();    // stage `tap % 3` complete for every wave; stage (tap + 2) % 3 is free
             asm volatile("" ::: "memory");
-            if (kt + 2 < NT) issue_b(kt + 2, (tap + 2) % 3);
-            if (tap == 0 && has_next) issue_a(cl + 1);        // (the landing area was consumed during the previous chunk)
             const int ky = tap / 3, kx = tap - ky * 3;
-            h16x8 fa[4], fb[5];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[i] = *reinterpret_cast<const h16x8*>(hb + a_off[kx] + (i + ky) * HSTR * 128);
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-                fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + (tap % 3) * STAGE_BYTES + j * 2048);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             // next chunk's operand image, one 16-byte slot per lane at a time, spread over taps 3..8; the two waves that share a
             // SIMD (w, w + 4) take alternate taps so one of them is always in its MFMAs.  The landing area is complete for every
             // lane that reads its OWN slot once its tap-3 wait has passed (raw rows are older than the tap-3 weights).
-            if (has_next && tap >= 3 && ((tap - 3) & 1) == wn) {
-                if (tap < 5) transform(Q0{}, cl + 1, hb_next);
-                else if (tap < 7) transform(Q1{}, cl + 1, hb_next);
-                else transform(Q2{}, cl + 1, hb_next);
+            const bool slice = has_next && tap >= 3 && ((tap - 3) & 1) == wn && !(dbg & (2 | 32));
+            Pending pd;
+            if (slice) {
+                if (tap < 5) tr_issue(Q0{}, cl + 1, pd);
+                else if (tap < 7) tr_issue(Q1{}, cl + 1, pd);
+                else tr_issue(Q2{}, cl + 1, pd);
+            }
+            h16x8 fa[4], fb[5];
+            if (!(dbg & 8)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    fa[i] = *reinterpret_cast<const h16x8*>(hb + a_off[kx] + (i + ky) * HSTR * 128);
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + (tap % 3) * STAGE_BYTES + j * 2048);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < 5; ++j) asm volatile("" : "=v"(fb[j]));
+            }
+            if (kt + 2 < NT && !(dbg & 1)) issue_b(kt + 2, (tap + 2) % 3);
+            if (tap == 0 && has_next && !(dbg & (2 | 64))) issue_a(cl + 1);   // (the landing area was consumed during the previous chunk)
+            if (!(dbg & 4)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < 5; ++j) asm volatile("" ::"v"(fb[j]));
+            }
+            if (slice) {
+                if (tap < 5) tr_finish(Q0{}, hb_next, pd);
+                else if (tap < 7) tr_finish(Q1{}, hb_next, pd);
+                else tr_finish(Q2{}, hb_next, pd);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -358,6 +458,8 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;
+    static const int dbg_env = getenv("BC_HALO_DBG") ? atoi(getenv("BC_HALO_DBG")) : 0;
+    g.halo_dbg = dbg_env;
     int sk = std::max(1, std::min(p.splitk, g.halo_nch));
     g.halo_cps = bc_ceil_div(g.halo_nch, sk);
     p.splitk = bc_ceil_div(g.halo_nch, g.halo_cps);
@@ -365,13 +467,22 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(halo conv): splitk=%d needs a slab", p.splitk);
     const int B = p.M / (p.Hout * p.Wout);
     dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
-    static std::atomic<unsigned long long> set_a{0}, set_p{0};
-    if (p.a_affine) {
-        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_halo_kernel<true>), LDS_TOTAL));
-        hipLaunchKernelGGL((conv_halo_kernel<true>), grid, dim3(512), LDS_TOTAL, stream, g);
+    static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
+    if (p.a_part1) {
+        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && p.a_ns1 > 0 && (!p.A2 || (p.a_part2 && p.a_ns2 > 0)),
+                     "bc_gemm(halo conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
+        const int cpg = p.Cin / p.a_groups;
+        BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && (8 * (g.halo_cps * 64 + 2 * cpg) + p.a_groups + 8) * 8 <= 2 * HALO_BYTES,
+                     "bc_gemm(halo conv): channel span %d per workgroup too wide for the in-kernel GroupNorm finalize (max %d): use "
+                     "bc_gn_finalize + a_affine or raise splitk", g.halo_cps * 64 + 2 * cpg, FIN_MAX_CH);
+        BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_halo_kernel<2>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_halo_kernel<2>), grid, dim3(512), LDS_TOTAL, stream, g);
+    } else if (p.a_affine) {
+        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_halo_kernel<1>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_halo_kernel<1>), grid, dim3(512), LDS_TOTAL, stream, g);
     } else {
-        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_halo_kernel<false>), LDS_TOTAL));
-        hipLaunchKernelGGL((conv_halo_kernel<false>), grid, dim3(512), LDS_TOTAL, stream, g);
+        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_halo_kernel<0>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_halo_kernel<0>), grid, dim3(512), LDS_TOTAL, stream, g);
     }
     BC_CHECK_LAUNCH();
     return 0;

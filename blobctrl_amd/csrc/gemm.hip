@@ -473,7 +473,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
                                          "Wout%%16==0, Hout%%8==0 (Cin=%d N=%d %dx%d)", p.Cin, p.N, p.Hout, p.Wout);
         BC_CHECK_ARG(!p.a_affine || p.a_act == BC_ACT_NONE || p.a_act == BC_ACT_SILU, "bc_gemm: a_act must be NONE or SILU");
     } else {
-        BC_CHECK_ARG(p.a_affine == nullptr, "bc_gemm: a_affine (fused GroupNorm prologue) is only available on BC_TILE_HALO");
+        BC_CHECK_ARG(p.a_affine == nullptr && p.a_part1 == nullptr, "bc_gemm: the fused GroupNorm prologue is only available on BC_TILE_HALO");
     }
     g.nk = bc_ceil_div(p.K, BK);
     if (halo) g.nk = p.Cin / BK;                    // split-K counts 64-channel chunks (each covers the nine taps)

@@ -42,6 +42,7 @@ struct GemmArgs {
     int vec_transposed;  // 1: BC_OUT_F16_T with rows_per_batch % 8 == 0 and ldc % 8 == 0: 16-byte stores along the token axis
     int halo_tx, halo_tpi;   // halo conv: pixel tiles per image row / per image
     int halo_nch, halo_cps;  // halo conv: 64-channel chunks in total / per split
+    int halo_dbg;            // halo conv: BC_HALO_DBG ablation bits (diagnostics)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile

@@ -99,7 +99,7 @@ class TrunkPlan:
             if x2 is not None:
                 kw.update(A2=x2.t, C1=x.C, lda2=x2.C)
             if affine is not None:
-                kw.update(a_affine=affine[0], a_act=affine[1])
+                kw.update(a_act=affine[1], **({"a_gn": affine[0]} if isinstance(affine[0], dict) else {"a_affine": affine[0]}))
         else:
             assert x2 is None and affine is None
         rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * Cin, out=out,
@@ -124,9 +124,9 @@ class TrunkPlan:
         pw = self.pw
         C2 = x2.C if x2 is not None else 0
         if self.halo_ok(x.C + C2, C2 and x.C, Cout, x.H, x.W):
-            ab = self.rec.gn_affine(x.t, x.C, x2.t if x2 is not None else None, C2, self.B, x.H * x.W, self.G, eps,
-                                    pw.f[norm + ".weight"], pw.f[norm + ".bias"])
-            return self.conv3x3(x, wname, Cout, x2=x2, affine=(ab, _lib.ACT_SILU), halo=True, **kw)
+            gn = dict(x1=x.t, C1=x.C, x2=x2.t if x2 is not None else None, C2=C2, B=self.B, HW=x.H * x.W, G=self.G, eps=eps,
+                      gamma=pw.f[norm + ".weight"], beta=pw.f[norm + ".bias"])
+            return self.conv3x3(x, wname, Cout, x2=x2, affine=(gn, _lib.ACT_SILU), halo=True, **kw)
         return self.conv3x3(self.groupnorm(x, x2, norm, eps, True), wname, Cout, **kw)
 
     def groupnorm(self, x: Act, x2: Optional[Act], name, eps, silu):

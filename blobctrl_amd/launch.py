@@ -195,7 +195,7 @@ class Recorder:
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rowvec_idx=None, rowvec_step=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None,
-             a_affine=None, a_act=_lib.ACT_NONE):
+             a_affine=None, a_act=_lib.ACT_NONE, a_gn=None):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -250,6 +250,25 @@ class Recorder:
             cps = -(-nch // max(1, splitk))
             cfg, sk, bm, bn = _lib.TILE_HALO, -(-nch // cps), 128, 160
             fast, mode = True, "halo"
+            if a_gn is not None:
+                # GroupNorm in front of the convolution: a_gn = dict(x1, C1, x2, C2, B, HW, G, eps, gamma, beta).  The finalize runs
+                # inside the convolution's prologue when the workgroup's channel span fits its scratch, else as its own launch.
+                G_ = a_gn["G"]
+                span = cps * 64 + 2 * (conv["Cin"] // G_)
+                (pa1, ns1), (pa2, ns2) = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"])
+                # Every workgroup re-reduces span x nslab partials: measured a LOSS against one bc_gn_finalize launch when that is
+                # 170 KB per workgroup (64 x 128 level: 63.9 vs 55.5 us per conv), a gain when it is a few KB (low-resolution levels)
+                vol = span * max(ns1, ns2) * 8
+                limit = int(os.environ.get("BC_GN_FINALIZE_IN_KERNEL_BYTES", "0"))      # (default off: no gain in the step, see DESIGN)
+                if span <= 712 and vol <= limit:
+                    g.a_part1, g.a_ns1, g.a_part2, g.a_ns2 = ptr(pa1), ns1, ptr(pa2), ns2
+                    g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), G_, a_gn["eps"]
+                    self.keep.append((pa1, pa2, a_gn["gamma"], a_gn["beta"]))
+                    mode = "halo_gnfin"
+                else:
+                    a_affine = self.gn_affine(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"], G_, a_gn["eps"],
+                                              a_gn["gamma"], a_gn["beta"])
+                    g.a_affine = ptr(a_affine)
         else:
             assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
@@ -333,6 +352,33 @@ class Recorder:
         self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"), variant="gn_apply_fused_kernel",
                    shape=("gn", B, HW, Cc), bytes_=nbytes)
         return out
+
+    def gn_sources(self, x1, C1, x2, C2, B, HW):
+        """Per-channel partial statistics of (x1 | x2): the producers' epilogue partials when they exist, else a recorded
+        bc_gn_stats pass.  Returns ((part1, nslab1), (part2, nslab2))."""
+        lib = self.lib
+        srcs = []
+        for x, c in ((x1, C1), (x2, C2 if x2 is not None else 0)):
+            if x is None:
+                srcs.append((None, 0))
+                continue
+            hit = self.parts.get(x.data_ptr())
+            if hit is not None and hit[0].shape[2] == c:
+                srcs.append((hit[0], hit[1]))
+            else:
+                nslab = (HW + 127) // 128
+                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
+                px, pp = x.data_ptr(), part.data_ptr()
+
+                def fn(stream, px=px, c=c, pp=pp, nslab=nslab):
+                    rc = lib.bc_gn_stats(px, c, B, HW, pp, nslab, stream)
+                    if rc:
+                        _lib.check(rc, "bc_gn_stats")
+                self.keep.append((x, part))
+                self._push(fn, "gn_stats", variant="gn_stats_kernel", shape=("gn_stats", B, HW, c), bytes_=B * HW * c * 2)
+                self.parts[x.data_ptr()] = (part, nslab)
+                srcs.append((part, nslab))
+        return tuple(srcs)
 
     def gn_affine(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta):
         """Per-(image, channel) affine (rstd*gamma, beta - mean*rstd*gamma) of GroupNorm over the channel-concat (x1 | x2), from the

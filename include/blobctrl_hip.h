@@ -102,6 +102,15 @@ typedef struct BcGemm {
      *      [B][Cin][2] as written by bc_gn_finalize; zero padding applies to the activated value.  NULL = plain convolution. ---- */
     const float* a_affine;
     int a_act;               /* BC_ACT_NONE or BC_ACT_SILU */
+    /* ---- ... or the same prologue with the GroupNorm FINALIZE done inside the convolution (no bc_gn_finalize launch): every
+     *      workgroup re-reduces the producers' per-channel partial statistics of the groups overlapping its channel range
+     *      (a_part1 [B][a_ns1][C1][2] for the channels of A, a_part2 [B][a_ns2][Cin - C1][2] for A2; same layout as gn_part),
+     *      then applies (x - mean) * rstd * a_gamma[k] + a_beta[k] and a_act.  Used when a_part1 != NULL (a_affine is then ignored);
+     *      needs the workgroup's channel span (+ group straddle) <= 720 channels, else call bc_gn_finalize and pass a_affine. ---- */
+    const float* a_part1; int a_ns1;
+    const float* a_part2; int a_ns2;
+    const float* a_gamma; const float* a_beta;
+    int a_groups; float a_eps;
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);

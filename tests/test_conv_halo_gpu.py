@@ -39,9 +39,12 @@ def test_halo_conv_plain(rec, B, H, W, Cin, Cout, sk):
     close(from_nhwc(out, B, H, W), conv_ref(x, w, b), what=f"halo conv {B}x{Cin}->{Cout}@{H}x{W} sk={sk}")
 
 
+@pytest.mark.parametrize("finalize", ["launch", "in_kernel"])
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout,sk,silu", [(2, 16, 16, 128, 0, 160, 1, True), (1, 8, 32, 64, 128, 320, 1, True),
-                                                       (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False)])
-def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, sk, silu):
+                                                       (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False),
+                                                       (1, 8, 16, 640, 320, 160, 3, True)])
+def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, sk, silu, finalize, monkeypatch):
+    monkeypatch.setenv("BC_GN_FINALIZE_IN_KERNEL_BYTES", "1000000")          # (the in-kernel finalize is opt-in)
     """GroupNorm statistics from a standalone pass -> bc_gn_finalize -> affine applied in the halo staging (zero padding AFTER the
     activation), two channel-concatenated sources, and the whole ResBlock epilogue: bias + time-embedding row vector + residual +
     BlobNet right-half residual + GroupNorm partials of the output."""
@@ -58,13 +61,19 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, s
 
     def fn():
         t1, t2 = nhwc(x1), (nhwc(x2) if C2 else None)
-        ab = rec.gn_affine(t1, C1, t2, C2, B, HW, G, 1e-5, gamma.cuda(), beta.cuda())
-        kw = dict(A2=t2, C1=C1, lda2=C2) if C2 else {}
+        if finalize == "launch":
+            kw = dict(a_affine=rec.gn_affine(t1, C1, t2, C2, B, HW, G, 1e-5, gamma.cuda(), beta.cuda()))
+        else:                                # GroupNorm finalize inside the convolution's prologue (no bc_gn_finalize launch)
+            kw = dict(a_gn=dict(x1=t1, C1=C1, x2=t2, C2=C2, B=B, HW=HW, G=G, eps=1e-5, gamma=gamma.cuda(), beta=beta.cuda()))
+        if C2:
+            kw.update(A2=t2, C1=C1, lda2=C2)
         out = rec.gemm(A=t1, lda=C1, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
                        conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=HW, tile_cfg=_lib.TILE_HALO,
-                       splitk=sk, a_affine=ab, a_act=_lib.ACT_SILU if silu else _lib.ACT_NONE, rowvec=h(temb), ld_rowvec=Cout,
+                       splitk=sk, a_act=_lib.ACT_SILU if silu else _lib.ACT_NONE, rowvec=h(temb), ld_rowvec=Cout,
                        R=nhwc(R), ldr=Cout, R2=nhwc(R2), ldr2=Cout, r2_xmin=W - H if W > H else 0, r2_bmod=1, out_w=W, want_gn=True,
                        **kw)
+        if finalize == "in_kernel":
+            assert "gnfin" in rec.seg.meta[-1]["variant"], rec.seg.meta[-1]["variant"]
         return out, rec.parts[out.data_ptr()]
     out, (part, nslab) = run(rec, fn)
     xh = xcat.half().float()

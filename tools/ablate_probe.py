@@ -45,13 +45,16 @@ def main():
         seg.run(s, side)
     base = timeit(lambda: run(full))
     print(f"full step: {base:.3f} ms")
-    groups = {"attention": ("attention",), "groupnorm": ("groupnorm", "groupnorm_fused_stats"), "layernorm": ("layernorm",),
+    groups = {"attention": ("attention",), "groupnorm": ("groupnorm", "groupnorm_fused_stats", "gn_finalize"), "layernorm": ("layernorm",),
+              "gn_finalize only": ("gn_finalize",), "transformer (all but attention)": ("layernorm", "ff", "qkv", "attn_out"),
+              "self-attn L0 only": ("attention@8192",), "everything but conv3x3": ("attention", "groupnorm", "groupnorm_fused_stats",
+              "gn_finalize", "layernorm", "ff", "qkv", "attn_out", "conv1x1", "zero_conv"),
               "ff": ("ff",), "conv3x3+conv_in+up/down": ("conv3x3", "conv_in", "upsample", "downsample", "conv_out"),
               "qkv+attn_out": ("qkv", "attn_out"), "conv1x1": ("conv1x1",), "zero_conv": ("zero_conv",), "temb": ("temb",)}
     for name, ks in groups.items():
         seg = Segment("ablate")
         for fn, sid, m in zip(full.calls, full.sids, full.meta):
-            if m["kind"] in ks:
+            if m["kind"] in ks or ("attention@8192" in ks and m["kind"] == "attention" and m["shape"][3] == 8192 and m["shape"][4] == 8192):
                 continue
             seg.calls.append(fn); seg.sids.append(sid); seg.meta.append(m)
         n_removed = len(full.calls) - len(seg.calls)
