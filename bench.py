@@ -153,15 +153,10 @@ def roofline(pipe, plan, res=512, batch=1):
     s = pipe.stream.cuda_stream
     with torch.cuda.stream(pipe.stream):
         plan.step_idx.zero_()
-    g = plan.step_active.graph
-    plan.step_active.graph = None
-    try:
-        plan.step_active.run(s)                  # warm (eager)
-        with torch.cuda.stream(pipe.stream):
-            plan.step_idx.zero_()
-        timed = plan.step_active.run_timed(s)
-    finally:
-        plan.step_active.graph = g
+    plan.step_active.run(s)                      # warm
+    with torch.cuda.stream(pipe.stream):
+        plan.step_idx.zero_()
+    timed = plan.step_active.run_timed(s)        # serial eager replay of the launch list, one HIP event pair per launch
     pipe.stream.synchronize()
     by = {}
     for m, ms in timed:

@@ -81,6 +81,25 @@ _SIGNATURES = {
     "bc_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "bc_add_cls_pos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    # ---- plan runtime (plan.hip)
+    "bc_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "bc_plan_destroy": (C.c_int, [C.c_void_p]),
+    "bc_plan_segment": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "bc_plan_find_segment": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "bc_plan_new_event": (C.c_int, [C.c_void_p]),
+    "bc_plan_add_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(BcGemm)]),
+    "bc_plan_add_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
+    "bc_plan_set_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bc_plan_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "bc_plan_num_launches": (C.c_int, [C.c_void_p, C.c_int]),
+    "bc_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
+    "bc_plan_capture": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
+    "bc_plan_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "bc_plan_capture_loop": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "bc_plan_run_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "bc_plan_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]),
+    "bc_plan_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bc_plan_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     "bc_graph_begin": (C.c_int, [C.c_void_p]),
     "bc_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -94,6 +113,26 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+# Recordable entry points of the plan runtime: name -> BC_OP_* code (include/blobctrl_hip.h).  The argument kinds of an op are derived
+# from its ctypes signature above (stream excluded): p pointer, i int, f float, l long long - the same strings plan.hip checks.
+OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused": 3, "bc_gn_apply": 4, "bc_layernorm": 5,
+       "bc_attention": 6, "bc_attention_causal": 7, "bc_assemble_input": 8, "bc_timestep_embedding": 9,
+       "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
+       "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
+       "bc_gaussian_sample": 19}
+OP_SIGNAL, OP_WAIT = 20, 21
+_KIND = {C.c_void_p: "p", C.c_int: "i", C.c_float: "f", C.c_longlong: "l", C.c_char_p: "p"}
+
+
+def op_signature(name):
+    """Argument kinds of a recordable entry point without its trailing stream argument."""
+    args = _SIGNATURES[name][1][:-1]
+    return "".join("p" if (a not in _KIND) else _KIND[a] for a in args)
+
+
+class BcPlanBuffer(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("address", C.c_void_p), ("bytes", C.c_longlong), ("host_data", C.c_void_p)]
 
 _lib = None
 

@@ -1,14 +1,16 @@
-"""Launch recorder: turns the hot path into a STATIC list of C-ABI kernel launches over pre-allocated device buffers.
+"""Plan compiler: turns the hot path into a STATIC list of C-ABI launches over pre-allocated device buffers.
 
-Every method allocates its output once (PyTorch is only the device allocator here), builds the ctypes argument block
-once, and appends a zero-argument-ish launch closure `fn(stream)` to the current segment.  Running a segment is a flat
-loop over closures; because buffers and argument blocks never change, a segment can be captured into a hipGraph
-(`Segment.capture`) and replayed with one `hipGraphLaunch`.
+Every Recorder method allocates its output once (PyTorch is only the device allocator here), builds the argument block once and
+appends ONE record to a segment of a `BcPlan` - the plan runtime of libblobctrl_hip (csrc/plan.hip, include/blobctrl_hip.h).
+Nothing of the replay is Python: `Segment.run` is one `bc_step` call (an eager loop over the records, or one `hipGraphLaunch` once
+the segment was captured), `Recorder.capture_loop` turns a whole sequence of segments (the N-step denoise loop) into ONE graph, and
+`Recorder.save` writes the relocatable `.bcplan` a plain C host can load and run (`bc_plan_load`).
 """
 import ctypes as C
 import json
 import os
-from typing import Callable, List, Optional
+import struct
+from typing import List, Optional
 
 import torch
 
@@ -18,6 +20,7 @@ from ._lib import BcGemm
 
 _TUNING_PATH = os.environ.get("BC_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
 _TUNING = None
+_M64 = (1 << 64) - 1
 
 
 def tuning_table():
@@ -35,140 +38,207 @@ def ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-class Segment:
-    """An ordered list of launches; replayable eagerly or as a hipGraph."""
+def _stream_array(stream, side=None, extra=()):
+    """Stream of every recorded stream id: 0 = `stream`, 1 = `side`, 2.. = `extra`; missing ones fall back to `stream`."""
+    ss = [stream, side if side is not None else stream] + [e if e is not None else stream for e in extra]
+    return (C.c_void_p * len(ss))(*ss), len(ss)
 
-    def __init__(self, name: str):
-        self.name = name
-        self.calls: List[Callable] = []
-        self.graph = None
+
+class Segment:
+    """An ordered list of launches inside a BcPlan; replayable eagerly or as a hipGraph."""
+
+    def __init__(self, rec: "Recorder", name: str):
+        self.rec, self.name = rec, name
+        self.id = rec.lib.bc_plan_segment(rec.plan, name.encode())
+        if self.id < 0:
+            _lib.check(1, "bc_plan_segment")
+        self.captured = False
         self.flops = 0          # algorithmic 2*MAC of the GEMM / attention launches recorded here
         self.kinds = {}
-        self.meta = []          # per call: dict(kind, flops, variant)
-        self.sids = []          # per call: 0 = main stream, 1 = side stream
+        self.meta = []          # per launch: dict(kind, flops, variant, shape, bytes, sid)
 
-    @staticmethod
-    def _streams(stream, side, extra):
-        """Stream of every recorded stream id: 0 = `stream`, 1 = `side`, 2.. = `extra`; missing ones fall back to `stream`."""
-        return (stream, side if side is not None else stream) + tuple(e if e is not None else stream for e in extra) + (stream,) * 4
+    def __len__(self):
+        return len(self.meta)
 
     def run(self, stream: int, side: int = None, extra=()):
         """Replay on `stream`; launches recorded for the side streams go to `side` / `extra` (default: same stream, i.e. serial)."""
-        if self.graph is not None:
-            _lib.check(_lib.load().bc_graph_launch(self.graph, stream), "bc_graph_launch")
-            return
-        streams = self._streams(stream, side, extra)
-        for fn, sid in zip(self.calls, self.sids):
-            fn(streams[sid])
+        arr, n = _stream_array(stream, side, extra)
+        rc = self.rec.lib.bc_step(self.rec.plan, self.id, arr, n)
+        if rc:
+            _lib.check(rc, f"bc_step({self.name})")
 
     def capture(self, stream: int, side: int = None, extra=()):
         """Capture this segment into a hipGraph on `stream` (a non-default stream).  Side-stream work joins the capture
         through the recorded fork / signal / wait events and becomes parallel branches of the graph."""
-        lib = _lib.load()
-        streams = self._streams(stream, side, extra)
-        _lib.check(lib.bc_graph_begin(stream), "bc_graph_begin")
+        arr, n = _stream_array(stream, side, extra)
+        _lib.check(self.rec.lib.bc_plan_capture(self.rec.plan, self.id, arr, n), f"bc_plan_capture({self.name})")
+        self.captured = True
+
+    def run_eager(self, stream: int, side: int = None, extra=()):
+        """Replay the launch list itself even when a graph exists (diagnostics)."""
+        if not self.captured:
+            return self.run(stream, side, extra)
+        self.release()
         try:
-            for fn, sid in zip(self.calls, self.sids):
-                fn(streams[sid])
+            self.run(stream, side, extra)
         finally:
-            g = C.c_void_p()
-            rc = lib.bc_graph_end(stream, C.byref(g))
-        _lib.check(rc, "bc_graph_end")
-        self.graph = g
+            self.capture(stream, side, extra) if stream else None
 
     def run_timed(self, stream: int):
-        """Eager replay with a HIP event pair around every launch (events are recorded on `stream`, the stream the
-        kernels run on).  Returns a list of (meta, milliseconds)."""
-        lib = _lib.load()
-        evs = []
-        for fn in self.calls:          # serial replay on ONE stream: isolates every kernel for the timing table
-            a, b = C.c_void_p(), C.c_void_p()
-            _lib.check(lib.bc_event_create(C.byref(a)), "bc_event_create")
-            _lib.check(lib.bc_event_create(C.byref(b)), "bc_event_create")
-            _lib.check(lib.bc_event_record(a, stream), "bc_event_record")
-            fn(stream)
-            _lib.check(lib.bc_event_record(b, stream), "bc_event_record")
-            evs.append((a, b))
-        out = []
-        for (a, b), m in zip(evs, self.meta):
-            ms = C.c_float()
-            _lib.check(lib.bc_event_elapsed_ms(a, b, C.byref(ms)), "bc_event_elapsed_ms")
-            out.append((m, ms.value))
-            lib.bc_event_destroy(a)
-            lib.bc_event_destroy(b)
-        return out
+        """Serial eager replay with a HIP event pair around every launch (recorded on `stream`, the stream the kernels run
+        on).  Returns a list of (meta, milliseconds)."""
+        n = len(self.meta)
+        ms = (C.c_float * max(1, n))()
+        _lib.check(self.rec.lib.bc_plan_run_timed(self.rec.plan, self.id, stream, ms), "bc_plan_run_timed")
+        return [(m, ms[i]) for i, m in enumerate(self.meta)]
+
+    def enable(self, index: int, on: bool):
+        """Diagnostics (ablation probes): skip / restore one launch; re-capture afterwards."""
+        _lib.check(self.rec.lib.bc_plan_enable(self.rec.plan, self.id, index, 1 if on else 0), "bc_plan_enable")
 
     def release(self):
-        if self.graph is not None:
-            _lib.load().bc_graph_destroy(self.graph)
-            self.graph = None
+        if self.captured:
+            self.rec.lib.bc_plan_release(self.rec.plan, self.id)
+            self.captured = False
 
 
 class Recorder:
     def __init__(self, device: torch.device):
         self.lib = _lib.load()
-        self.device = device
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        _lib.check(self.lib.bc_plan_create(C.byref(h)), "bc_plan_create")
+        self.plan = h
         self.seg: Optional[Segment] = None
-        self.keep = []                      # keeps ctypes blocks / tensors alive
+        self.segments: List[Segment] = []
+        self.keep = []                      # keeps tensors referenced by the records alive
+        self._workspace = set()
+        self._storages = {}                 # storage address -> uint8 view of every storage the records point into (memory map)
+        self.named = {}                     # name -> tensor (I/O buffers a C host looks up with bc_plan_buffer)
         self._slab = {}                     # split-K scratch PER STREAM id (the branches run concurrently)
         self._slab_elems = {}
-        info = (C.c_int * 4)()
-        _lib.check(self.lib.bc_device_info(info), "bc_device_info")
-        self.num_cu = info[0]
+        self.num_cu = 256
+        if self.device.type == "cuda":
+            info = (C.c_int * 4)()
+            _lib.check(self.lib.bc_device_info(info), "bc_device_info")
+            self.num_cu = info[0]
         self.bytes_allocated = 0
         self.parts = {}                     # data_ptr of a GEMM output -> (per-channel GroupNorm partials, nslab)
         self.sid = 0                        # stream id new launches are recorded for (0 main, 1 side)
         self.events = []
+        self.loop_graphs = []
+
+    def close(self):
+        """Destroy the plan (graphs, events).  Buffers are torch tensors and go with the recorder."""
+        if self.plan is not None:
+            for g in self.loop_graphs:
+                self.lib.bc_graph_destroy(g)
+            self.loop_graphs = []
+            self.lib.bc_plan_destroy(self.plan)
+            self.plan = None
 
     # ------------------------------------------------------------------ buffers
-    def empty(self, *shape, dtype=torch.float16):
-        t = torch.empty(*shape, dtype=dtype, device=self.device)
+    def empty(self, *shape, dtype=torch.float16, name=None):
+        return self._track(torch.empty(*shape, dtype=dtype, device=self.device), name)
+
+    def zeros(self, *shape, dtype=torch.float16, name=None):
+        return self._track(torch.zeros(*shape, dtype=dtype, device=self.device), name)
+
+    def _track(self, t, name=None):
         self.bytes_allocated += t.numel() * t.element_size()
+        self._workspace.add(t.untyped_storage().data_ptr())        # the plan's own activations / per-edit inputs: no contents saved
+        return self.register(t, name)
+
+    def register(self, t: torch.Tensor, name=None):
+        """Put the STORAGE behind a tensor (a fresh allocation, a weight arena a view points into, a table) on the plan's memory map,
+        so that `save` can express every pointer of the launch records as (buffer, offset).  Called for every tensor a record uses."""
+        if t is not None and torch.is_tensor(t):
+            st = t.untyped_storage()
+            key = st.data_ptr()
+            if key not in self._storages and st.nbytes() > 0:
+                self._storages[key] = torch.empty(0, dtype=torch.uint8, device=t.device).set_(st)
+            if name:
+                self.named[name] = t
         return t
 
-    def zeros(self, *shape, dtype=torch.float16):
-        t = torch.zeros(*shape, dtype=dtype, device=self.device)
-        self.bytes_allocated += t.numel() * t.element_size()
-        return t
+    @property
+    def buffers(self):
+        return list(self._storages.values())
 
     def begin(self, name: str) -> Segment:
-        self.seg = Segment(name)
+        self.seg = Segment(self, name)
+        self.segments.append(self.seg)
         return self.seg
 
     # ------------------------------------------------------------------ streams / events
     def new_event(self):
-        e = C.c_void_p()
-        _lib.check(self.lib.bc_event_create_sync(C.byref(e)), "bc_event_create_sync")
+        e = self.lib.bc_plan_new_event(self.plan)
+        if e < 0:
+            _lib.check(1, "bc_plan_new_event")
         self.events.append(e)
         return e
 
     def signal(self, ev):
         """Record `ev` on the stream currently being recorded for."""
-        lib = self.lib
-
-        def fn(stream):
-            rc = lib.bc_event_record(ev, stream)
-            if rc:
-                _lib.check(rc, "bc_event_record")
-        self._push(fn, "event_record")
+        self._add_op(_lib.OP_SIGNAL, "i", (ev,), "event_record")
 
     def wait(self, ev):
         """Make the stream currently being recorded for wait on `ev`."""
-        lib = self.lib
+        self._add_op(_lib.OP_WAIT, "i", (ev,), "event_wait")
 
-        def fn(stream):
-            rc = lib.bc_stream_wait_event(stream, ev)
-            if rc:
-                _lib.check(rc, "bc_stream_wait_event")
-        self._push(fn, "event_wait")
+    def _add_op(self, op, sig, args, kind, flops=0, variant="", shape=None, bytes_=0):
+        assert len(sig) == len(args), (op, sig, args)
+        words = (C.c_uint64 * max(1, len(args)))()
+        for k, (c, v) in enumerate(zip(sig, args)):
+            if c == "p":
+                words[k] = 0 if v is None else (self.register(v).data_ptr() if torch.is_tensor(v) else int(v))
+            elif c == "f":
+                words[k] = struct.unpack("<I", struct.pack("<f", float(v)))[0]
+            else:
+                words[k] = int(v) & _M64
+        idx = self.lib.bc_plan_add_op(self.plan, self.seg.id, self.sid, op, words, len(args))
+        if idx < 0 or idx != len(self.seg.meta):
+            _lib.check(1, f"bc_plan_add_op({kind})")
+        self._push(kind, flops, variant, shape, bytes_)
 
-    def _push(self, fn, kind, flops=0, variant="", shape=None, bytes_=0):
-        self.seg.calls.append(fn)
-        self.seg.sids.append(self.sid)
+    def _push(self, kind, flops=0, variant="", shape=None, bytes_=0):
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
         # bytes_ = algorithmic HBM bytes of an HBM-bound launch (each activation read once + written once, fp16)
-        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape, bytes=bytes_))
+        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape, bytes=bytes_, sid=self.sid))
+
+    def capture_loop(self, segments, stream, side=None, extra=()):
+        """ONE hipGraph for a whole sequence of segments (e.g. prologue + the N denoise steps); returns the graph handle for
+        `bc_graph_launch`.  Per-step scalars are read through the device step counter, so the replay takes no arguments."""
+        ids = (C.c_int * len(segments))(*[sg.id for sg in segments])
+        arr, n = _stream_array(stream, side, extra)
+        g = C.c_void_p()
+        _lib.check(self.lib.bc_plan_capture_loop(self.plan, ids, len(segments), arr, n, C.byref(g)), "bc_plan_capture_loop")
+        self.loop_graphs.append(g)
+        return g
+
+    def save(self, path: str):
+        """Write the relocatable plan file: buffer table (named I/O buffers, weights / tables with their contents, zero-filled
+        workspace) + launch records with (buffer, offset) pointers.  Loaded by `bc_plan_load` (C hosts: tests/c/plan_edit.c)."""
+        for t in self._slab.values():
+            self.register(t)
+        bufs = self.buffers
+        names = {}
+        for n, t in self.named.items():
+            assert t.data_ptr() == t.untyped_storage().data_ptr(), f"named buffer {n} must own its storage"
+            names[t.data_ptr()] = n
+        arr = (_lib.BcPlanBuffer * len(bufs))()
+        hold = []
+        for i, t in enumerate(bufs):
+            nbytes = t.numel() * t.element_size()
+            arr[i].name = names.get(t.data_ptr(), "").encode()
+            arr[i].address = t.data_ptr()
+            arr[i].bytes = nbytes
+            if nbytes and t.data_ptr() not in self._workspace:         # weights, tables, constants: stored with their contents
+                host = t.detach().cpu().contiguous()
+                hold.append(host)
+                arr[i].host_data = host.data_ptr()
+        _lib.check(self.lib.bc_plan_save(self.plan, path.encode(), arr, len(bufs)), "bc_plan_save")
 
     def reserve_slab(self, elems: int):
         """Shared split-K scratch of the CURRENT stream: consumed by the reduce kernel that immediately follows on that
@@ -176,7 +246,9 @@ class Recorder:
         sid = self.sid
         if elems > self._slab_elems.get(sid, 0):
             self._slab[sid] = torch.empty(elems, dtype=torch.float32, device=self.device)
+            self._workspace.add(self._slab[sid].untyped_storage().data_ptr())
             self._slab_elems[sid] = elems
+            _lib.check(self.lib.bc_plan_set_slab(self.plan, sid, self._slab[sid].data_ptr()), "bc_plan_set_slab")
 
     # ------------------------------------------------------------------ GEMM family
     def plan_gemm(self, M, N, K, fast, mode, tile_cfg=0, splitk=None):
@@ -264,6 +336,8 @@ class Recorder:
                     g.a_part1, g.a_ns1, g.a_part2, g.a_ns2 = ptr(pa1), ns1, ptr(pa2), ns2
                     g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), G_, a_gn["eps"]
                     self.keep.append((pa1, pa2, a_gn["gamma"], a_gn["beta"]))
+                    for t in (pa1, pa2, a_gn["gamma"], a_gn["beta"]):
+                        self.register(t)
                     mode = "halo_gnfin"
                 else:
                     a_affine = self.gn_affine(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"], G_, a_gn["eps"],
@@ -290,73 +364,25 @@ class Recorder:
                 g.gn_part = part.data_ptr()
                 self.parts[g.C] = (part, nslab)
 
-        sid = self.sid
-
-        def fn(stream, g=g, lib=self.lib):
-            if g.splitk > 1:
-                g.slab = rec._slab[sid].data_ptr()
-            rc = lib.bc_gemm(C.byref(g), stream)
-            if rc:
-                _lib.check(rc, "bc_gemm")
-
-        self.keep.append((g, A, A2, W, out, bias, R, R2, rowvec, colscale, alpha_dev, alpha_idx, part, a_affine))
+        idx = self.lib.bc_plan_add_gemm(self.plan, self.seg.id, self.sid, C.byref(g))
+        if idx < 0 or idx != len(self.seg.meta):
+            _lib.check(1, "bc_plan_add_gemm")
+        refs = (A, A2, W, out, bias, R, R2, rowvec, rowvec_idx, colscale, alpha_dev, alpha_idx, part, a_affine)
+        self.keep.append(refs)
+        for t in refs:
+            self.register(t)
         variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
-        self._push(fn, kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
+        self._push(kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out=None):
-        """GroupNorm(+SiLU) of the channel-concat (x1 | x2).  Per-channel partial statistics are taken from the producing
-        GEMM's epilogue when it emitted them (self.parts), otherwise a standalone bc_gn_stats pass is recorded."""
-        lib = self.lib
-        c2 = C2 if x2 is not None else 0
-        Cc = C1 + c2
-        ab = self.empty(B, Cc, 2, dtype=torch.float32)
-        if out is None:
-            out = self.empty(B, HW, Cc)
-        stats_calls = []
-        srcs = []
-        for x, c in ((x1, C1), (x2, c2)):
-            if x is None:
-                srcs.append((None, 0))
-                continue
-            hit = self.parts.get(x.data_ptr())
-            if hit is not None and hit[0].shape[2] == c:
-                srcs.append((hit[0], hit[1]))
-            else:
-                nslab = (HW + 127) // 128
-                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
-                stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
-                srcs.append((part, nslab))
-        (pa1, ns1), (pa2, ns2) = srcs
-        p1, p2, pab, pg, pb, po = ptr(x1), ptr(x2), ptr(ab), ptr(gamma), ptr(beta), ptr(out)
-        pp1, pp2 = ptr(pa1), ptr(pa2)
-        fused = not os.environ.get("BC_GN_UNFUSED") and Cc // G <= 96          # (the fused kernel's LDS staging holds <= 256 channels)
-
-        def fn(stream):
-            rc = 0
-            for (px, c, pp, ns) in stats_calls:
-                rc = rc or lib.bc_gn_stats(px, c, B, HW, pp, ns, stream)
-            if fused:
-                rc = rc or lib.bc_gn_apply_fused(pp1, ns1, C1, pp2, ns2, c2, p1, p2, B, HW, G, eps, pg, pb, 1 if silu else 0, po,
-                                                 stream)
-            else:
-                rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
-                rc = rc or lib.bc_gn_apply(p1, C1, p2, c2, B, HW, pab, 1 if silu else 0, po, stream)
-            if rc:
-                _lib.check(rc, "groupnorm")
-
-        self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta, out))
-        nbytes = 2 * B * HW * Cc * 2 + sum(B * HW * c * 2 for (_, c, _, _) in stats_calls)     # stats pass re-reads its source
-        self._push(fn, "groupnorm" + ("" if stats_calls else "_fused_stats"), variant="gn_apply_fused_kernel",
-                   shape=("gn", B, HW, Cc), bytes_=nbytes)
-        return out
+    def _op(self, name, args, kind, **meta):
+        self._add_op(_lib.OPS[name], _lib.op_signature(name), args, kind, **meta)
 
     def gn_sources(self, x1, C1, x2, C2, B, HW):
         """Per-channel partial statistics of (x1 | x2): the producers' epilogue partials when they exist, else a recorded
         bc_gn_stats pass.  Returns ((part1, nslab1), (part2, nslab2))."""
-        lib = self.lib
         srcs = []
         for x, c in ((x1, C1), (x2, C2 if x2 is not None else 0)):
             if x is None:
@@ -368,99 +394,73 @@ class Recorder:
             else:
                 nslab = (HW + 127) // 128
                 part = self.empty(B, nslab, c, 2, dtype=torch.float32)
-                px, pp = x.data_ptr(), part.data_ptr()
-
-                def fn(stream, px=px, c=c, pp=pp, nslab=nslab):
-                    rc = lib.bc_gn_stats(px, c, B, HW, pp, nslab, stream)
-                    if rc:
-                        _lib.check(rc, "bc_gn_stats")
                 self.keep.append((x, part))
-                self._push(fn, "gn_stats", variant="gn_stats_kernel", shape=("gn_stats", B, HW, c), bytes_=B * HW * c * 2)
+                self._op("bc_gn_stats", (x, c, B, HW, part, nslab), "gn_stats", variant="gn_stats_kernel",
+                         shape=("gn_stats", B, HW, c), bytes_=B * HW * c * 2)
                 self.parts[x.data_ptr()] = (part, nslab)
                 srcs.append((part, nslab))
         return tuple(srcs)
+
+    def groupnorm(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out=None):
+        """GroupNorm(+SiLU) of the channel-concat (x1 | x2) as its own pass.  Per-channel partial statistics are taken from the
+        producing GEMM's epilogue when it emitted them (self.parts), otherwise a standalone bc_gn_stats pass is recorded."""
+        c2 = C2 if x2 is not None else 0
+        Cc = C1 + c2
+        if out is None:
+            out = self.empty(B, HW, Cc)
+        n_before = len(self.seg.meta)
+        (pa1, ns1), (pa2, ns2) = self.gn_sources(x1, C1, x2, c2, B, HW)
+        own_stats = len(self.seg.meta) > n_before
+        fused = not os.environ.get("BC_GN_UNFUSED") and Cc // G <= 96          # (the fused kernel's LDS staging holds <= 256 channels)
+        self.keep.append((x1, x2, pa1, pa2, gamma, beta, out))
+        kind = "groupnorm" + ("" if own_stats else "_fused_stats")
+        if fused:
+            self._op("bc_gn_apply_fused", (pa1, ns1, C1, pa2, ns2, c2, x1, x2, B, HW, G, eps, gamma, beta, 1 if silu else 0, out), kind,
+                     variant="gn_apply_fused_kernel", shape=("gn", B, HW, Cc), bytes_=2 * B * HW * Cc * 2)
+        else:
+            ab = self.empty(B, Cc, 2, dtype=torch.float32)
+            self.keep.append(ab)
+            self._op("bc_gn_finalize", (pa1, ns1, C1, pa2, ns2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
+                     variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc))
+            self._op("bc_gn_apply", (x1, C1, x2, c2, B, HW, ab, 1 if silu else 0, out), kind, variant="gn_apply_kernel",
+                     shape=("gn", B, HW, Cc), bytes_=2 * B * HW * Cc * 2)
+        return out
 
     def gn_affine(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta):
         """Per-(image, channel) affine (rstd*gamma, beta - mean*rstd*gamma) of GroupNorm over the channel-concat (x1 | x2), from the
         producers' per-channel partial statistics: ab [B][C1+C2][2] fp32.  The consumer convolution applies it (and SiLU) while it
         stages its input halo (BcGemm.a_affine), so the normalised activation never goes through HBM."""
-        lib = self.lib
         c2 = C2 if x2 is not None else 0
         Cc = C1 + c2
         ab = self.empty(B, Cc, 2, dtype=torch.float32)
-        stats_calls, srcs = [], []
-        for x, c in ((x1, C1), (x2, c2)):
-            if x is None:
-                srcs.append((None, 0))
-                continue
-            hit = self.parts.get(x.data_ptr())
-            if hit is not None and hit[0].shape[2] == c:
-                srcs.append((hit[0], hit[1]))
-            else:
-                nslab = (HW + 127) // 128
-                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
-                stats_calls.append((x.data_ptr(), c, part.data_ptr(), nslab))
-                srcs.append((part, nslab))
-        (pa1, ns1), (pa2, ns2) = srcs
-        pp1, pp2, pab, pg, pb = ptr(pa1), ptr(pa2), ptr(ab), ptr(gamma), ptr(beta)
-
-        def fn(stream):
-            rc = 0
-            for (px, c, pp, ns) in stats_calls:
-                rc = rc or lib.bc_gn_stats(px, c, B, HW, pp, ns, stream)
-            rc = rc or lib.bc_gn_finalize(pp1, ns1, C1, pp2, ns2, c2, B, HW, G, eps, pg, pb, pab, stream)
-            if rc:
-                _lib.check(rc, "gn_affine")
-
+        (pa1, ns1), (pa2, ns2) = self.gn_sources(x1, C1, x2, c2, B, HW)
         self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta))
-        self._push(fn, "gn_finalize", variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc),
-                   bytes_=sum(B * HW * c * 2 for (_, c, _, _) in stats_calls))
+        self._op("bc_gn_finalize", (pa1, ns1, C1, pa2, ns2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
+                 variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc))
         return ab
 
     def layernorm(self, x, rows, Cc, gamma, beta, eps, out=None, ldx=None, ldy=None):
-        lib = self.lib
         if out is None:
             out = self.empty(rows, Cc)
-        px, pg, pb, po = ptr(x), ptr(gamma), ptr(beta), ptr(out)
-        ldx = ldx or Cc
-        ldy = ldy or Cc
-
-        def fn(stream):
-            rc = lib.bc_layernorm(px, rows, Cc, ldx, pg, pb, eps, po, ldy, stream)
-            if rc:
-                _lib.check(rc, "bc_layernorm")
-
         self.keep.append((x, gamma, beta, out))
-        self._push(fn, "layernorm", variant="layernorm_kernel", shape=("ln", rows, Cc), bytes_=2 * rows * Cc * 2)
+        self._op("bc_layernorm", (x, rows, Cc, ldx or Cc, gamma, beta, eps, out, ldy or Cc), "layernorm", variant="layernorm_kernel",
+                 shape=("ln", rows, Cc), bytes_=2 * rows * Cc * 2)
         return out
 
     # ------------------------------------------------------------------ attention
     def attention(self, Q, K, Vt, out, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale,
                   q_off=0, k_off=0, causal=False):
-        lib = self.lib
-        entry = lib.bc_attention_causal if causal else lib.bc_attention
-        pq = Q.data_ptr() + q_off * 2
-        pk = K.data_ptr() + k_off * 2
-        pv, po = ptr(Vt), ptr(out)
-
-        def fn(stream):
-            rc = entry(pq, pk, pv, po, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, stream)
-            if rc:
-                _lib.check(rc, "bc_attention")
-
         self.keep.append((Q, K, Vt, out))
-        self._push(fn, "attention", 4 * B * heads * Nq * Nkv * d, f"attn_fwd_kernel<{d}>", (B, heads, d, Nq, Nkv))
+        self._op("bc_attention_causal" if causal else "bc_attention",
+                 (Q.data_ptr() + q_off * 2, K.data_ptr() + k_off * 2, Vt, out, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs,
+                  obs, scale), "attention", flops=4 * B * heads * Nq * Nkv * d, variant=f"attn_fwd_kernel<{d}>",
+                 shape=(B, heads, d, Nq, Nkv))
         return out
 
     # ------------------------------------------------------------------ glue
     def call(self, name, *args, kind=None, keep=()):
-        """Record a generic `bc_<name>(*args, stream)` launch with pre-marshalled arguments."""
-        f = getattr(self.lib, name)
-
-        def fn(stream):
-            rc = f(*args, stream)
-            if rc:
-                _lib.check(rc, name)
-
+        """Record a generic `bc_<name>(*args, stream)` launch (any entry point listed in _lib.OPS)."""
         self.keep.append(keep)
-        self._push(fn, kind or name)
+        for t in keep if isinstance(keep, (tuple, list)) else (keep,):
+            self.register(t)
+        self._op(name, args, kind or name)

@@ -74,11 +74,7 @@ class StableDiffusionBlobNetPipeline:
         while len(self._plans) >= self.max_cached_plans:              # evict the least recently used plan and its graphs
             old = self._plans.pop(next(iter(self._plans)))
             torch.cuda.synchronize(self.device)
-            for seg in (old.prologue, old.step_active, old.step_inactive):
-                seg.release()
-            for ev in old.rec.events:
-                self.lib.bc_event_destroy(ev)
-            old.rec.events = []
+            old.rec.close()                                           # graphs and events of the evicted plan
         dev = self.device
         rec = Recorder(dev)
         P = type("Plan", (), {})()
@@ -162,15 +158,8 @@ class StableDiffusionBlobNetPipeline:
             else:
                 eps = plan.record_forward(P.unet_in, residuals)
             P.eps = eps
-            g = P.guidance
-
-            def step_fn(stream, lib=rec.lib):
-                rc = lib.bc_cfg_scheduler_step(eps.data_ptr(), P.latents.data_ptr(), P.coef.data_ptr(),
-                                               P.step_idx.data_ptr(), P.hist.data_ptr(), -1.0, B, h, w,
-                                               P.eps_guided.data_ptr(), 1, stream)
-                if rc:
-                    _lib.check(rc, "bc_cfg_scheduler_step")
-            rec._push(step_fn, "cfg_step")
+            rec.call("bc_cfg_scheduler_step", eps, P.latents, P.coef, P.step_idx, P.hist, -1.0, B, h, w, P.eps_guided, 1,
+                     kind="cfg_step")
 
         # ---- step A: BlobNet + UNet
         # The BlobNet branch is recorded for the side stream: fork (side waits for the start of the step on main), every

@@ -262,6 +262,57 @@ int bc_event_record(void* ev, bc_stream stream);
 int bc_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int bc_event_destroy(void* ev);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Plan runtime (plan.hip): the loop body of StableDiffusionBlobNetPipeline.__call__ (pipeline_blobnet.py:1025-1123: BlobNet forward,
+ * patched UNet forward, crop + CFG, scheduler step) - or any other forward pass of this library - as a STATIC list of launches that
+ * is compiled once per (batch, canvas, steps) configuration and replayed without Python in the loop.
+ *   build   : bc_plan_create -> bc_plan_segment ("prologue", "step_active", "step_inactive", ...) -> bc_plan_add_gemm / bc_plan_add_op
+ *             (stream_id 0 = main stream, 1.. = side streams; BC_OP_SIGNAL / BC_OP_WAIT on plan events express the dependencies
+ *             between them and become DAG edges when captured) -> bc_plan_set_slab (split-K scratch per stream id)
+ *   run     : bc_step replays one segment on the caller's streams (its captured hipGraph when bc_plan_capture was called, else
+ *             eagerly); bc_plan_capture_loop captures a whole sequence of segments (the N-step denoise loop) into ONE graph, replayed
+ *             with bc_graph_launch; per-step scalars come from device tables indexed by a device-side step counter, so the replay
+ *             needs no host arguments.
+ *   persist : bc_plan_save writes a relocatable plan (every pointer = (buffer, offset) of the caller-declared buffer table, with
+ *             the initial contents of weights / tables); bc_plan_load allocates one arena, uploads, patches the records; a plain C
+ *             host then runs an edit: bc_plan_buffer to find the I/O buffers, bc_step / bc_plan_capture_loop (tests/c/plan_edit.c).
+ * streams == NULL / nstreams == 0 makes the plan use three streams of its own.
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct BcPlan BcPlan;
+enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY_FUSED = 3, BC_OP_GN_APPLY = 4, BC_OP_LAYERNORM = 5,
+       BC_OP_ATTENTION = 6, BC_OP_ATTENTION_CAUSAL = 7, BC_OP_ASSEMBLE_INPUT = 8, BC_OP_TIMESTEP_EMBEDDING = 9,
+       BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
+       BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
+       BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_COUNT = 22 };
+typedef struct BcPlanBuffer {
+    const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
+    const void* address;     /* the address the launch records were built against */
+    long long   bytes;
+    const void* host_data;   /* initial contents to store in the file (weights, tables) or NULL = zero-filled workspace */
+} BcPlanBuffer;
+
+int bc_plan_create(BcPlan** out);
+int bc_plan_destroy(BcPlan* plan);
+int bc_plan_segment(BcPlan* plan, const char* name);                       /* -> segment id, < 0 on error */
+int bc_plan_find_segment(BcPlan* plan, const char* name);                  /* -> segment id or -1 */
+int bc_plan_new_event(BcPlan* plan);                                       /* -> event id, < 0 on error */
+int bc_plan_add_gemm(BcPlan* plan, int seg, int stream_id, const BcGemm* g);             /* -> launch index; `slab` is taken from
+                                                                                          * bc_plan_set_slab(stream_id) at run time */
+/* args: the entry point's arguments in order WITHOUT the stream, one 64-bit word each (pointers as addresses, ints sign-extended,
+ * floats as their 32-bit pattern); BC_OP_SIGNAL / BC_OP_WAIT take the event id. -> launch index */
+int bc_plan_add_op(BcPlan* plan, int seg, int stream_id, int op, const uint64_t* args, int nargs);
+int bc_plan_set_slab(BcPlan* plan, int stream_id, float* slab);
+int bc_plan_enable(BcPlan* plan, int seg, int index, int enabled);         /* diagnostics: skip / restore one launch (ablation probes) */
+int bc_plan_num_launches(BcPlan* plan, int seg);
+int bc_step(BcPlan* plan, int seg, const bc_stream* streams, int nstreams);
+int bc_plan_capture(BcPlan* plan, int seg, const bc_stream* streams, int nstreams);
+int bc_plan_release(BcPlan* plan, int seg);                                /* drop the segment's graph (back to eager replay) */
+int bc_plan_capture_loop(BcPlan* plan, const int* seg_sequence, int n, const bc_stream* streams, int nstreams, void** graph_exec_out);
+int bc_plan_run_timed(BcPlan* plan, int seg, bc_stream stream, float* ms_out /* [bc_plan_num_launches] */);
+int bc_plan_save(BcPlan* plan, const char* path, const BcPlanBuffer* buffers, int nbuffers);
+int bc_plan_load(const char* path, BcPlan** out);
+int bc_plan_buffer(BcPlan* plan, const char* name, void** ptr, long long* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,6 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench                                                        # noqa: E402
-from blobctrl_amd.launch import Segment                             # noqa: E402
 
 
 def timeit(fn, n=15):
@@ -52,18 +51,20 @@ def main():
               "ff": ("ff",), "conv3x3+conv_in+up/down": ("conv3x3", "conv_in", "upsample", "downsample", "conv_out"),
               "qkv+attn_out": ("qkv", "attn_out"), "conv1x1": ("conv1x1",), "zero_conv": ("zero_conv",), "temb": ("temb",)}
     for name, ks in groups.items():
-        seg = Segment("ablate")
-        for fn, sid, m in zip(full.calls, full.sids, full.meta):
-            if m["kind"] in ks or ("attention@8192" in ks and m["kind"] == "attention" and m["shape"][3] == 8192 and m["shape"][4] == 8192):
-                continue
-            seg.calls.append(fn); seg.sids.append(sid); seg.meta.append(m)
-        n_removed = len(full.calls) - len(seg.calls)
-        run(seg)
+        off = [i for i, m in enumerate(full.meta)
+               if m["kind"] in ks or ("attention@8192" in ks and m["kind"] == "attention" and m["shape"][3] == 8192 and m["shape"][4] == 8192)]
+        for i in off:
+            full.enable(i, False)
+        full.release()
+        run(full)
         torch.cuda.synchronize()
-        seg.capture(s, side)
-        t = timeit(lambda: run(seg))
-        print(f"without {name:26s} ({n_removed:3d} launches): {t:7.3f} ms  -> marginal cost {base - t:6.3f} ms", flush=True)
-        seg.release()
+        full.capture(s, side)
+        t = timeit(lambda: run(full))
+        print(f"without {name:26s} ({len(off):3d} launches): {t:7.3f} ms  -> marginal cost {base - t:6.3f} ms", flush=True)
+        for i in off:
+            full.enable(i, True)
+    full.release()
+    full.capture(s, side)
 
 
 if __name__ == "__main__":

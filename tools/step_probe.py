@@ -48,7 +48,7 @@ def main():
             seg.run(s, side, pipe._extra())
         print(f"one_stream={one_stream}: active step {timeit(lambda: run(P.step_active)):.3f} ms, "
               f"inactive (UNet only) {timeit(lambda: run(P.step_inactive)):.3f} ms; launches active "
-              f"{len(P.step_active.calls)} inactive {len(P.step_inactive.calls)}", flush=True)
+              f"{len(P.step_active)} inactive {len(P.step_inactive)}", flush=True)
         del pipe, P
         if not os.environ.get("PROBE_NO_GC"):
             import gc
