@@ -288,7 +288,7 @@ def main():
         return stub_worker(args)
 
     from blobctrl_amd import dist as bdist
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from blobctrl_amd.splat import splat_features
     from blobctrl_amd.weights import PackedTrunk
     import torch.distributed as tdist
@@ -314,7 +314,7 @@ def main():
     pw_u = bdist.broadcast_packed(build_unet, dev)          # rank 0 packs, RCCL broadcast over xGMI to the others
     pw_b = bdist.broadcast_packed(build_blob, dev)
     t_weights = time.perf_counter() - t0
-    pipe = StableDiffusionBlobNetPipeline(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=args.scheduler)
+    pipe = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=args.scheduler)
     inp = synth_inputs(h, w, batch=args.batch)
     inp_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}     # inputs resident in HBM
     score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device=str(dev))   # HIP rasteriser

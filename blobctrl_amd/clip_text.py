@@ -9,7 +9,7 @@ and the residual adds are GEMM epilogues.  Tokenisation stays on the host (calle
 import torch
 
 from . import _lib
-from .launch import Recorder
+from .launch import Recorder, run_graphed
 
 
 class CLIPTextModel:
@@ -116,5 +116,5 @@ class CLIPTextModel:
         if clip_skip not in P.final:
             raise ValueError(f"clip_skip={clip_skip} not supported (0 < clip_skip < min(layers, 4))")
         P.ids.copy_(input_ids.to(self.device, torch.int64))
-        P.seg.run(torch.cuda.current_stream().cuda_stream)
+        run_graphed(P.seg, self.device)
         return (P.final[clip_skip].view(B, T, self.D).clone(),)

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .launch import Recorder
+from .launch import Recorder, run_graphed
 from .weights import pad8
 
 
@@ -131,7 +131,7 @@ class Dinov2Model:
             raise ValueError("pixel_values must be [B,3,H,W] with H, W multiples of the patch size")
         P = self._plan(B, H, W)
         P.pixels.copy_(pixel_values.to(self.device, torch.float32))
-        P.seg.run(torch.cuda.current_stream().cuda_stream)
+        run_graphed(P.seg, self.device)
         return P.pooled16.float()
 
     def __call__(self, pixel_values):

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .engine import Residuals, TrunkConfig, TrunkPlan
-from .launch import Recorder
+from .launch import Recorder, run_graphed
 from .weights import PackedTrunk, pad8
 
 
@@ -23,21 +23,56 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-class _TrunkModule:
+class ModelConfig(dict):
+    """`module.config` with attribute AND mapping access, like diffusers' FrozenDict (pipe:957 reads `unet.config.in_channels`,
+    pipe:993 `unet.config.time_cond_proj_dim`)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class _TrunkModule(torch.nn.Module):
+    """An `nn.Module` (DiffusionPipeline.register_modules, D/pipelines/pipeline_utils.py:788, accepts it; `.parameters()`, `.dtype`,
+    `.device`, `.eval()`, `.to()` behave) whose forward runs a compiled launch plan.  The weights are the packed fp16 / fp32 arenas;
+    they are exposed as two frozen Parameters that SHARE the arenas' storage.  `.to()` / `.half()` / `.float()` are no-ops: the layouts
+    are fixed at construction (device = the one given to the constructor)."""
+
     def __init__(self, state_dict, config: TrunkConfig, device="cuda:0"):
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
+        super().__init__()
+        self._device = torch.device(device)
+        if self._device.type != "cuda":
             raise _lib.BlobCtrlHipError("blobctrl_amd modules run on MI355X only; there is no CPU fallback")
         _lib.load()
-        self.config = config
-        self.weights = PackedTrunk(state_dict, self.device, config.block_out_channels)
-        self.dtype = torch.float16
+        self.trunk_config = config
+        latent = config.out_channels if config.out_channels else 4
+        self.config = ModelConfig(
+            # the reference script leaves unet.config.in_channels at the LATENT channel count (4) although conv_in has 5 inputs
+            # (scripts/blobctrl_inference.py:233-249); BlobNet: in_channels=4, conditioning_channels=1+F (bn config)
+            in_channels=latent if config.is_blobnet or config.in_channels == latent + 1 else config.in_channels,
+            conv_in_channels=config.in_channels, out_channels=config.out_channels, block_out_channels=tuple(config.block_out_channels),
+            layers_per_block=config.layers_per_block, attention_head_dim=config.num_heads, norm_num_groups=config.norm_num_groups,
+            cross_attention_dim=config.cross_attention_dim, time_cond_proj_dim=None, sample_size=64,
+            conditioning_channels=(config.in_channels - latent) if config.is_blobnet else None)
+        self.weights = state_dict if isinstance(state_dict, PackedTrunk) else PackedTrunk(state_dict, self._device, config.block_out_channels)
+        self.packed_fp16 = torch.nn.Parameter(self.weights.h_arena, requires_grad=False)
+        self.packed_fp32 = torch.nn.Parameter(self.weights.f_arena, requires_grad=False)
         self._plans = {}
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return torch.float16
 
     def to(self, *a, **k):
         return self
 
-    def eval(self):
+    def _apply(self, fn, *a, **k):          # .cuda() / .half() / .float(): the packed layouts stay as built
         return self
 
     def _to_nhwc(self, rec, x: torch.Tensor, cpad: int) -> torch.Tensor:
@@ -76,12 +111,12 @@ class BlobNetModel(_TrunkModule):
             rec = Recorder(self.device)
             P = type("Plan", (), {})()
             P.rec = rec
-            P.x_in = rec.zeros(B, H * W, pad8(self.config.in_channels))
+            P.x_in = rec.zeros(B, H * W, pad8(self.trunk_config.in_channels))
             P.t = rec.zeros(1, dtype=torch.float32)
             P.idx = rec.zeros(1, dtype=torch.int32)
             P.scale = rec.zeros(1, dtype=torch.float32)
             P.seg = rec.begin("blobnet")
-            plan = TrunkPlan(rec, self.weights, self.config, B, H, W)
+            plan = TrunkPlan(rec, self.weights, self.trunk_config, B, H, W)
             plan.record_time(P.t, P.idx)
             P.res = plan.record_forward(P.x_in, None, zero_scale=(1.0, P.scale, P.idx))
             P.shapes = plan.feat_shapes
@@ -95,13 +130,13 @@ class BlobNetModel(_TrunkModule):
         if return_dict:
             raise NotImplementedError("return_dict=True is broken in the reference (bn:947-956); use return_dict=False")
         B, C, H, W = sample.shape
-        if C != self.config.in_channels:
-            raise ValueError(f"expected {self.config.in_channels} input channels, got {C}")
+        if C != self.trunk_config.in_channels:
+            raise ValueError(f"expected {self.trunk_config.in_channels} input channels, got {C}")
         P = self._plan(B, H, W)
         P.x_in.copy_(self._to_nhwc(P.rec, sample, P.x_in.shape[-1]))
         P.t.fill_(float(timestep))
         P.scale.fill_(conditioning_scale)
-        P.seg.run(_stream())
+        run_graphed(P.seg, self.device)
         dt = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
         sd, sm, su = P.shapes
         down = [self._to_nchw(P.rec, r, B, c, h, w, dt) for r, (c, h, w) in zip(P.res.down, sd)]
@@ -109,7 +144,6 @@ class BlobNetModel(_TrunkModule):
         up = [self._to_nchw(P.rec, r, B, c, h, w, dt) for r, (c, h, w) in zip(P.res.up, su)]
         return down, mid, up
 
-    __call__ = forward
 
 
 class UNet2DConditionModel(_TrunkModule):
@@ -128,12 +162,12 @@ class UNet2DConditionModel(_TrunkModule):
         return cls(sd, cfg, device)
 
     def _res_shapes(self, H, W):
-        boc = self.config.block_out_channels
+        boc = self.trunk_config.block_out_channels
         nb = len(boc)
         down = [(boc[0], H, W)]
         h, w = H, W
         for i in range(nb):
-            down += [(boc[i], h, w)] * self.config.layers_per_block
+            down += [(boc[i], h, w)] * self.trunk_config.layers_per_block
             if i < nb - 1:
                 h, w = (h + 1) // 2, (w + 1) // 2
                 down.append((boc[i], h, w))
@@ -149,7 +183,7 @@ class UNet2DConditionModel(_TrunkModule):
         up = []
         for i in range(nb):
             hh, ww = sizes[nb - 1 - i]
-            up += [(rev[i], hh, ww)] * (self.config.layers_per_block + 1)
+            up += [(rev[i], hh, ww)] * (self.trunk_config.layers_per_block + 1)
             if i < nb - 1:
                 up.append((rev[i],) + sizes[nb - 2 - i])
         return down, mid, up
@@ -160,7 +194,7 @@ class UNet2DConditionModel(_TrunkModule):
             rec = Recorder(self.device)
             P = type("Plan", (), {})()
             P.rec = rec
-            P.x_in = rec.zeros(B, H * W, pad8(self.config.in_channels))
+            P.x_in = rec.zeros(B, H * W, pad8(self.trunk_config.in_channels))
             P.ctx = rec.zeros(B, T, Dc)
             P.t = rec.zeros(1, dtype=torch.float32)
             P.idx = rec.zeros(1, dtype=torch.int32)
@@ -172,7 +206,7 @@ class UNet2DConditionModel(_TrunkModule):
                 P.res_shapes = (sd, sm, su)
             P.residuals = residuals
             P.seg = rec.begin("unet")
-            plan = TrunkPlan(rec, self.weights, self.config, B, H, W)
+            plan = TrunkPlan(rec, self.weights, self.trunk_config, B, H, W)
             plan.record_context(P.ctx, T)
             plan.record_time(P.t, P.idx)
             P.eps = plan.record_forward(P.x_in, residuals)
@@ -193,8 +227,8 @@ class UNet2DConditionModel(_TrunkModule):
                 up_block_add_samples: Optional[List[torch.Tensor]] = None, added_cond_kwargs=None,
                 return_dict: bool = False, **kw):
         B, C, H, W = sample.shape
-        if C != self.config.in_channels:
-            raise ValueError(f"expected {self.config.in_channels} input channels, got {C}")
+        if C != self.trunk_config.in_channels:
+            raise ValueError(f"expected {self.trunk_config.in_channels} input channels, got {C}")
         is_blobnet = (down_block_add_samples is not None and mid_block_add_sample is not None
                       and up_block_add_samples is not None)                        # unet_2d_condition.py:1200
         T, Dc = encoder_hidden_states.shape[1:]
@@ -211,10 +245,9 @@ class UNet2DConditionModel(_TrunkModule):
             self._fill_residual(P, P.residuals.mid, mid_block_add_sample, sm)
             for buf, s in zip(P.residuals.up, su):
                 self._fill_residual(P, buf, up_block_add_samples.pop(0), s)        # (:1313)
-        P.seg.run(_stream())
+        run_graphed(P.seg, self.device)
         dt = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
-        out = torch.empty(B, self.config.out_channels, H, W, dtype=torch.float32, device=self.device)
-        out.copy_(P.eps.view(B, H, W, self.config.out_channels).permute(0, 3, 1, 2))
+        out = torch.empty(B, self.trunk_config.out_channels, H, W, dtype=torch.float32, device=self.device)
+        out.copy_(P.eps.view(B, H, W, self.trunk_config.out_channels).permute(0, 3, 1, 2))
         return (out.to(dt),)
 
-    __call__ = forward

@@ -33,8 +33,10 @@ def blobnet_keep(num_steps, start, end):
     return [1.0 - float(i / num_steps < start or (i + 1) / num_steps > end) for i in range(num_steps)]
 
 
-class StableDiffusionBlobNetPipeline:
-    """MI355X engine with the reference pipeline's call surface for the denoising hot path."""
+class BlobCtrlEngine:
+    """The denoising hot path on MI355X at tensor level (prompt embeddings, image latents, scores, DINO feature in; latents out):
+    static launch plans per (batch, canvas, steps), hipGraph replay, two streams.  `StableDiffusionBlobNetPipeline` below wraps it
+    with the reference pipeline's constructor and `__call__` signature."""
 
     def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
                  device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None, text_encoder=None,
@@ -212,6 +214,13 @@ class StableDiffusionBlobNetPipeline:
         torch.cuda.synchronize(self.device)
         P.captured = True
 
+    def _join_caller(self):
+        """The engine works on private non-blocking streams: make them wait for whatever the caller has enqueued on ITS current
+        stream (inputs produced by splat_features / Dinov2Model / torch ops are asynchronous) before reading any input."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in (self.stream, self.side_stream, self.side_stream2):
+            st.wait_stream(cur)
+
     def _streams(self):
         s = self.stream.cuda_stream
         return s, (self.side_stream.cuda_stream if self.two_streams else s)
@@ -242,6 +251,7 @@ class StableDiffusionBlobNetPipeline:
             raise ValueError("this pipeline was built without a text encoder: pass prompt_embeds, or text_encoder=...")
         if prompt_ids.shape != negative_prompt_ids.shape:
             raise ValueError("prompt_ids and negative_prompt_ids must have the same shape")
+        self._join_caller()
         with torch.cuda.stream(self.stream):
             emb = self.text_encoder(torch.cat([negative_prompt_ids, prompt_ids], 0), clip_skip=clip_skip)[0]
         self.stream.synchronize()
@@ -251,6 +261,7 @@ class StableDiffusionBlobNetPipeline:
         """pipe:300-309: image [1,3,H,W] in [-1,1] -> posterior sample * scaling_factor, [1,4,H/8,W/8] fp32."""
         if self.vae is None:
             raise ValueError("this pipeline was built without a VAE: pass fg_image_latents / bg_image_latents, or vae=...")
+        self._join_caller()
         with torch.cuda.stream(self.stream):
             lat = self.vae.encode(image).latent_dist.sample(generator, scale=self.vae.config.scaling_factor)
         self.stream.synchronize()
@@ -261,6 +272,7 @@ class StableDiffusionBlobNetPipeline:
         ((x/2+0.5).clamp(0,1); "pt" = [B,3,H,W] tensor, "np" = [B,H,W,3] numpy)."""
         if self.vae is None:
             raise ValueError("this pipeline was built without a VAE: use output_type='latent', or pass vae=...")
+        self._join_caller()
         with torch.cuda.stream(self.stream):
             img = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
             img = (img / 2 + 0.5).clamp(0, 1)
@@ -268,14 +280,15 @@ class StableDiffusionBlobNetPipeline:
         return img if output_type == "pt" else img.permute(0, 2, 3, 1).cpu().float().numpy()
 
     @torch.no_grad()
-    def __call__(self, prompt_embeds: torch.Tensor, fg_image_latents: Optional[torch.Tensor] = None,
+    def denoise(self, prompt_embeds: torch.Tensor, fg_image_latents: Optional[torch.Tensor] = None,
                  bg_image_latents: Optional[torch.Tensor] = None, gs_score: torch.Tensor = None, dino_feats: Optional[torch.Tensor] = None, num_inference_steps: int = 50,
                  guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None,
                  latents: Optional[torch.Tensor] = None, blobnet_conditioning_scale: float = 1.0,
                  blobnet_control_guidance_start: float = 0.0, blobnet_control_guidance_end: float = 1.0,
                  output_type: str = "latent", callback_on_step_end=None, trace: Optional[list] = None,
                  teacher_latents: Optional[List[torch.Tensor]] = None, fg_image: Optional[torch.Tensor] = None,
-                 bg_image: Optional[torch.Tensor] = None, return_sample: bool = False, eta: float = 0.0):
+                 bg_image: Optional[torch.Tensor] = None, return_sample: bool = False, eta: float = 0.0,
+                 do_classifier_free_guidance: Optional[bool] = None, callback_self=None):
         """prompt_embeds [2B, T, D] = cat(negative, positive) (pipe:937-949); fg/bg_image_latents [1,4,h,w] already scaled
         by 0.18215 (pipe:300-309); gs_score [1,2,h,w] = (bg, fg) scores (pipe:974); dino_feats [1,1,F] (pipe:982).
         Instead of the latents, `fg_image` / `bg_image` [1,3,8h,8w] in [-1,1] may be given when the pipeline has a VAE.
@@ -305,9 +318,18 @@ class StableDiffusionBlobNetPipeline:
         # pipe:494-497: guidance_scale <= 1 switches classifier-free guidance OFF in the reference (prompt_embeds then holds the
         # positive prompt only and the UNet output is used as is).  The engine keeps its CFG-batch-2 plan: the positive embeddings
         # fill both halves and the effective scale is 1, eps_u + 1 * (eps_c - eps_u) = eps_c.
-        if guidance_scale <= 1.0:
-            if latents is not None and prompt_embeds.shape[0] == latents.shape[0]:
-                prompt_embeds = torch.cat([prompt_embeds, prompt_embeds], 0)
+        # `do_classifier_free_guidance=False` (what the reference derives from guidance_scale <= 1) says explicitly that prompt_embeds
+        # holds the positive prompts only; without the flag the layout is inferred from `latents` and refused when ambiguous.
+        if do_classifier_free_guidance is None:
+            do_classifier_free_guidance = guidance_scale > 1.0
+            if not do_classifier_free_guidance:
+                if latents is None:
+                    raise ValueError("guidance_scale <= 1 without `latents`: pass do_classifier_free_guidance=False (prompt_embeds = "
+                                     "positive prompts only) or =True (negative and positive halves) - the layout cannot be inferred")
+                do_classifier_free_guidance = prompt_embeds.shape[0] != latents.shape[0]
+        if not do_classifier_free_guidance:
+            prompt_embeds = torch.cat([prompt_embeds, prompt_embeds], 0)
+        if guidance_scale <= 1.0 or not do_classifier_free_guidance:
             guidance_scale = 1.0
         B2, T, Dc = prompt_embeds.shape
         if B2 % 2:
@@ -341,6 +363,7 @@ class StableDiffusionBlobNetPipeline:
         scale_rows = [[sc * k for sc in req_scales] for k in keep]                   # [step][image]
         scales = [max(abs(v) for v in row) for row in scale_rows]                    # a step is BlobNet-free iff every scale is 0
         bg, fg = gs_score.unbind(dim=1)                                              # pipe:974
+        self._join_caller()
         with torch.cuda.stream(self.stream):
             P.latents.copy_(latents.to(dev, torch.float32) * sched.init_noise_sigma)
             P.fg_lat.copy_(fg_image_latents.to(dev, torch.float32).reshape(Bi, 4, h, w))
@@ -383,7 +406,7 @@ class StableDiffusionBlobNetPipeline:
                 trace.append((P.eps_guided.clone(), P.latents.clone()))
             if callback_on_step_end is not None:
                 self.stream.synchronize()
-                ret = callback_on_step_end(self, i, int(sched.timesteps[i]), {"latents": P.latents})
+                ret = callback_on_step_end(callback_self or self, i, int(sched.timesteps[i]), {"latents": P.latents})
                 if isinstance(ret, dict) and ret.get("latents") is not None and ret["latents"] is not P.latents:
                     with torch.cuda.stream(self.stream):                         # pipe:1112 `latents = callback_outputs.pop(...)`
                         P.latents.copy_(ret["latents"].to(dev, torch.float32))
@@ -391,6 +414,306 @@ class StableDiffusionBlobNetPipeline:
         out = P.latents.clone()
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
+    __call__ = denoise
+
     # convenience for bench / tests ------------------------------------------------------------------
     def plan_for(self, B, h, w, T, ctx_dim, nsteps, per_request=False):
         return self._plan(B, h, w, T, ctx_dim, nsteps, per_request)
+
+
+# ======================================================================================================================
+# The reference's pipeline surface: same constructor keywords, same __call__ signature, same error behaviour,
+# `.images` output - so that scripts/blobctrl_inference.py:191-205 runs unchanged on the MI355X modules.
+# ======================================================================================================================
+class StableDiffusionBlobNetPipelineOutput:
+    """pipeline_blobnet.py:1163-1166 (`images`, `nsfw_content_detected`; tuple-like for `return_dict=False` callers)."""
+
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images, self.nsfw_content_detected = images, nsfw_content_detected
+
+    def __iter__(self):
+        return iter((self.images, self.nsfw_content_detected))
+
+    def __getitem__(self, i):
+        return (self.images, self.nsfw_content_detected)[i]
+
+
+class StableDiffusionBlobNetPipeline:
+    """Drop-in for blobctrl/pipelines/pipeline_blobnet.py:StableDiffusionBlobNetPipeline on MI355X.
+
+    Components (pipe:206-243): `vae` = blobctrl_amd.vae.AutoencoderKL, `unet` / `blobnet` = blobctrl_amd.modules shells (any LoRA is
+    merged when the UNet is packed), `tokenizer` = any callable with the CLIPTokenizer call contract (host side), `text_encoder` =
+    blobctrl_amd.clip_text.CLIPTextModel, `scheduler` = blobctrl_amd.schedulers.UniPCMultistepScheduler | DDIMScheduler,
+    `dinov2_processor` = image_processor.Dinov2ImageProcessor (or the HF processor), `dinov2` = blobctrl_amd.dinov2.Dinov2Model.
+    The denoise loop itself is the captured-plan engine (BlobCtrlEngine): the module shells are not called per step."""
+
+    _callback_tensor_inputs = ["latents", "image_embeds", "negative_image_embeds"]
+
+    def __init__(self, vae, unet, tokenizer, text_encoder, blobnet, scheduler, safety_checker=None, dinov2_processor=None,
+                 dinov2=None, requires_safety_checker: bool = False, use_graphs: bool = True):
+        from .image_processor import Dinov2ImageProcessor, VaeImageProcessor
+        from .schedulers import TableScheduler
+        if safety_checker is not None:
+            raise NotImplementedError("the reference disables the safety checker (pipe:1133-1135); pass safety_checker=None")
+        if not isinstance(scheduler, TableScheduler):
+            raise TypeError("scheduler must be blobctrl_amd.schedulers.UniPCMultistepScheduler or DDIMScheduler")
+        self.vae, self.unet, self.blobnet, self.tokenizer, self.text_encoder = vae, unet, blobnet, tokenizer, text_encoder
+        self.dinov2, self.dinov2_processor = dinov2, dinov2_processor if dinov2_processor is not None else Dinov2ImageProcessor()
+        self.safety_checker = None
+        self.device = unet.device
+        self.engine = BlobCtrlEngine(unet.weights, blobnet.weights, unet.trunk_config, blobnet.trunk_config, device=str(unet.device),
+                                     scheduler=scheduler.kind, use_graphs=use_graphs, vae=vae, text_encoder=text_encoder)
+        self._scheduler = scheduler
+        nblocks = len(getattr(vae.config, "block_out_channels", (0, 0, 0, 0))) if vae is not None else 4
+        self.vae_scale_factor = 2 ** (nblocks - 1)                                                  # pipe:241
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)    # pipe:242
+        self._guidance_scale, self._clip_skip, self._num_timesteps = 7.5, None, 0
+
+    # ---- attribute plumbing the scripts touch (inf:276-279)
+    @property
+    def scheduler(self):
+        return self._scheduler
+
+    @scheduler.setter
+    def scheduler(self, s):
+        from .schedulers import TableScheduler
+        if not isinstance(s, TableScheduler):
+            raise TypeError("scheduler must be blobctrl_amd.schedulers.UniPCMultistepScheduler or DDIMScheduler")
+        self._scheduler = s
+        self.engine.scheduler_kind = s.kind
+
+    def to(self, *a, **k):
+        return self
+
+    def set_progress_bar_config(self, **k):
+        pass
+
+    def load_lora_weights(self, *a, **k):
+        raise NotImplementedError("LoRA is merged when the UNet is packed: UNet2DConditionModel.from_pretrained(..., lora_path=...) "
+                                  "(the packed layouts are immutable)")
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None                # pipe:494-497
+
+    @property
+    def clip_skip(self):
+        return self._clip_skip
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    # ---- pipe:328-436
+    def check_inputs(self, prompt, callback_steps, negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None,
+                     ip_adapter_image=None, ip_adapter_image_embeds=None, blobnet_conditioning_scale=1.0, control_guidance_start=0.0,
+                     control_guidance_end=1.0, callback_on_step_end_tensor_inputs=None):
+        if callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(k in self._callback_tensor_inputs
+                                                                      for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found "
+                             f"{[k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`:"
+                             f" {negative_prompt_embeds}. Please make sure to only forward one of the two.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                             f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+        if not isinstance(blobnet_conditioning_scale, float):
+            raise TypeError("For single blobnet: `blobnet_conditioning_scale` must be type `float`.")
+        if not isinstance(control_guidance_start, (tuple, list)):
+            control_guidance_start = [control_guidance_start]
+        if not isinstance(control_guidance_end, (tuple, list)):
+            control_guidance_end = [control_guidance_end]
+        if len(control_guidance_start) != len(control_guidance_end):
+            raise ValueError(f"`control_guidance_start` has {len(control_guidance_start)} elements, but `control_guidance_end` has "
+                             f"{len(control_guidance_end)} elements. Make sure to provide the same number of elements to each list.")
+        for start, end in zip(control_guidance_start, control_guidance_end):
+            if start >= end:
+                raise ValueError(f"control guidance start: {start} cannot be larger or equal to control guidance end: {end}.")
+            if start < 0.0:
+                raise ValueError(f"control guidance start: {start} can't be smaller than 0.")
+            if end > 1.0:
+                raise ValueError(f"control guidance end: {end} can't be larger than 1.0.")
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
+            raise NotImplementedError("IP-Adapter inputs are not part of the BlobCtrl path (the scripts never pass them)")
+
+    # ---- pipe:508-687
+    def _tokenize(self, text, max_length):
+        ids = self.tokenizer(text, padding="max_length", max_length=max_length, truncation=True, return_tensors="pt").input_ids
+        return torch.as_tensor(ids, dtype=torch.int64)
+
+    def encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt=None,
+                      prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                      lora_scale: Optional[float] = None, clip_skip: Optional[int] = None):
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("this pipeline was built without tokenizer / text_encoder: pass prompt_embeds")
+            ids = self._tokenize(prompt, getattr(self.tokenizer, "model_max_length", 77))
+            prompt_embeds = self.text_encoder(ids.to(self.device), clip_skip=clip_skip)[0]
+        prompt_embeds = prompt_embeds.to(self.device)
+        bs_embed, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs_embed * num_images_per_prompt, seq_len, -1)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            if negative_prompt is None:
+                uncond_tokens = [""] * batch_size
+            elif prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            elif isinstance(negative_prompt, str):
+                uncond_tokens = [negative_prompt]
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            else:
+                uncond_tokens = negative_prompt
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("this pipeline was built without tokenizer / text_encoder: pass negative_prompt_embeds")
+            ids = self._tokenize(uncond_tokens, prompt_embeds.shape[1])
+            negative_prompt_embeds = self.text_encoder(ids.to(self.device))[0]
+        if do_classifier_free_guidance:
+            seq_len = negative_prompt_embeds.shape[1]
+            negative_prompt_embeds = negative_prompt_embeds.to(self.device).repeat(1, num_images_per_prompt, 1)
+            negative_prompt_embeds = negative_prompt_embeds.view(batch_size * num_images_per_prompt, seq_len, -1)
+        return prompt_embeds, negative_prompt_embeds
+
+    # ---- pipe:300-309 (the posterior sample draws from the GLOBAL generator there; `generator` makes it reproducible here)
+    def encode_latents(self, image, device=None, dtype=None, prompt_embeds=None, height=512, width=512, generator=None):
+        if self.vae is None:
+            raise ValueError("this pipeline was built without a VAE: it cannot encode images")
+        if not torch.is_tensor(image):
+            image = self.image_processor.preprocess(image, height=height, width=width)
+        lat = self.engine.encode_latents(image.to(self.device, torch.float32), generator)
+        return lat if prompt_embeds is None else lat.repeat(prompt_embeds.shape[0], 1, 1, 1)
+
+    # ---- pipe:690-703
+    def encode_image_dinov2(self, image, device=None):
+        if self.dinov2 is None:
+            raise ValueError("this pipeline was built without dinov2: it cannot embed the foreground image")
+        if not torch.is_tensor(image):
+            image = self.dinov2_processor.preprocess(images=image, do_resize=True, return_tensors="pt", do_convert_rgb=True)["pixel_values"]
+        emb = self.dinov2(pixel_values=torch.as_tensor(image).to(self.device, torch.float32)).pooler_output
+        return emb.unsqueeze(1) if emb.ndim == 2 else emb
+
+    # ---- pipe:438-453 + D/utils/torch_utils.py:38-83 (a CPU generator draws on the CPU, then the noise moves to the device)
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                noise = torch.cat([torch.randn((1,) + shape[1:], generator=g_, device=g_.device, dtype=torch.float32).cpu()
+                                   for g_ in generator], 0)
+            else:
+                gdev = generator.device if generator is not None else "cpu"
+                noise = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+        else:
+            noise = latents
+        noise = noise.to(self.device, torch.float32)
+        return noise * self.scheduler.init_noise_sigma, noise
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]] = None, fg_image=None, bg_image=None, gs_score: torch.Tensor = None,
+                 height: Optional[int] = 512, width: Optional[int] = 512, num_inference_steps: int = 50, timesteps: List[int] = None,
+                 guidance_scale: float = 7.5, negative_prompt: Optional[Union[str, List[str]]] = None,
+                 num_images_per_prompt: Optional[int] = 1, eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 ip_adapter_image=None, ip_adapter_image_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, blobnet_conditioning_scale: Union[float, List[float]] = 1.0,
+                 blobnet_control_guidance_start: Union[float, List[float]] = 0.0,
+                 blobnet_control_guidance_end: Union[float, List[float]] = 1.0, clip_skip: Optional[int] = None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_sample: bool = False,
+                 **kwargs):
+        """pipeline_blobnet.py:743-1166 with the same keyword names, defaults and error behaviour.  Returns
+        StableDiffusionBlobNetPipelineOutput(images=..., nsfw_content_detected=None) or `(images, None)` for return_dict=False;
+        `output_type` "pil" | "np" | "pt" | "latent"."""
+        callback_steps = kwargs.pop("callback_steps", None)
+        if kwargs.pop("callback", None) is not None:
+            raise NotImplementedError("`callback` is deprecated in the reference (pipe:868-875): use callback_on_step_end")
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments {sorted(kwargs)}")
+        if timesteps is not None:
+            raise NotImplementedError("custom `timesteps` are not tabulated; pass num_inference_steps")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs (runtime LoRA scale) are not supported: LoRA is merged at load")
+        # 0.1 align the control-guidance format (pipe:884-893)
+        if not isinstance(blobnet_control_guidance_start, list) and isinstance(blobnet_control_guidance_end, list):
+            blobnet_control_guidance_start = len(blobnet_control_guidance_end) * [blobnet_control_guidance_start]
+        elif not isinstance(blobnet_control_guidance_end, list) and isinstance(blobnet_control_guidance_start, list):
+            blobnet_control_guidance_end = len(blobnet_control_guidance_start) * [blobnet_control_guidance_end]
+        elif not isinstance(blobnet_control_guidance_start, list) and not isinstance(blobnet_control_guidance_end, list):
+            blobnet_control_guidance_start, blobnet_control_guidance_end = [blobnet_control_guidance_start], [blobnet_control_guidance_end]
+        # 1. check inputs (pipe:897-909)
+        self.check_inputs(prompt, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds, ip_adapter_image,
+                          ip_adapter_image_embeds, blobnet_conditioning_scale, blobnet_control_guidance_start,
+                          blobnet_control_guidance_end, callback_on_step_end_tensor_inputs)
+        if gs_score is None:
+            raise ValueError("gs_score is required (pipe:974)")
+        # 2. call parameters (pipe:912-922)
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        self._guidance_scale, self._clip_skip = guidance_scale, clip_skip
+        cfg = self.do_classifier_free_guidance
+        # 3. prompt (pipe:937-949)
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, self.device, num_images_per_prompt, cfg, negative_prompt,
+                                                                   prompt_embeds=prompt_embeds,
+                                                                   negative_prompt_embeds=negative_prompt_embeds, clip_skip=clip_skip)
+        if cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+        # 5./6. timesteps and latents (pipe:953-968); the noise is drawn BEFORE the images are encoded, like the reference
+        self.scheduler.set_timesteps(num_inference_steps)
+        self._num_timesteps = num_inference_steps
+        lat0, noise = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.config.in_channels, height, width,
+                                           prompt_embeds.dtype, self.device, generator, latents)
+        # 7. image latents (pipe:970-971): fg first, then bg - the order in which the reference consumes the global generator
+        fg_lat = self.encode_latents(fg_image, height=height, width=width)
+        bg_lat = self.encode_latents(bg_image, height=height, width=width)
+        # 9. DINOv2 feature of the foreground (pipe:982)
+        dino = self.encode_image_dinov2(fg_image)
+        # 12. loop (pipe:1025-1123) on the captured plans
+        cb = None
+        if callback_on_step_end is not None:
+            def cb(_engine, i, t, kw):
+                out = callback_on_step_end(self, i, t, {k: kw[k] for k in callback_on_step_end_tensor_inputs if k in kw})
+                return out
+        final = self.engine.denoise(prompt_embeds, fg_lat, bg_lat, gs_score.to(self.device), dino,
+                                    num_inference_steps=num_inference_steps, guidance_scale=float(guidance_scale), latents=noise,
+                                    blobnet_conditioning_scale=blobnet_conditioning_scale,
+                                    blobnet_control_guidance_start=blobnet_control_guidance_start[0],
+                                    blobnet_control_guidance_end=blobnet_control_guidance_end[0], output_type="latent",
+                                    callback_on_step_end=cb, return_sample=return_sample, eta=eta, do_classifier_free_guidance=cfg)
+        # pipe:1132-1166
+        if output_type != "latent":
+            if self.vae is None:
+                raise ValueError("this pipeline was built without a VAE: use output_type='latent'")
+            image = self.vae.decode(final / self.vae.config.scaling_factor, return_dict=False)[0]
+        else:
+            image = final
+        image = self.image_processor.postprocess(image, output_type=output_type, do_denormalize=[True] * image.shape[0])
+        if not return_dict:
+            return (image, None)
+        return StableDiffusionBlobNetPipelineOutput(images=image, nsfw_content_detected=None)

@@ -207,3 +207,81 @@ class TableScheduler:
         out = apply_table_step(row, model_output, sample, self._hist)
         self._i += 1
         return (out,)
+
+
+class SchedulerConfig(dict):
+    """`scheduler.config` with attribute and mapping access (the scripts do `X.from_config(pipeline.scheduler.config)`, inf:276-277)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+_SD15 = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+             prediction_type="epsilon")
+
+
+class _ConfiguredScheduler(TableScheduler):
+    _kind = None
+    _defaults = {}
+
+    def __init__(self, **kw):
+        cfg = dict(_SD15)
+        cfg.update(self._defaults)
+        cfg.update({k: v for k, v in kw.items() if v is not None})
+        if cfg["beta_schedule"] != "scaled_linear" or cfg["prediction_type"] != "epsilon":
+            raise NotImplementedError("only the SD-1.5 configuration (scaled_linear betas, epsilon prediction) is tabulated")
+        self._check(cfg)
+        super().__init__(self._kind, num_train_timesteps=cfg["num_train_timesteps"], beta_start=cfg["beta_start"],
+                         beta_end=cfg["beta_end"])
+        self.config = SchedulerConfig(cfg)
+        # like diffusers' `_use_default_values`: keys the caller did not give are NOT inherited by another class's from_config
+        self.config["_use_default_values"] = sorted(k for k in cfg if k not in kw or kw[k] is None)
+        self.timesteps = None
+
+    def _check(self, cfg):
+        pass
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        """Like diffusers' ConfigMixin.from_config: keys this class knows are taken from `config` (another scheduler's config is
+        fine - unknown keys such as PNDM's `skip_prk_steps` are dropped), everything else keeps this class's defaults."""
+        known = set(_SD15) | set(cls._defaults)
+        defaulted = set(dict(config).get("_use_default_values", ()))
+        src = {k: v for k, v in dict(config).items() if k not in defaulted}
+        src.update(kw)
+        return cls(**{k: v for k, v in src.items() if k in known})
+
+    @property
+    def kind(self):
+        return self._kind
+
+    @kind.setter
+    def kind(self, v):
+        pass
+
+
+class UniPCMultistepScheduler(_ConfiguredScheduler):
+    """Drop-in for diffusers' UniPCMultistepScheduler as the scripts configure it (`from_config(PNDM config)`)."""
+    _kind = "unipc"
+    _defaults = dict(solver_order=2, solver_type="bh2", predict_x0=True, lower_order_final=True, timestep_spacing="linspace",
+                     final_sigmas_type="zero", thresholding=False)
+
+    def _check(self, cfg):
+        if (cfg["solver_order"], cfg["solver_type"], cfg["predict_x0"], cfg["lower_order_final"], cfg["timestep_spacing"],
+                cfg["final_sigmas_type"], cfg["thresholding"]) != (2, "bh2", True, True, "linspace", "zero", False):
+            raise NotImplementedError("UniPC is tabulated for solver_order=2 / bh2 / predict_x0 / lower_order_final / linspace / "
+                                      "final sigma zero (what the reference scripts run)")
+
+
+class DDIMScheduler(_ConfiguredScheduler):
+    """Drop-in for diffusers' DDIMScheduler with the SD-1.5 scheduler_config.json values (eta = 0)."""
+    _kind = "ddim"
+    _defaults = dict(clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading", thresholding=False)
+
+    def _check(self, cfg):
+        if cfg["clip_sample"] or cfg["set_alpha_to_one"] or cfg["timestep_spacing"] != "leading" or cfg["steps_offset"] != 1 or \
+                cfg["thresholding"]:
+            raise NotImplementedError("DDIM is tabulated for clip_sample=False, set_alpha_to_one=False, leading spacing, steps_offset=1")

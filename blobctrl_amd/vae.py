@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .launch import Recorder
+from .launch import Recorder, run_graphed
 from .weights import pack_conv3x3, pack_matrix, pad8
 
 
@@ -62,6 +62,7 @@ class AutoencoderKL:
         self.lib = _lib.load()
         self.config = self._Cfg()
         self.G, self.lpb = norm_num_groups, layers_per_block
+        self.config.block_out_channels = None       # (set below from the weights)
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.latent_channels = sd["post_quant_conv.weight"].shape[0]
         self.h, self.f = {}, {}
@@ -78,6 +79,12 @@ class AutoencoderKL:
             a = f"{side}.mid_block.attentions.0."
             self.h[a + "to_qk.weight"] = torch.cat([sd[a + "to_q.weight"], sd[a + "to_k.weight"]], 0).half().to(dev)
             self.f[a + "to_qk.bias"] = torch.cat([sd[a + "to_q.bias"], sd[a + "to_k.bias"]], 0).to(dev)
+        i = 0
+        boc = []
+        while f"encoder.down_blocks.{i}.resnets.0.conv1.weight" in sd:
+            boc.append(sd[f"encoder.down_blocks.{i}.resnets.0.conv1.weight"].shape[0])
+            i += 1
+        self.config.block_out_channels = tuple(boc)
         self._plans = {}
 
     @classmethod
@@ -223,7 +230,7 @@ class AutoencoderKL:
         s = torch.cuda.current_stream().cuda_stream
         zz = z.to(self.device, torch.float32).contiguous()
         _lib.check(self.lib.bc_nchw_to_nhwc_f16(zz.data_ptr(), 1, B, Cz, h * w, 8, P.z.data_ptr(), s), "bc_nchw_to_nhwc_f16")
-        P.seg.run(s)
+        run_graphed(P.seg, self.device)
         img = P.img
         out = img.t.view(B, img.H, img.W, img.C).permute(0, 3, 1, 2).contiguous()
         return (out,)
@@ -238,7 +245,7 @@ class AutoencoderKL:
         s = torch.cuda.current_stream().cuda_stream
         xx = x.to(self.device, torch.float32).contiguous()
         _lib.check(self.lib.bc_nchw_to_nhwc_f16(xx.data_ptr(), 1, B, 3, H * W, 8, P.x.data_ptr(), s), "bc_nchw_to_nhwc_f16")
-        P.seg.run(s)
+        run_graphed(P.seg, self.device)
         out = type("AutoencoderKLOutput", (), {})()
         out.latent_dist = _Dist(self, P.moments, B, P.hw[0], P.hw[1])
         return out

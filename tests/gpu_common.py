@@ -15,6 +15,6 @@ def tiny_trunk_configs():
 
 
 def make_pipeline(usd, bsd, scheduler="unipc", use_graphs=True):
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     u, b = tiny_trunk_configs()
-    return StableDiffusionBlobNetPipeline(usd, bsd, u, b, device="cuda:0", scheduler=scheduler, use_graphs=use_graphs)
+    return BlobCtrlEngine(usd, bsd, u, b, device="cuda:0", scheduler=scheduler, use_graphs=use_graphs)

@@ -71,10 +71,10 @@ def test_request_batch_mixed_ops_equals_single_edits_tiny():
 @pytest.fixture(scope="module")
 def full_pipe():
     import bench
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     ucfg, bcfg = bench.full_configs()
     usd, bsd = bench.synth_weights()
-    return StableDiffusionBlobNetPipeline(usd, bsd, ucfg, bcfg, device="cuda:0", scheduler="ddim")
+    return BlobCtrlEngine(usd, bsd, ucfg, bcfg, device="cuda:0", scheduler="ddim")
 
 
 def _inputs(res, batch):
@@ -126,10 +126,10 @@ def test_batch8_samples_equal_batch1_full_size(full_pipe):
 def test_plan_cache_is_bounded():
     """Plans (static buffers + captured graphs) are cached per (batch, canvas, steps); the cache evicts least-recently-used plans."""
     usd, bsd = tiny_weights()
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from tests.gpu_common import tiny_trunk_configs
     u, b = tiny_trunk_configs()
-    pipe = StableDiffusionBlobNetPipeline(usd, bsd, u, b, device="cuda:0", scheduler="ddim", max_cached_plans=2)
+    pipe = BlobCtrlEngine(usd, bsd, u, b, device="cuda:0", scheduler="ddim", max_cached_plans=2)
     args = (g(82, 2, 7, TINY["ctx"]), g(84, 1, 4, 8, 8), g(85, 1, 4, 8, 8), g(86, 1, 2, 8, 8).abs().clamp(max=1), g(87, 1, 1, TINY["feat"]))
     first = pipe(*args, num_inference_steps=2, latents=g(81, 1, 4, 8, 8)).cpu()
     for n in (3, 4, 5):

@@ -61,14 +61,14 @@ def test_full_size_two_step_loop_vs_oracle(full):
     latent scale.  ~1.5 minutes of host CPU time (the oracle runs BlobNet on both CFG halves like the reference does)."""
     import os
     import bench
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from blobctrl_amd.splat import splat_features
     from oracle import pipeline as o_pipe, schedulers as o_sched
     torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
     h = w = 64
     inp = bench.synth_inputs(h, w, batch=1)
     score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
-    pipe = StableDiffusionBlobNetPipeline(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
+    pipe = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
     out = pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=2, guidance_scale=7.5,
                latents=inp["latents"]).cpu().numpy()
     ref = o_pipe.denoise_loop(full["usd"], full["oucfg"], full["bsd"], full["obcfg"], o_sched.DDIMOracle(), 2, inp["latents"],

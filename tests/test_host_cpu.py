@@ -168,3 +168,39 @@ def test_no_hot_kernel_uses_scratch(tmp_path):
     for name, scratch in seen.items():
         limit = 128 if "attn_fwd_kernel" in name else 0
         assert scratch <= limit, f"{name}: {scratch} bytes of scratch per lane"
+
+
+def test_image_processors_match_the_reference_processors(golden_dir):
+    """Dinov2ImageProcessor vs transformers' BitImageProcessor with the dinov2 preprocessor_config values, VaeImageProcessor.preprocess
+    vs diffusers' (lanczos resize to (height, width), RGB, [-1, 1]) on a non-square image - fixture from tools/make_golden.py."""
+    from PIL import Image
+    from blobctrl_amd.image_processor import Dinov2ImageProcessor, VaeImageProcessor
+    z = np.load(os.path.join(golden_dir, "pipeline_call.npz"))
+    odd = Image.fromarray(z["odd"])
+    px = Dinov2ImageProcessor().preprocess(images=odd, do_resize=True, return_tensors="pt", do_convert_rgb=True)
+    assert px.pixel_values.shape == (1, 3, 224, 224) and dict(**px).keys() == {"pixel_values"}
+    assert np.abs(px["pixel_values"].numpy() - z["odd_dino_pixels"]).max() < 2e-6
+    v = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    assert np.abs(v.preprocess(odd, height=64, width=96).numpy() - z["odd_vae_pixels"]).max() < 1e-6
+    x = torch.rand(2, 3, 8, 8) * 2 - 1
+    assert v.postprocess(x, "latent") is x
+    assert torch.equal(v.postprocess(x, "pt"), (x / 2 + 0.5).clamp(0, 1))
+    assert v.postprocess(x, "np").shape == (2, 8, 8, 3) and v.postprocess(x, "pil")[0].size == (8, 8)
+
+
+def test_scheduler_dropins_from_config_rules():
+    """`UniPCMultistepScheduler.from_config(pipeline.scheduler.config)` (inf:276): explicitly set keys are inherited, defaulted
+    ones are not (UniPC keeps its own linspace spacing although the source config says 'leading')."""
+    from blobctrl_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
+    d = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1, clip_sample=False,
+                      set_alpha_to_one=False)
+    u = UniPCMultistepScheduler.from_config(dict(d.config, skip_prk_steps=True))
+    u.set_timesteps(50)
+    assert u.config.timestep_spacing == "linspace" and u.timesteps[:3].tolist() == [999, 979, 959] and u.order == 1
+    back = DDIMScheduler.from_config(u.config)
+    back.set_timesteps(50)
+    assert back.timesteps[:3].tolist() == [981, 961, 941] and back.init_noise_sigma == 1.0
+    import copy
+    copy.deepcopy(u)                                     # pipe:1021 deep-copies the scheduler
+    with pytest.raises(NotImplementedError):
+        UniPCMultistepScheduler(solver_order=3)

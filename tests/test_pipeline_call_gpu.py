@@ -1,0 +1,97 @@
+"""The reference-signature pipeline end to end: `StableDiffusionBlobNetPipeline(vae=, unet=, tokenizer=,
+text_encoder=, blobnet=, scheduler=, dinov2_processor=, dinov2=)(prompt=..., fg_image=PIL, bg_image=PIL, gs_score=..., height=,
+width=, ..., output_type=...)` on MI355X against tests/golden/pipeline_call.npz, which tools/make_golden.py produced by running the
+REFERENCE pipeline's own __call__ (blobctrl/pipelines/pipeline_blobnet.py:743-1166) with the same keyword arguments on CPU fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import PIPE, TINY, FakeTokenizer, pipeline_cases, psnr, tiny_pipeline_weights, tiny_weights  # noqa: E402
+from tests.gpu_common import tiny_trunk_configs  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pipeline_call.npz")
+
+
+@pytest.fixture(scope="module")
+def parts():
+    from blobctrl_amd.clip_text import CLIPTextModel
+    from blobctrl_amd.dinov2 import Dinov2Model
+    from blobctrl_amd.modules import BlobNetModel, UNet2DConditionModel
+    from blobctrl_amd.vae import AutoencoderKL
+    usd, bsd = tiny_weights()
+    ucfg, bcfg = tiny_trunk_configs()
+    vsd, csd, dsd = tiny_pipeline_weights()
+    return dict(unet=UNet2DConditionModel(usd, ucfg), blobnet=BlobNetModel(bsd, bcfg),
+                vae=AutoencoderKL(vsd, norm_num_groups=PIPE["vae_groups"]),
+                text_encoder=CLIPTextModel(csd, num_heads=PIPE["clip"]["heads"]),
+                dinov2=Dinov2Model(dsd, num_heads=PIPE["dino"]["heads"], patch_size=PIPE["dino"]["patch"]))
+
+
+def build(parts, scheduler):
+    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.schedulers import DDIMScheduler, UniPCMultistepScheduler
+    sch = UniPCMultistepScheduler() if scheduler == "unipc" else DDIMScheduler()
+    return StableDiffusionBlobNetPipeline(tokenizer=FakeTokenizer(), scheduler=sch, safety_checker=None, requires_safety_checker=False,
+                                          **parts)
+
+
+@pytest.mark.parametrize("case", ["unipc", "ddim_neg2", "nocfg"])
+def test_pipeline_call_matches_reference_call(parts, case):
+    from PIL import Image
+    z = np.load(GOLD)
+    kw = dict(pipeline_cases()[case])
+    pipe = build(parts, kw.pop("scheduler"))
+    seed, rng_seed = kw.pop("seed"), kw.pop("rng_seed")
+    common = dict(fg_image=Image.fromarray(z["fg"]), bg_image=Image.fromarray(z["bg"]), gs_score=torch.from_numpy(z["gs_score"]),
+                  height=64, width=64, **kw)
+    torch.manual_seed(rng_seed)                          # the VAE posterior samples come from the global generator, like pipe:304
+    out = pipe(generator=torch.Generator().manual_seed(seed), output_type="latent", **common)
+    got, ref = out.images.cpu().numpy(), z[f"{case}_latents"]
+    assert got.shape == ref.shape
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    # tiny random nets are not denoisers: a few free-running steps amplify fp16 rounding (see test_parity_gpu's loop tests)
+    assert rel < 3e-2 and psnr(got, ref) > 36.0, (case, rel, psnr(got, ref))
+    assert out.nsfw_content_detected is None
+    tup = pipe(generator=torch.Generator().manual_seed(seed), output_type="latent", return_dict=False, **common) \
+        if case == "nocfg" else None
+    if tup is not None:
+        assert isinstance(tup, tuple) and tup[1] is None and tup[0].shape == ref.shape
+    if case == "unipc":                                  # decode + postprocess: "np" and "pil" outputs
+        torch.manual_seed(rng_seed)
+        img = pipe(generator=torch.Generator().manual_seed(seed), output_type="np", **common).images
+        ref_img = z["unipc_image_np"]
+        assert img.shape == ref_img.shape == (1, 64, 64, 3) and img.min() >= 0.0 and img.max() <= 1.0
+        assert np.abs(img - ref_img).mean() < 2e-2
+        torch.manual_seed(rng_seed)
+        pil = pipe(generator=torch.Generator().manual_seed(seed), output_type="pil", **common).images
+        assert len(pil) == 1 and pil[0].size == (64, 64)
+        assert np.abs(np.asarray(pil[0]).astype(np.float32) / 255 - img[0]).max() <= 0.5 / 255 + 1e-6
+
+
+def test_pipeline_call_argument_errors_match_the_reference(parts):
+    from PIL import Image
+    z = np.load(GOLD)
+    pipe = build(parts, "unipc")
+    ok = dict(fg_image=Image.fromarray(z["fg"]), bg_image=Image.fromarray(z["bg"]), gs_score=torch.from_numpy(z["gs_score"]), height=64,
+              width=64, num_inference_steps=2, output_type="latent")
+    with pytest.raises(ValueError, match="Provide either `prompt` or `prompt_embeds`"):
+        pipe(**ok)
+    with pytest.raises(ValueError, match="Cannot forward both `prompt`"):
+        pipe(prompt="x", prompt_embeds=torch.zeros(1, 77, TINY["ctx"]), **ok)
+    with pytest.raises(TypeError, match="must be type `float`"):
+        pipe(prompt="x", blobnet_conditioning_scale=1, **ok)
+    with pytest.raises(ValueError, match="cannot be larger or equal to control guidance end"):
+        pipe(prompt="x", blobnet_control_guidance_start=0.5, blobnet_control_guidance_end=0.5, **ok)
+    with pytest.raises(TypeError, match="should be the same type"):
+        pipe(prompt="x", negative_prompt=["y"], **ok)
+    # the scripts swap the scheduler through from_config (inf:276-277)
+    from blobctrl_amd.schedulers import DDIMScheduler
+    pipe.scheduler = DDIMScheduler.from_config(pipe.scheduler.config)
+    assert pipe.engine.scheduler_kind == "ddim" and pipe.unet.config.in_channels == 4 and pipe.unet.dtype == torch.float16
+    assert next(pipe.dinov2.parameters()).device.type == "cuda" if hasattr(pipe.dinov2, "parameters") else True
+    out = pipe(prompt="x", **ok).images
+    assert out.shape == (1, 4, 8, 8) and torch.isfinite(out).all()

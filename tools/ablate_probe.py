@@ -22,7 +22,7 @@ def timeit(fn, n=15):
 
 
 def main():
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from blobctrl_amd.splat import splat_features
     dev = torch.device("cuda:0")
     ucfg, bcfg = bench.full_configs()
@@ -30,7 +30,7 @@ def main():
     h = w = 64
     inp = bench.synth_inputs(h, w, batch=1)
     score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device=str(dev))
-    pipe = StableDiffusionBlobNetPipeline(usd, bsd, ucfg, bcfg, device=str(dev), scheduler="ddim")
+    pipe = BlobCtrlEngine(usd, bsd, ucfg, bcfg, device=str(dev), scheduler="ddim")
     pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=4, latents=inp["latents"])
     P = pipe.plan_for(1, h, w, 77, 768, 4)
     s, side = pipe._streams()

@@ -29,7 +29,7 @@ def main():
     from blobctrl_amd.clip_text import CLIPTextModel
     from blobctrl_amd.dinov2 import Dinov2Model
     from blobctrl_amd.modules import BlobNetModel, UNet2DConditionModel
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
     from blobctrl_amd.vae import AutoencoderKL
 
@@ -45,7 +45,7 @@ def main():
         vae = AutoencoderKL.from_pretrained(sd15, subfolder="vae")
         clip = CLIPTextModel.from_pretrained(sd15, subfolder="text_encoder")
         dino = Dinov2Model.from_pretrained(os.path.join(args.models, "dinov2-large"))
-        pipe = StableDiffusionBlobNetPipeline(unet.weights, blob.weights, unet.config, blob.config, scheduler="unipc", vae=vae,
+        pipe = BlobCtrlEngine(unet.weights, blob.weights, unet.trunk_config, blob.trunk_config, scheduler="unipc", vae=vae,
                                               text_encoder=clip)
     else:
         ucfg, bcfg = bench.full_configs()
@@ -53,7 +53,7 @@ def main():
         vae = AutoencoderKL(synth.synth_state_dict(synth.vae_param_shapes(), 33))
         clip = CLIPTextModel(synth.synth_state_dict(synth.clip_text_param_shapes(), 88), num_heads=12)
         dino = Dinov2Model(synth.synth_state_dict(synth.dinov2_param_shapes(1024, 24, 4, 14, 37 * 37), 99), num_heads=16)
-        pipe = StableDiffusionBlobNetPipeline(usd, bsd, ucfg, bcfg, scheduler="unipc", vae=vae, text_encoder=clip)
+        pipe = BlobCtrlEngine(usd, bsd, ucfg, bcfg, scheduler="unipc", vae=vae, text_encoder=clip)
     t1 = sync()
     R = args.res
     rng = np.random.Generator(np.random.PCG64(0))

@@ -425,8 +425,90 @@ def golden_lora_keys():
     print("lora keys:", len(out["pairs"]), "pairs;", out["kwargs_no_alpha"], out["kwargs_alpha"])
 
 
+def golden_pipeline_call():
+    """The REFERENCE pipeline's own `__call__` (pipe:743-1166) end to end on tiny components: PIL images + prompt strings in, latents
+    (and one decoded image) out - tokenizer stand-in, CLIP, VAE encode (global-generator posterior samples), DINOv2 processor + model,
+    rank-1 splat, BlobNet + patched UNet loop, scheduler, VAE decode, VaeImageProcessor.postprocess."""
+    from PIL import Image
+    from diffusers import AutoencoderKL
+    from transformers import BitImageProcessor, CLIPTextConfig, CLIPTextModel, Dinov2Config, Dinov2Model
+    from tests.common import PIPE, FakeTokenizer, pipeline_cases, tiny_pipeline_weights
+    c = TINY
+    unet5, blob = build_tiny()
+    # the script's construction (inf:229-249): a 4-channel UNet whose conv_in is replaced by a 5-channel one; config.in_channels stays 4
+    unet = UNet2DConditionModel(in_channels=4, out_channels=4, block_out_channels=c["boc"], norm_num_groups=c["groups"],
+                                attention_head_dim=c["heads"], cross_attention_dim=c["ctx"], layers_per_block=2)
+    unet.conv_in = torch.nn.Conv2d(5, unet.conv_in.out_channels, kernel_size=3, stride=1, padding=1)
+    unet.load_state_dict(unet5.state_dict(), strict=True)
+    unet.eval()
+    assert unet.config.in_channels == 4
+    vsd, csd, dsd = tiny_pipeline_weights()
+    vae = AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4, block_out_channels=PIPE["vae_boc"], layers_per_block=2,
+                        latent_channels=4, norm_num_groups=PIPE["vae_groups"], sample_size=32).eval()
+    vae.load_state_dict(vsd, strict=True)
+    pc = PIPE["clip"]
+    te = CLIPTextModel(CLIPTextConfig(vocab_size=pc["vocab"], hidden_size=pc["hidden"], intermediate_size=pc["inter"],
+                                      num_hidden_layers=pc["layers"], num_attention_heads=pc["heads"], max_position_embeddings=77,
+                                      hidden_act="quick_gelu", layer_norm_eps=1e-5)).eval()
+    have = {k for k in te.state_dict().keys() if "position_ids" not in k}
+    pre = "" if any(k.startswith("text_model.") for k in have) else "text_model."
+    assert set(csd.keys()) == {pre + k for k in have}, "clip schema mismatch"
+    te.load_state_dict({k[len(pre):]: v for k, v in csd.items()}, strict=False)
+    pd = PIPE["dino"]
+    dino = Dinov2Model(Dinov2Config(hidden_size=pd["hidden"], num_hidden_layers=pd["layers"], num_attention_heads=pd["heads"],
+                                    image_size=14 * pd["grid"], patch_size=pd["patch"], mlp_ratio=pd["mlp_ratio"])).eval()
+    assert set(dsd.keys()) == set(dino.state_dict().keys()), "dinov2 schema mismatch"
+    dino.load_state_dict(dsd, strict=True)
+    # facebook/dinov2-* preprocessor_config.json values (external knowledge, like the ViT-L sizes): what AutoImageProcessor resolves to
+    proc = BitImageProcessor(do_resize=True, size={"shortest_edge": 256}, resample=3, do_center_crop=True,
+                             crop_size={"height": 224, "width": 224}, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+                             image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], do_convert_rgb=True)
+    rng = np.random.Generator(np.random.PCG64(3))
+    # smooth-ish images (random low-res blocks upsampled) so that resize filters matter but nothing saturates
+    def img(h, w):
+        lo = rng.integers(0, 256, (h // 8, w // 8, 3)).astype(np.uint8)
+        return np.kron(lo, np.ones((8, 8, 1), np.uint8)) // 2 + rng.integers(0, 128, (h, w, 3)).astype(np.uint8)
+    out = {"fg": img(64, 64), "bg": img(64, 64)}
+    ell = [[40.0, 42.0], [20.0, 30.0], 25.0]
+    mean, cov = ref_inf.get_gs_from_ellipse(ell)
+    nm, nc = ref_inf.normalize_gs(mean, cov, 64, 64)
+    gs = splat_features(**ref_inf.get_blob_dict_from_norm_gs(nm, nc), score_size=(8, 8), return_d_score=True)   # [1,2,8,8] f64
+    out["gs_score"] = gs.numpy()
+    # image-processor pins (host code on our side): DINOv2 preprocessing of non-square images, VAE preprocessing with a resize
+    from diffusers.image_processor import VaeImageProcessor
+    odd = Image.fromarray(img(72, 104))
+    out["odd"] = np.array(odd)
+    out["odd_dino_pixels"] = proc.preprocess(images=odd, do_resize=True, return_tensors="pt", do_convert_rgb=True).pixel_values.numpy()
+    out["odd_vae_pixels"] = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True).preprocess(odd, height=64, width=96).numpy()
+    for name, kw in pipeline_cases().items():
+        kw = dict(kw)
+        sch = (UniPCMultistepScheduler(**SD_SCHED) if kw.pop("scheduler") == "unipc"
+               else DDIMScheduler(**SD_SCHED, clip_sample=False, set_alpha_to_one=False))
+        pipe = StableDiffusionBlobNetPipeline(vae=vae, unet=unet, tokenizer=FakeTokenizer(), text_encoder=te, blobnet=blob,
+                                              scheduler=sch, safety_checker=None, dinov2_processor=proc, dinov2=dino,
+                                              requires_safety_checker=False)
+        pipe.set_progress_bar_config(disable=True)
+        seed, rng_seed = kw.pop("seed"), kw.pop("rng_seed")
+        common = dict(fg_image=Image.fromarray(out["fg"]), bg_image=Image.fromarray(out["bg"]), gs_score=gs, height=64, width=64, **kw)
+        torch.manual_seed(rng_seed)           # the VAE posterior samples come from the GLOBAL generator (pipe:304)
+        r = pipe(generator=torch.Generator().manual_seed(seed), output_type="latent", **common)
+        out[f"{name}_latents"] = r.images.numpy()
+        if name == "unipc":
+            torch.manual_seed(rng_seed)
+            r = pipe(generator=torch.Generator().manual_seed(seed), output_type="np", **common)
+            out[f"{name}_image_np"] = np.asarray(r.images)
+        print(f"pipeline __call__ {name}: latents std {out[f'{name}_latents'].std():.4f}")
+    np.savez_compressed(os.path.join(OUT, "pipeline_call.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     check_full_schema()
+    golden_pipeline_call()
     golden_lora_keys()
     golden_blob_edit()
     golden_clip_text()

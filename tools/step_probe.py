@@ -22,7 +22,7 @@ def timeit(fn, n=20):
 
 
 def main():
-    from blobctrl_amd.pipeline import StableDiffusionBlobNetPipeline
+    from blobctrl_amd.pipeline import BlobCtrlEngine
     from blobctrl_amd.splat import splat_features
     dev = torch.device("cuda:0")
     ucfg, bcfg = bench.full_configs()
@@ -37,7 +37,7 @@ def main():
             os.environ["BC_ONE_STREAM"] = "1"
         else:
             os.environ.pop("BC_ONE_STREAM", None)
-        pipe = StableDiffusionBlobNetPipeline(usd, bsd, ucfg, bcfg, device=str(dev), scheduler="ddim")
+        pipe = BlobCtrlEngine(usd, bsd, ucfg, bcfg, device=str(dev), scheduler="ddim")
         pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=4, latents=inp["latents"])
         P = pipe.plan_for(1, h, w, 77, 768, 4)
         s, side = pipe._streams()
