@@ -101,6 +101,13 @@ inline float as_float(uint64_t v) { uint32_t u = (uint32_t)v; float f; memcpy(&f
 #define L(k) (long long)r.a[k]
 #define F(k) as_float(r.a[k])
 
+int plan_event(BcPlan* pl, int e, hipEvent_t* out) {
+    BC_CHECK_ARG(e >= 0 && e < (int)pl->events.size(), "plan: bad event id %d", e);
+    if (!pl->events[e]) BC_CHECK_HIP(hipEventCreateWithFlags(&pl->events[e], hipEventDisableTiming));
+    *out = pl->events[e];
+    return 0;
+}
+
 int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
     bc_stream s = streams[r.sid < nstreams ? r.sid : 0];
     switch (r.op) {
@@ -142,15 +149,17 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
         case BC_OP_NHWC_TO_NCHW: return bc_nhwc_to_nchw(CP(bc_half, 0), I(1), I(2), I(3), I(4), P(5), I(6), s);
         case BC_OP_GAUSSIAN_SAMPLE: return bc_gaussian_sample(CP(bc_half, 0), CP(float, 1), I(2), I(3), I(4), F(5), MP(float, 6), s);
         case BC_OP_SIGNAL: {
-            const int e = I(0);
-            BC_CHECK_ARG(e >= 0 && e < (int)pl->events.size(), "plan: bad event id %d", e);
-            BC_CHECK_HIP(hipEventRecord(pl->events[e], reinterpret_cast<hipStream_t>(s)));
+            hipEvent_t ev;
+            int rc = plan_event(pl, I(0), &ev);
+            if (rc) return rc;
+            BC_CHECK_HIP(hipEventRecord(ev, reinterpret_cast<hipStream_t>(s)));
             return 0;
         }
         case BC_OP_WAIT: {
-            const int e = I(0);
-            BC_CHECK_ARG(e >= 0 && e < (int)pl->events.size(), "plan: bad event id %d", e);
-            BC_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(s), pl->events[e], 0));
+            hipEvent_t ev;
+            int rc = plan_event(pl, I(0), &ev);
+            if (rc) return rc;
+            BC_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(s), ev, 0));
             return 0;
         }
         default: bc_set_error("plan: unknown op %d", r.op); return 1;
@@ -233,7 +242,8 @@ extern "C" int bc_plan_destroy(BcPlan* pl) {
     if (!pl) return 0;
     for (Seg& s : pl->segs)
         if (s.graph) (void)hipGraphExecDestroy(s.graph);
-    for (hipEvent_t e : pl->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : pl->events)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < pl->n_own_streams; ++i) (void)hipStreamDestroy(pl->own_streams[i]);
     if (pl->arena) (void)hipFree(pl->arena);
     delete pl;
@@ -249,9 +259,7 @@ extern "C" int bc_plan_segment(BcPlan* pl, const char* name) {
 
 extern "C" int bc_plan_new_event(BcPlan* pl) {
     if (!pl) return -1;
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { bc_set_error("bc_plan_new_event: hipEventCreate failed"); return -1; }
-    pl->events.push_back(e);
+    pl->events.push_back(nullptr);          // created on first use: plans can be compiled (and saved) on a machine without a GPU
     return (int)pl->events.size() - 1;
 }
 

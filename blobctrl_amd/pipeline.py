@@ -40,11 +40,15 @@ class BlobCtrlEngine:
 
     def __init__(self, unet_state_dict, blobnet_state_dict, unet_config: TrunkConfig, blobnet_config: TrunkConfig,
                  device="cuda:0", scheduler: str = "unipc", use_graphs: bool = True, vae=None, text_encoder=None,
-                 max_cached_plans: int = 4):
+                 max_cached_plans: int = 4, compile_only: bool = False):
+        """`compile_only=True` (device may then be "cpu"): the engine only COMPILES plans into `.bcplan` files (`compile_plan`) for the
+        C plan runtime (bc_plan_load / bc_step); nothing can be executed and no GPU is touched."""
         self.device = torch.device(device)
-        if self.device.type != "cuda":
+        self.compile_only = compile_only
+        if self.device.type != "cuda" and not compile_only:
             raise _lib.BlobCtrlHipError("blobctrl_amd runs on MI355X only (device must be cuda:N); there is no CPU fallback")
-        torch.cuda.set_device(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
         self.lib = _lib.load()
         self.unet_cfg, self.blob_cfg = unet_config, blobnet_config
         # either reference-schema state dicts (packed here) or already-packed / broadcast replicas (dist.broadcast_packed)
@@ -54,9 +58,10 @@ class BlobCtrlEngine:
             PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
         self.scheduler_kind = scheduler
         self.use_graphs = use_graphs
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
-        self.side_stream2 = torch.cuda.Stream(device=self.device)    # (BC_SPLIT_CFG: the cond half of the UNet batch)
+        if self.device.type == "cuda":
+            self.stream = torch.cuda.Stream(device=self.device)
+            self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
+            self.side_stream2 = torch.cuda.Stream(device=self.device)    # (BC_SPLIT_CFG: the cond half of the UNet batch)
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
         self._plans = {}                                              # (batch, canvas, steps, ...) -> plan, least recently used first
         self.max_cached_plans = max(1, int(max_cached_plans))         # a 512^2 batch-1 plan holds ~2.5 GB of activations
@@ -75,7 +80,8 @@ class BlobCtrlEngine:
             return self._plans[key]
         while len(self._plans) >= self.max_cached_plans:              # evict the least recently used plan and its graphs
             old = self._plans.pop(next(iter(self._plans)))
-            torch.cuda.synchronize(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             old.rec.close()                                           # graphs and events of the evicted plan
         dev = self.device
         rec = Recorder(dev)
@@ -86,26 +92,26 @@ class BlobCtrlEngine:
         f32 = torch.float32
         Bi = B if per_request else 1                         # images (fg / bg / score / feature sets) behind the batch
         P.Bi = Bi
-        P.latents = rec.zeros(B, 4, h, w, dtype=f32)
-        P.fg_lat = rec.zeros(Bi, 4, h, w, dtype=f32)
-        P.bg_lat = rec.zeros(Bi, 4, h, w, dtype=f32)
-        P.fg_score = rec.zeros(Bi, h, w, dtype=f32)
-        P.bg_score = rec.zeros(Bi, h, w, dtype=f32)
-        P.feat = rec.zeros(Bi, max(F, 1), dtype=f32)
-        P.ctx = rec.zeros(2 * B, T, ctx_dim)
-        P.step_idx = rec.zeros(1, dtype=torch.int32)
-        P.t_table = rec.zeros(nsteps, dtype=f32)
-        P.coef = rec.zeros(nsteps, 16, dtype=f32)
-        P.scale_table = rec.zeros(nsteps * Bi, dtype=f32)   # [step][image] conditioning_scale * keep
-        P.hist = rec.zeros(3, B * 4 * h * w, dtype=f32)
-        P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32)
+        P.latents = rec.zeros(B, 4, h, w, dtype=f32, name="latents")
+        P.fg_lat = rec.zeros(Bi, 4, h, w, dtype=f32, name="fg_lat")
+        P.bg_lat = rec.zeros(Bi, 4, h, w, dtype=f32, name="bg_lat")
+        P.fg_score = rec.zeros(Bi, h, w, dtype=f32, name="fg_score")
+        P.bg_score = rec.zeros(Bi, h, w, dtype=f32, name="bg_score")
+        P.feat = rec.zeros(Bi, max(F, 1), dtype=f32, name="feat")
+        P.ctx = rec.zeros(2 * B, T, ctx_dim, name="ctx")
+        P.step_idx = rec.zeros(1, dtype=torch.int32, name="step_idx")
+        P.t_table = rec.zeros(nsteps, dtype=f32, name="t_table")
+        P.coef = rec.zeros(nsteps, 16, dtype=f32, name="coef")
+        P.scale_table = rec.zeros(nsteps * Bi, dtype=f32, name="scale_table")   # [step][image] conditioning_scale * keep
+        P.hist = rec.zeros(3, B * 4 * h * w, dtype=f32, name="hist")
+        P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32, name="eps_guided")
         P.guidance = [7.5]
 
         # rank-1 collapse of the BlobNet feature channels (per-edit weight): not for per-request batches (one weight per launch)
         P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request
         unet_cin = pad8(self.unet_cfg.in_channels)
         blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
-        P.feat16 = rec.zeros(1, pad8(max(F, 1)))
+        P.feat16 = rec.zeros(1, pad8(max(F, 1)), name="feat16")
         P.blob_in = rec.zeros(B, H * W, blob_cin)
         P.unet_in = rec.zeros(2 * B, H * W, unet_cin)
 
@@ -415,6 +421,29 @@ class BlobCtrlEngine:
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
     __call__ = denoise
+
+    def compile_plan(self, path, B, h, w, T, ctx_dim, num_inference_steps, guidance_scale=7.5, blobnet_conditioning_scale=1.0,
+                     blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0):
+        """Write the launch plan of one edit configuration as a relocatable `.bcplan` file for the C plan runtime
+        (include/blobctrl_hip.h: bc_plan_load / bc_plan_buffer / bc_step / bc_plan_capture_loop): segments "prologue",
+        "step_active", "step_inactive"; packed weights and the scheduler / guidance tables stored with their contents; the per-edit
+        inputs are the NAMED buffers latents, fg_lat, bg_lat, fg_score, bg_score (fp32), feat (fp32) / feat16 (fp16, rank-1
+        collapse), ctx (fp16 [2B][T][ctx_dim] = cat(negative, positive)); the result is read from `latents`.  Returns the per-step
+        segment names (which steps run BlobNet)."""
+        n = num_inference_steps
+        P = self._plan(B, h, w, T, ctx_dim, n, False)
+        sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
+        sched.set_timesteps(n)
+        keep = blobnet_keep(n, blobnet_control_guidance_start, blobnet_control_guidance_end)
+        P.t_table.copy_(sched.timesteps.to(torch.float32))
+        coef = sched.table().clone()
+        coef[:, 11] = float(guidance_scale)
+        P.coef.copy_(coef)
+        P.scale_table.copy_(torch.tensor([blobnet_conditioning_scale * k for k in keep], dtype=torch.float32))
+        for t in (P.t_table, P.coef, P.scale_table):                 # constants of this configuration: saved WITH their contents
+            P.rec._workspace.discard(t.untyped_storage().data_ptr())
+        P.rec.save(path)
+        return ["step_active" if blobnet_conditioning_scale * k != 0.0 else "step_inactive" for k in keep]
 
     # convenience for bench / tests ------------------------------------------------------------------
     def plan_for(self, B, h, w, T, ctx_dim, nsteps, per_request=False):
