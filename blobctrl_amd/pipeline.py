@@ -63,6 +63,7 @@ class BlobCtrlEngine:
             self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
             self.side_stream2 = torch.cuda.Stream(device=self.device)    # (BC_SPLIT_CFG: the cond half of the UNet batch)
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
+        self.loop_graph = os.environ.get("BC_LOOP_GRAPH", "1") != "0"     # whole-edit graph (one launch per edit) vs one graph per step
         self._plans = {}                                              # (batch, canvas, steps, ...) -> plan, least recently used first
         self.max_cached_plans = max(1, int(max_cached_plans))         # a 512^2 batch-1 plan holds ~2.5 GB of activations
         self._sched_cache = {}
@@ -200,6 +201,7 @@ class BlobCtrlEngine:
             unet_i.tproj, unet_i.tproj_table = unet_a.tproj, unet_a.tproj_table
         record_unet(unet_i, None)
         P.eps_inactive = P.eps
+        P.loop_graphs = {}
         P.captured = False
         self._plans[key] = P
         return P
@@ -210,6 +212,7 @@ class BlobCtrlEngine:
         s, side = self._streams()
         # warm-up run outside capture (module loading, attribute setting) then capture each segment once
         torch.cuda.synchronize(self.device)
+        P.prologue.run(s)
         for seg in (P.step_active, P.step_inactive):
             with torch.cuda.stream(self.stream):
                 P.step_idx.zero_()
@@ -400,6 +403,22 @@ class BlobCtrlEngine:
                 P.latents.copy_(latents.to(dev, torch.float32) * sched.init_noise_sigma)
                 P.step_idx.zero_()
                 P.hist.zero_()
+        plain = teacher_latents is None and callback_on_step_end is None and trace is None
+        if plain and self.use_graphs and self.loop_graph:
+            # the WHOLE edit (prologue + n steps) as ONE hipGraph per (plan, active / inactive pattern): one launch per edit; the
+            # per-step scalars (timestep, scheduler coefficients, conditioning scale) are read through the device step counter
+            key = tuple(v != 0.0 for v in scales)
+            g = P.loop_graphs.get(key)
+            if g is None:
+                if len(P.loop_graphs) >= 4:
+                    P.loop_graphs.clear()                                      # (handles stay owned by the recorder until close)
+                segs = [P.prologue] + [P.step_active if a else P.step_inactive for a in key]
+                torch.cuda.synchronize(self.device)
+                g = P.loop_graphs[key] = P.rec.capture_loop(segs, s, side, self._extra())
+            _lib.check(self.lib.bc_graph_launch(g, s), "bc_graph_launch")
+            torch.cuda.synchronize(self.device)
+            out = P.latents.clone()
+            return out if output_type == "latent" else self.decode_latents(out, output_type)
         P.prologue.run(s)
         for i in range(n):
             if teacher_latents is not None:

@@ -1,0 +1,145 @@
+"""The north-star parity bar AT the benchmark's size and length: full-size SD-1.5 / BlobNet shapes, 512x512,
+FIFTY scheduler steps, UniPC (what the reference scripts run, inf:276) and DDIM, CFG 7.5.
+
+A random-weight trajectory is not contractive, so a free-running 50-step latent cannot be compared with a CPU run step for step;
+the test is TEACHER-FORCED at spread step indices incl. the last two: the engine runs its 50 steps and records (x_i, guided eps_i,
+x_{i+1}); for the chosen i the CPU oracle evaluates the loop body (BlobNet + patched UNet + crop + CFG, oracle/pipeline.py after
+pipe:1031-1098) ON THE ENGINE'S x_i, and eps must agree to max-abs <= 1e-2 of its scale and PSNR >= 40 dB; the scheduler update
+x_{i+1} is then re-evaluated on the host in fp64 from the engine's own (x, eps, history) with the coefficient tables that
+tests/test_host_cpu.py pins against the reference trajectories.  ~25 s of host CPU per oracle step (8 steps).
+
+Also here: BASELINE configs[2] literally (batch 8, MIXED operations, per-request inputs, 512^2) against the same requests run one
+at a time, and configs[4] (768^2) with one oracle-checked step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import g, psnr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    from oracle.nets import NetConfig
+    usd, bsd = bench.synth_weights()
+    ucfg, bcfg = bench.full_configs()
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    return dict(usd=usd, bsd=bsd, ucfg=ucfg, bcfg=bcfg, oucfg=NetConfig(in_channels=5, cross_attention_dim=768),
+                obcfg=NetConfig(in_channels=1029, cross_attention_dim=None))
+
+
+def _oracle_eps(full, x, t, inp, score, guidance, cond_scale=1.0):
+    from oracle.pipeline import noise_pred_step
+    B2 = 2 * x.shape[0]
+    bg_s, fg_s = score.cpu().float().unbind(dim=1)
+    bg_s, fg_s = bg_s.unsqueeze(1).repeat(B2, 1, 1, 1), fg_s.unsqueeze(1).repeat(B2, 1, 1, 1)
+    feats = torch.einsum("nmhw,nmc->nchw", fg_s, inp["dino"].repeat(B2, 1, 1)).contiguous()
+    with torch.no_grad():
+        return noise_pred_step(full["usd"], full["oucfg"], full["bsd"], full["obcfg"], x, torch.tensor(int(t)), inp["prompt"],
+                               inp["fg"].repeat(B2, 1, 1, 1), inp["bg"].repeat(B2, 1, 1, 1), fg_s, bg_s, feats, cond_scale, guidance)
+
+
+@pytest.mark.parametrize("sched,check", [("unipc", (0, 1, 25, 48, 49)), ("ddim", (0, 30, 49))])
+def test_fifty_step_edit_teacher_forced_at_spread_steps(full, sched, check):
+    import bench
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.schedulers import DDIMTable, UniPCTable
+    from blobctrl_amd.splat import splat_features
+    h = w = 64
+    n = 50
+    inp = bench.synth_inputs(h, w, batch=1)
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
+    eng = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler=sched)
+    trace = []
+    final = eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=n, guidance_scale=7.5,
+                latents=inp["latents"], blobnet_control_guidance_end=0.9, trace=trace).cpu()
+    assert len(trace) == n and torch.isfinite(final).all()
+    xs = [inp["latents"].clone()] + [x.cpu() for (_, x) in trace]            # x_0 (init sigma = 1) ... x_50
+    eps = [e.cpu() for (e, _) in trace]
+    tab = UniPCTable() if sched == "unipc" else DDIMTable()
+    tab.set_timesteps(n)
+    keep_end = 0.9
+    worst_eps, worst_step = 0.0, 0.0
+    for i in check:
+        active = (i + 1) / n <= keep_end
+        ref = _oracle_eps(full, xs[i], tab.timesteps[i], inp, score, 7.5, 1.0 if active else 0.0).numpy()
+        got = eps[i].numpy()
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        worst_eps = max(worst_eps, rel)
+        print(f"{sched} step {i:2d} (t={int(tab.timesteps[i])}, BlobNet {'on' if active else 'off'}): eps max-abs/scale {rel:.3e}, "
+              f"PSNR {psnr(got, ref):.1f} dB")
+        assert rel < 1e-2 and psnr(got, ref) > 40.0, (sched, i, rel)
+    # scheduler update at EVERY step from the engine's own (x, eps): fp64 host evaluation of the pinned coefficient rows
+    coef = tab.table().double()
+    m0 = m1 = last = torch.zeros_like(xs[0], dtype=torch.float64)
+    for i in range(n):
+        c = coef[i]
+        x, e = xs[i].double(), eps[i].double()
+        x0 = x * c[0] - e * c[1]
+        xc = x if c[2] == 0 else c[3] * last + c[4] * m0 + c[5] * m1 + c[6] * x0
+        xn = c[7] * xc + c[8] * x0 + c[9] * m0 + c[10] * e
+        m1, m0, last = m0, x0, xc
+        err = (xs[i + 1].double() - xn).abs().max().item() / max(1.0, xn.abs().max().item())
+        worst_step = max(worst_step, err)
+        assert err < 2e-5, (sched, i, err)
+    print(f"{sched}: worst eps {worst_eps:.3e}, worst scheduler-update error {worst_step:.2e} over {n} steps")
+    # the whole-edit hipGraph gives the same final latents as the per-step trace run, bit for bit
+    again = eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=n, guidance_scale=7.5,
+                latents=inp["latents"], blobnet_control_guidance_end=0.9).cpu()
+    assert torch.equal(again, final)
+
+
+def test_c3_batch8_mixed_operations_per_request_full_size(full):
+    """BASELINE configs[2]: eight DIFFERENT edit requests (own images, ellipses, DINO features, prompts, noise; two `remove`
+    requests with strength 0.0 and gs_score = (1, 0), inf:175-188; one weaker move) as one per-request batch - the 1029-channel
+    conv_in without the rank-1 collapse - against the same requests run one at a time."""
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
+    eng = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="unipc")
+    B, h, w, steps = 8, 64, 64, 3
+    ells = [[[200.0 + 30 * i, 180.0 + 25 * i], [60.0 + 6 * i, 90.0 - 4 * i], 20.0 * i] for i in range(B)]
+    strengths = [1.0, 0.0, 1.0, 1.2, 0.0, 1.0, 0.6, 1.0]
+    score = torch.cat([splat_features(**blob_dict_from_ellipse(e, 512, 512), score_size=(h, w), return_d_score=True, device="cuda:0")
+                       for e in ells]).float()
+    for b, s in enumerate(strengths):
+        if s == 0.0:
+            score[b, 0], score[b, 1] = 1.0, 0.0
+    fg, bg = g(201, B, 4, h, w) * 0.18215 * 5, g(202, B, 4, h, w) * 0.18215 * 5
+    dino, lat = g(203, B, 1, 1024), g(204, B, 4, h, w)
+    neg, pos = g(205, 1, 77, 768).repeat(B, 1, 1), g(206, B, 77, 768)
+    kw = dict(num_inference_steps=steps, guidance_scale=7.5, blobnet_control_guidance_end=0.9)
+    out = eng(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=strengths, **kw).cpu().numpy()
+    assert out.shape == (B, 4, h, w) and np.isfinite(out).all()
+    for b in (0, 1, 3, 6):
+        single = eng(torch.cat([neg[b:b + 1], pos[b:b + 1]]), fg[b:b + 1], bg[b:b + 1], score[b:b + 1], dino[b:b + 1],
+                     latents=lat[b:b + 1], blobnet_conditioning_scale=strengths[b], **kw).cpu().numpy()
+        rel = np.abs(out[b:b + 1] - single).max() / np.abs(single).max()
+        print(f"C3 request {b} (strength {strengths[b]}): rel {rel:.3e}, PSNR {psnr(out[b:b + 1], single):.1f} dB")
+        assert rel < 3e-2 and psnr(out[b:b + 1], single) > 40.0, (b, rel)
+    assert np.abs(out[0] - out[2]).max() > 1e-2 * np.abs(out[0]).max()            # the requests really are different edits
+
+
+def test_c5_768_single_step_vs_oracle(full):
+    """BASELINE configs[4] shape: one 768 x 768 denoise step (canvas 96 x 192, 18 432-token self-attention) against the CPU oracle."""
+    import bench
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.schedulers import DDIMTable
+    from blobctrl_amd.splat import splat_features
+    h = w = 96
+    inp = bench.synth_inputs(h, w, batch=1)
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
+    eng = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
+    trace = []
+    eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=1, guidance_scale=7.5, latents=inp["latents"],
+        trace=trace)
+    tab = DDIMTable()
+    tab.set_timesteps(1)
+    ref = _oracle_eps(full, inp["latents"], tab.timesteps[0], inp, score, 7.5).numpy()
+    got = trace[0][0].cpu().numpy()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"768^2 step: eps max-abs/scale {rel:.3e}, PSNR {psnr(got, ref):.1f} dB")
+    assert rel < 1e-2 and psnr(got, ref) > 40.0
