@@ -213,6 +213,63 @@ def roofline(pipe, plan, res=512, batch=1):
         dict(by_kernel=table, top_shapes=detail)
 
 
+def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3):
+    """One complete edit as scripts/blobctrl_inference.py runs it (UniPC, guidance window [0, 0.9], CFG 7.5), every stage on the
+    clock: Gaussian-blob splat + DINOv2 ViT-L/14 on the 224^2 crop + CLIP text encoder (prompt and negative prompt) + 2 VAE encodes
+    + the denoise loop (45 BlobNet-active + 5 UNet-only steps) + VAE decode.  Seeded synthetic weights of the real architectures;
+    inputs are device tensors (image decoding / tokenisation stay on the host).  Median of `reps` edits after one warm-up edit."""
+    import statistics
+    import numpy as np
+    from blobctrl_amd import synth
+    from blobctrl_amd.clip_text import CLIPTextModel
+    from blobctrl_amd.dinov2 import Dinov2Model
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
+    from blobctrl_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(synth.synth_state_dict(synth.vae_param_shapes(), 33), device=str(dev))
+    clip = CLIPTextModel(synth.synth_state_dict(synth.clip_text_param_shapes(), 88), num_heads=12, device=str(dev))
+    dino = Dinov2Model(synth.synth_state_dict(synth.dinov2_param_shapes(1024, 24, 4, 14, 37 * 37), 99), num_heads=16, device=str(dev))
+    eng = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler="unipc", vae=vae, text_encoder=clip)
+    rng = np.random.Generator(np.random.PCG64(0))
+    fg = torch.from_numpy(rng.uniform(-1, 1, (1, 3, res, res)).astype(np.float32)).to(dev)
+    bg = torch.from_numpy(rng.uniform(-1, 1, (1, 3, res, res)).astype(np.float32)).to(dev)
+    crop = torch.from_numpy(rng.standard_normal((1, 3, 224, 224)).astype(np.float32)).to(dev)      # processor output (host side)
+    ids = torch.from_numpy(rng.integers(0, 49408, size=(2, 1, 77)).astype(np.int64)).to(dev)
+    sc = res / 512.0
+    blob = blob_dict_from_ellipse([[361.1067 * sc, 367.8526 * sc], [85.4812 * sc, 103.6543 * sc], 87.3739], res, res)
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def one():
+        t = [sync()]
+        score = splat_features(**blob, score_size=(res // 8, res // 8), return_d_score=True, device=str(dev))
+        t.append(sync())
+        feats = dino(crop).pooler_output.view(1, 1, -1)
+        t.append(sync())
+        prompt = eng.encode_prompt(ids[1], ids[0])
+        t.append(sync())
+        fl, bl = eng.encode_latents(fg, torch.Generator().manual_seed(1)), eng.encode_latents(bg, torch.Generator().manual_seed(2))
+        t.append(sync())
+        lat = eng(prompt, fl, bl, score, feats, num_inference_steps=denoise_steps, guidance_scale=7.5,
+                  generator=torch.Generator().manual_seed(0), blobnet_conditioning_scale=1.0, blobnet_control_guidance_end=0.9)
+        t.append(sync())
+        img = eng.decode_latents(lat, "pt")
+        t.append(sync())
+        assert torch.isfinite(img).all()
+        return [1e3 * (b - a) for a, b in zip(t[:-1], t[1:])]
+
+    one()
+    runs = [one() for _ in range(reps)]
+    med = [statistics.median(r[k] for r in runs) for k in range(6)]
+    names = ["splat_ms", "dinov2_ms", "clip_text_ms", "vae_encode_x2_ms", "denoise_loop_ms", "vae_decode_ms"]
+    out = {n: round(v, 3) for n, v in zip(names, med)}
+    out["edit_ms_end_to_end"] = round(statistics.median(sum(r) for r in runs), 2)
+    out["config"] = f"{res}x{res}, {denoise_steps} UniPC steps, guidance window [0, 0.9] (script defaults, inf:300-307), CFG 7.5, batch 1"
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -276,6 +333,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per edit (BASELINE configs[2]/[4] use 8 / 4; headline = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (splat + DINOv2 + CLIP + VAE + loop) timing")
     ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE configs[3]: this many independent edit requests in total, sharded round-robin over the ranks "
@@ -409,6 +467,10 @@ def main():
         line["roofline"] = rl
         if args.table:
             print(json.dumps(table, indent=1), file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_e2e and args.batch == 1 and not args.requests:
+        e2e = end_to_end(pw_u, pw_b, ucfg, bcfg, dev, args.res, args.denoise_steps)
+        line["edit_ms_end_to_end"] = e2e["edit_ms_end_to_end"]
+        line["end_to_end"] = e2e
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == 1:
         cb, _ = cpu_baseline(state["usd"], state["bsd"], inp, h, w, args.denoise_steps, args.scheduler)
         line["cpu_baseline"] = cb

@@ -4,9 +4,11 @@ an ellipse into the three pipeline inputs (fg image, bg image, gs_score) - scrip
 
 Pinned: every function marked [pinned] is checked against vectors produced by EXECUTING the reference's own definitions
 (tools/make_golden.py::golden_blob_edit extracts them from scripts/blobctrl_app.py with `ast`; fixture tests/golden/blob_edit.json).
-Not pinned (OpenCV, a third-party dependency that is absent here): mask -> ellipse fitting (`cv2.fitEllipse` on the convex hull,
-app:382-389) is not provided; `ellipse_mask` replaces `cv2.ellipse(..., -1, lineType=LINE_AA)` + the app's `> 0` threshold by an exact
-"pixel square touches the ellipse" test on a 4 x 4 sub-pixel grid, which can differ from OpenCV's rasteriser on boundary pixels.
+Not pinned to OpenCV (a third-party dependency that is absent here), but defined in closed form and tested against hand-checkable
+vectors: `ellipse_from_mask` / `fit_ellipse` / `convex_hull` stand in for `cv2.fitEllipse(cv2.convexHull(contours))` (app:382-389) with a
+direct least-squares fit that returns exact ellipses exactly; `ellipse_mask` replaces `cv2.ellipse(..., -1, lineType=LINE_AA)` + the
+app's `> 0` threshold by the exact "pixel square intersects the filled ellipse" predicate, which can differ from OpenCV's polygon
+rasteriser on the outermost ring of pixels.
 """
 import math
 from typing import Sequence, Tuple
@@ -117,21 +119,106 @@ def object_region_from_mask(mask: np.ndarray, image: np.ndarray) -> np.ndarray:
     return out
 
 
-def ellipse_mask(ellipse: Ellipse, height: int, width: int, sub: int = 4) -> np.ndarray:
-    """[NOT pinned - replaces cv2.ellipse(..., thickness=-1, LINE_AA) followed by the app's `> 0`, app:1113-1121] uint8 mask, 255
-    where the pixel square [x-0.5, x+0.5] x [y-0.5, y+0.5] contains a point of the filled ellipse (sampled on a sub x sub grid)."""
+def ellipse_mask(ellipse: Ellipse, height: int, width: int) -> np.ndarray:
+    """[NOT pinned to OpenCV, which is absent here - replaces cv2.ellipse(..., thickness=-1, lineType=LINE_AA) followed by the app's
+    `> 0` (app:1113-1121, composite_mask_and_image app:461-476): every pixel the anti-aliased fill gives ANY coverage is masked]
+    uint8 mask, 255 exactly where the closed pixel square [x - 0.5, x + 0.5] x [y - 0.5, y + 0.5] intersects the filled ellipse.
+    Exact, not sampled: the ellipse is mapped to the unit disc, the pixel square to a parallelogram, and the distance from the
+    origin to that parallelogram is compared with 1 (closed forms for circles / axis-aligned ellipses: tests/test_blob_edit_cpu.py).
+    OpenCV's fill is a polygon approximation of the ellipse with a ~1-pixel anti-aliasing footprint; the two masks can differ on
+    the outermost ring of pixels."""
     (xc, yc), (d1, d2), angle = ellipse
     t = math.radians(angle)
     a, b = max(d1 / 2.0, 1e-9), max(d2 / 2.0, 1e-9)
-    off = (np.arange(sub) + 0.5) / sub - 0.5
-    ys = (np.arange(height)[:, None] + off[None, :]).reshape(-1)                  # [H*sub]
-    xs = (np.arange(width)[:, None] + off[None, :]).reshape(-1)                   # [W*sub]
-    X, Y = xs[None, :] - xc, ys[:, None] - yc
-    u = X * math.cos(t) + Y * math.sin(t)                                         # coordinates along the d1 / d2 axes
-    v = -X * math.sin(t) + Y * math.cos(t)
-    inside = (u / a) ** 2 + (v / b) ** 2 <= 1.0
-    cover = inside.reshape(height, sub, width, sub).any(axis=(1, 3))
+    ct, st = math.cos(t), math.sin(t)
+    X, Y = np.meshgrid(np.arange(width, dtype=np.float64) - xc, np.arange(height, dtype=np.float64) - yc)
+
+    def to_disc(x, y):                                  # image offset -> unit-disc coordinates (u along the d1 axis, v along d2)
+        return (x * ct + y * st) / a, (-x * st + y * ct) / b
+    corners = [to_disc(X + dx, Y + dy) for dx, dy in ((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5))]
+    cu, cv = to_disc(X, Y)
+    inside = cu * cu + cv * cv <= 1.0                   # (a pixel whose centre is inside intersects trivially)
+    best = np.full(X.shape, np.inf)
+    # origin inside the parallelogram <=> the ellipse centre lies in the pixel square
+    origin_in = (np.abs(X) <= 0.5) & (np.abs(Y) <= 0.5)
+    for k in range(4):
+        (pu, pv), (qu, qv) = corners[k], corners[(k + 1) % 4]
+        eu, ev = qu - pu, qv - pv
+        tt = np.clip(-(pu * eu + pv * ev) / np.maximum(eu * eu + ev * ev, 1e-300), 0.0, 1.0)
+        du, dv = pu + tt * eu, pv + tt * ev
+        best = np.minimum(best, du * du + dv * dv)
+    cover = inside | origin_in | (best <= 1.0)
     return (cover * 255).astype(np.uint8)
+
+
+def convex_hull(points: np.ndarray) -> np.ndarray:
+    """cv2.convexHull restated (Andrew's monotone chain): hull vertices [K, 2] without collinear points."""
+    pts = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0)
+    if len(pts) <= 2:
+        return pts
+
+    def half(seq):
+        out = []
+        for p_ in seq:
+            while len(out) >= 2 and ((out[-1][0] - out[-2][0]) * (p_[1] - out[-2][1]) - (out[-1][1] - out[-2][1]) * (p_[0] - out[-2][0])) <= 0:
+                out.pop()
+            out.append(tuple(p_))
+        return out
+    lower, upper = half(pts), half(pts[::-1])
+    return np.array(lower[:-1] + upper[:-1], dtype=np.float64)
+
+
+def fit_ellipse(points: np.ndarray) -> Ellipse:
+    """[NOT pinned to OpenCV, which is absent here - stands in for cv2.fitEllipse (app:387)] direct least-squares ellipse fit
+    (Fitzgibbon / Halir-Flusser: minimise the algebraic distance a x^2 + b xy + c y^2 + d x + e y + f subject to 4ac - b^2 = 1)
+    of >= 5 points, returned in OpenCV's RotatedRect convention ((xc, yc), (d1, d2), angle): full axis lengths with d1 <= d2 and the
+    angle of the d1 axis in degrees in [0, 180), measured in image coordinates (the convention every function of this file and
+    cv2.ellipse use).  Points lying exactly on an ellipse return that ellipse (tested); for noisy points OpenCV's own solver
+    (a different normalisation of the same algebraic fit) can give slightly different axes."""
+    P = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+    if len(P) < 5:
+        raise ValueError("fit_ellipse needs at least 5 points")
+    m = P.mean(0)
+    sc = max(np.abs(P - m).max(), 1e-12)
+    x, y = (P[:, 0] - m[0]) / sc, (P[:, 1] - m[1]) / sc              # conditioning: centred, unit scale
+    D1 = np.stack([x * x, x * y, y * y], 1)
+    D2 = np.stack([x, y, np.ones_like(x)], 1)
+    S1, S2, S3 = D1.T @ D1, D1.T @ D2, D2.T @ D2
+    T = -np.linalg.solve(S3, S2.T)
+    M = S1 + S2 @ T
+    M = np.stack([M[2] / 2.0, -M[1], M[0] / 2.0])                     # inv(C1) @ M with C1 = [[0,0,2],[0,-1,0],[2,0,0]]
+    w, V = np.linalg.eig(M)
+    V = np.real(V)
+    cond = 4.0 * V[0] * V[2] - V[1] ** 2
+    k = int(np.argmax(cond))                                          # the one eigenvector with 4ac - b^2 > 0
+    if not cond[k] > 0:
+        raise ValueError("fit_ellipse: the points do not determine an ellipse")
+    a1 = V[:, k]
+    A, B, C_ = a1
+    D, E, F = T @ a1
+    # centre, axes and orientation of A x^2 + B xy + C y^2 + D x + E y + F = 0
+    den = B * B - 4.0 * A * C_
+    x0, y0 = (2.0 * C_ * D - B * E) / den, (2.0 * A * E - B * D) / den
+    F0 = A * x0 * x0 + B * x0 * y0 + C_ * y0 * y0 + D * x0 + E * y0 + F
+    Q = np.array([[A, B / 2.0], [B / 2.0, C_]]) / (-F0)               # (p - c)^T Q (p - c) = 1
+    ev, evec = np.linalg.eigh(Q)
+    if ev.min() <= 0:
+        raise ValueError("fit_ellipse: degenerate conic")
+    semi = 1.0 / np.sqrt(ev)                                          # eigh: ascending eigenvalues -> semi[0] is the LONG semi-axis
+    short_dir = evec[:, 1]
+    ang = math.degrees(math.atan2(short_dir[1], short_dir[0])) % 180.0
+    return ((float(x0 * sc + m[0]), float(y0 * sc + m[1])), (float(2.0 * semi[1] * sc), float(2.0 * semi[0] * sc)), float(ang))
+
+
+def ellipse_from_mask(mask: np.ndarray) -> Ellipse:
+    """app:382-389 `_get_ellipse`: ellipse fitted to the convex hull of the mask's external contours.  The hull of the contour points
+    equals the hull of the set pixels, so no contour tracing is needed."""
+    mask = np.asarray(mask)
+    ind = mask > 0 if mask.ndim == 2 else mask.sum(-1) > 0
+    ys, xs = np.nonzero(ind)
+    if len(xs) == 0:
+        raise ValueError("empty mask")
+    return fit_ellipse(convex_hull(np.stack([xs, ys], 1)))
 
 
 def build_edit_inputs(op: str, image: np.ndarray, start_ellipse: Ellipse, target_ellipse: Ellipse = None, strength: float = 1.0,

@@ -66,3 +66,62 @@ def test_ellipse_mask_properties():
     centre_in = (u / 18.0) ** 2 + (v / 10.0) ** 2 <= 1.0
     assert np.all(m[centre_in] == 255)
     assert be.ellipse_mask(((40.0, 30.0), (1e-5, 1e-5), 0.0), 64, 80).sum() <= 255 * 1          # the degenerate `add` start ellipse
+
+
+def test_ellipse_mask_matches_closed_forms_for_circles_and_axis_aligned_ellipses():
+    """Hand-checkable closed form: for an axis-aligned ellipse the pixel square nearest point to the centre is (clamp(|dx| - 0.5, 0),
+    clamp(|dy| - 0.5, 0)) in each axis independently (scaling x by 1/a and y by 1/b keeps the square a box), so the pixel is masked
+    iff (ex / a)^2 + (ey / b)^2 <= 1.  OpenCV (cv2.ellipse LINE_AA + `> 0`, app:1113-1121) is absent in this image: these vectors pin
+    the definition 'every pixel the filled ellipse touches', not OpenCV's polygon approximation."""
+    H, W = 48, 64
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    for (xc, yc, d1, d2, ang) in [(30.0, 20.0, 18.0, 18.0, 0.0), (31.5, 22.25, 25.0, 9.0, 0.0), (12.0, 40.0, 7.0, 30.0, 90.0),
+                                  (63.0, 0.0, 10.0, 14.0, 180.0), (20.3, 20.7, 1e-5, 1e-5, 0.0)]:
+        a, b = (d1 / 2, d2 / 2) if ang % 180.0 == 0.0 else (d2 / 2, d1 / 2)          # 90 degrees swaps the axes
+        ex = np.maximum(np.abs(xx - xc) - 0.5, 0.0) / max(a, 1e-9)
+        ey = np.maximum(np.abs(yy - yc) - 0.5, 0.0) / max(b, 1e-9)
+        ref = ((ex * ex + ey * ey <= 1.0) * 255).astype(np.uint8)
+        got = be.ellipse_mask(((xc, yc), (d1, d2), ang), H, W)
+        assert np.array_equal(got, ref), (xc, yc, d1, d2, ang, int((got != ref).sum()))
+    # rotated ellipse: contains every pixel whose CENTRE is inside, stays within a one-pixel dilation of that set, 180-degree symmetric
+    e = ((31.5, 23.5), (40.0, 12.0), 33.0)
+    m = be.ellipse_mask(e, H, W) > 0
+    t = np.radians(33.0)
+    u = (xx - 31.5) * np.cos(t) + (yy - 23.5) * np.sin(t)
+    v = -(xx - 31.5) * np.sin(t) + (yy - 23.5) * np.cos(t)
+    centre_in = (u / 20.0) ** 2 + (v / 6.0) ** 2 <= 1.0
+    assert (m | ~centre_in).all()
+    dil = np.zeros_like(centre_in)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            dil |= np.roll(np.roll(centre_in, dy, 0), dx, 1)
+    assert (dil | ~m).all() and m.sum() > centre_in.sum()
+    assert np.array_equal(m, m[::-1, ::-1])                                           # (31.5, 23.5) is the centre of symmetry of the 48 x 64 pixel grid
+
+
+def test_fit_ellipse_recovers_exact_ellipses_and_mask_hulls():
+    """cv2.fitEllipse stand-in (app:382-389): points ON an ellipse give that ellipse back, in OpenCV's ((xc, yc), (d1 <= d2), angle of
+    the d1 axis in [0, 180)) convention; the ellipse fitted to the hull of a rasterised ellipse mask reproduces it to a pixel."""
+    for (xc, yc, d1, d2, ang) in [(361.1067, 367.8526, 85.4812, 103.6543, 87.3739), (100.0, 90.0, 60.0, 200.0, 10.0),
+                                  (256.0, 256.0, 120.0, 121.0, 135.0), (40.5, 470.25, 40.0, 300.0, 179.0)]:
+        th = np.linspace(0, 2 * np.pi, 23, endpoint=False) + 0.1
+        t = np.radians(ang)
+        u, v = d1 / 2 * np.cos(th), d2 / 2 * np.sin(th)
+        pts = np.stack([xc + u * np.cos(t) - v * np.sin(t), yc + u * np.sin(t) + v * np.cos(t)], 1)
+        (fx, fy), (f1, f2), fa = be.fit_ellipse(pts)
+        np.testing.assert_allclose([fx, fy, f1, f2], [xc, yc, d1, d2], rtol=1e-9, atol=1e-7)
+        assert f1 <= f2 and 0.0 <= fa < 180.0 and min(abs(fa - ang), 180.0 - abs(fa - ang)) < 1e-6
+        # same orientation convention as the app's calculate_ellipse_vertices (app:502-532) and cv2.ellipse: the four axis end
+        # points of the FITTED ellipse lie on the ORIGINAL one
+        for vx, vy in be.calculate_ellipse_vertices(((fx, fy), (f1, f2), fa)):
+            uu = (vx - xc) * np.cos(t) + (vy - yc) * np.sin(t)
+            vv = -(vx - xc) * np.sin(t) + (vy - yc) * np.cos(t)
+            assert abs((uu / (d1 / 2)) ** 2 + (vv / (d2 / 2)) ** 2 - 1.0) < 1e-6
+    e = ((120.0, 96.0), (70.0, 110.0), 25.0)
+    mask = be.ellipse_mask(e, 200, 240)
+    (fx, fy), (f1, f2), fa = be.ellipse_from_mask(mask)
+    assert abs(fx - 120.0) < 0.6 and abs(fy - 96.0) < 0.6 and abs(f1 - 70.0) < 2.0 and abs(f2 - 110.0) < 2.0 and abs(fa - 25.0) < 1.5
+    hull = be.convex_hull(np.array([[0, 0], [4, 0], [2, 0], [4, 4], [0, 4], [2, 2], [1, 3]]))
+    assert sorted(map(tuple, hull)) == [(0.0, 0.0), (0.0, 4.0), (4.0, 0.0), (4.0, 4.0)]
+    with pytest.raises(ValueError):
+        be.fit_ellipse(np.zeros((4, 2)))

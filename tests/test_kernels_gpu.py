@@ -483,3 +483,58 @@ def test_bad_arguments_fail_loudly(rec):
     with pytest.raises(_lib.BlobCtrlHipError):
         run(rec, lambda: rec.attention(h(g(1, 1, 8, 24)), h(g(2, 1, 8, 24)), h(g(3, 1, 24, 64)), rec.empty(1, 8, 24), 1, 2, 12,
                                        8, 8, 24, 24, 64, 24, 192, 192, 24 * 64, 192, 1.0))                       # d = 12
+
+
+@pytest.mark.parametrize("kind", ["linear", "conv3x3"])
+def test_lora_merged_equals_runtime_low_rank_branch_full_size(rec, kind):
+    """the UNet LoRA is merged at load (W + (alpha / r) B A, weights.merge_lora; peft itself is absent here).  At the
+    production shapes the merged layer must equal the adapter as peft EXECUTES it - base layer + scale * lora_B(lora_A(x)) as two
+    extra small GEMMs at run time - for a Linear (to_q of the 64 x 128 level, M = 16384) and a Conv2d pair (3x3 rank-r conv then
+    1x1, D/loaders/unet.py:314-340)."""
+    from blobctrl_amd.weights import merge_lora, pack_conv3x3
+    r, alpha = 4, 8.0
+    scale = alpha / r
+    if kind == "linear":
+        M, C = 16384, 320
+        x, w = g(1, M, C), g(2, C, C) / math.sqrt(C)
+        a, b = g(3, r, C) / math.sqrt(C), g(4, C, r) * 0.5
+        sd = merge_lora({"m.weight": w}, {"m.lora_A.weight": a, "m.lora_B.weight": b}, {"m": alpha})
+
+        def fn():
+            xd = h(x)
+            merged = rec.gemm(A=xd, W=h(sd["m.weight"]), M=M, N=C, K=C, out=rec.empty(M, C))
+            base = rec.gemm(A=xd, W=h(w), M=M, N=C, K=C, out=rec.empty(M, C))
+            ap = torch.zeros(8, C)
+            ap[:r] = a                                                       # rank padded to the 8-element K granularity
+            bp = torch.zeros(C, 8)
+            bp[:, :r] = b
+            low = rec.gemm(A=xd, W=h(ap), M=M, N=8, K=C, out=rec.empty(M, 8))
+            branch = rec.gemm(A=low, W=h(bp), M=M, N=C, K=8, out=rec.empty(M, C), alpha=scale, R=base, ldr=C)
+            return merged, branch
+        merged, branch = run(rec, fn)
+        ref = x.half().float() @ (w + scale * b @ a).t()
+    else:
+        B, H, W, C = 2, 32, 64, 640
+        x, w = g(1, B, C, H, W), g(2, C, C, 3, 3) / math.sqrt(9 * C)
+        a, b = g(3, r, C, 3, 3) / math.sqrt(9 * C), g(4, C, r, 1, 1) * 0.5
+        sd = merge_lora({"m.weight": w}, {"m.lora_A.weight": a, "m.lora_B.weight": b}, {"m": alpha})
+        M = B * H * W
+        conv = dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1)
+
+        def fn():
+            xd = h(x.permute(0, 2, 3, 1).reshape(M, C).contiguous())
+            merged = rec.gemm(A=xd, W=h(pack_conv3x3(sd["m.weight"])), M=M, N=C, K=9 * C, out=rec.empty(M, C), conv=conv)
+            base = rec.gemm(A=xd, W=h(pack_conv3x3(w)), M=M, N=C, K=9 * C, out=rec.empty(M, C), conv=conv)
+            ap = torch.zeros(8, C, 3, 3)
+            ap[:r] = a
+            bp = torch.zeros(C, 8)
+            bp[:, :r] = b.flatten(1)
+            low = rec.gemm(A=xd, W=h(pack_conv3x3(ap)), M=M, N=8, K=9 * C, out=rec.empty(M, 8), conv=conv)
+            branch = rec.gemm(A=low, W=h(bp), M=M, N=C, K=8, out=rec.empty(M, C), alpha=scale, R=base, ldr=C)
+            return merged, branch
+        merged, branch = run(rec, fn)
+        ref = F.conv2d(x.half().float(), w + scale * (b.flatten(1) @ a.flatten(1)).reshape(w.shape), padding=1)
+        ref = ref.permute(0, 2, 3, 1).reshape(M, C)
+    close(merged, ref, rtol=4e-3, what=f"merged LoRA {kind} vs fp32")
+    close(branch, ref, rtol=6e-3, what=f"runtime LoRA branch {kind} vs fp32")
+    close(merged, branch, rtol=8e-3, what=f"merged vs runtime branch {kind}")
