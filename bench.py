@@ -54,8 +54,8 @@ def synth_inputs(h, w, T=77, ctx=768, feat=1024, batch=1):
 def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
     """The CPU oracle (oracle/, kind 'port') timed on the host cores: FULL denoise steps of the same workload as the reference
     executes them (BlobNet AND UNet at CFG batch 2, fp32, pipe:1043-1090), one warm-up step, then the median of `timed_steps`
-    steps.  The thread count is chosen once by a sweep over {32, 64, 128, all} on a proxy (the first
-    ResBlock convolution shape); it is recorded in `cores`.  The 50-step edit and the C1 (20-step) edit are extrapolations of
+    steps.  The thread count is chosen once by a sweep over {16, 32, 64, 128} on a proxy (one ResBlock
+    convolution, one GEGLU projection, one self-attention of the step); it is recorded in `cores`.  The 50-step edit and the C1 (20-step) edit are extrapolations of
     the measured step time and are labelled as such."""
     import statistics
     from oracle import blob_splat
@@ -66,15 +66,23 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
     except AttributeError:
         avail = os.cpu_count() or 1
     sweep = {}
-    xs = torch.randn(2, 320, h, 2 * w)
-    ws = torch.randn(320, 320, 3, 3)
-    for nt in sorted({min(avail, c) for c in (32, 64, 128, avail)}):
-        torch.set_num_threads(nt)
+    # proxy = one convolution, one GEGLU projection and one self-attention of the step's mix (a convolution alone favours thread
+    # counts at which the attention / linear layers of the full nets oversubscribe: 64 threads won the conv and lost the step)
+    xs, ws = torch.randn(2, 320, h, 2 * w), torch.randn(320, 320, 3, 3)
+    xl, wl = torch.randn(2 * h * 2 * w, 320), torch.randn(2560, 320)
+    q = torch.randn(2, 8, (h // 2) * w, 80)
+
+    def proxy():
         torch.nn.functional.conv2d(xs, ws, padding=1)
+        torch.nn.functional.linear(xl, wl)
+        torch.nn.functional.scaled_dot_product_attention(q, q, q)
+    for nt in sorted({min(avail, c) for c in (16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        proxy()
         t0 = time.perf_counter()
-        for _ in range(3):
-            torch.nn.functional.conv2d(xs, ws, padding=1)
-        sweep[nt] = (time.perf_counter() - t0) / 3
+        for _ in range(2):
+            proxy()
+        sweep[nt] = (time.perf_counter() - t0) / 2
     cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     ucfg = NetConfig(in_channels=5, cross_attention_dim=768)
@@ -100,7 +108,7 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
     t_step = statistics.median(times[1:])
     sample = (f"{timed_steps} full denoise steps after 1 warm-up step (BlobNet + UNet at CFG batch 2 as the reference executes "
               f"them, fp32, {8*h}x{8*w}): median {t_step:.2f} s/step on {cores} threads (warm-up {times[0]:.2f} s; thread sweep on a "
-              f"conv proxy {{{', '.join(f'{k}: {v*1e3:.0f} ms' for k, v in sorted(sweep.items()))}}}); value = 1 / (s/step x {steps}) "
+              f"conv + linear + attention proxy {{{', '.join(f'{k}: {v*1e3:.0f} ms' for k, v in sorted(sweep.items()))}}}); value = 1 / (s/step x {steps}) "
               "is an EXTRAPOLATION of the measured step time to the whole edit (the scheduler update is negligible)")
     return dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
                 host_cpus_visible=avail, s_per_step=round(t_step, 3), step_times_s=[round(x, 3) for x in times],

@@ -263,9 +263,16 @@ extern "C" int bc_plan_new_event(BcPlan* pl) {
     return (int)pl->events.size() - 1;
 }
 
+// (the two add functions return the launch INDEX, so errors are negative)
+#define ADD_CHECK(cond, ...)                             \
+    do {                                                 \
+        if (!(cond)) { bc_set_error(__VA_ARGS__); return -1; } \
+    } while (0)
+
 extern "C" int bc_plan_add_gemm(BcPlan* pl, int seg, int stream_id, const BcGemm* g) {
-    SEG(pl, seg);
-    BC_CHECK_ARG(g != nullptr && stream_id >= 0 && stream_id < kMaxStreams, "bc_plan_add_gemm: bad arguments");
+    ADD_CHECK(pl != nullptr && seg >= 0 && seg < (int)pl->segs.size(), "bc_plan_add_gemm: bad segment id %d", seg);
+    Seg& sg = pl->segs[seg];
+    ADD_CHECK(g != nullptr && stream_id >= 0 && stream_id < kMaxStreams, "bc_plan_add_gemm: bad arguments");
     Rec r;
     r.op = BC_OP_GEMM;
     r.sid = stream_id;
@@ -275,10 +282,12 @@ extern "C" int bc_plan_add_gemm(BcPlan* pl, int seg, int stream_id, const BcGemm
 }
 
 extern "C" int bc_plan_add_op(BcPlan* pl, int seg, int stream_id, int op, const uint64_t* args, int nargs) {
-    SEG(pl, seg);
+    ADD_CHECK(pl != nullptr && seg >= 0 && seg < (int)pl->segs.size(), "bc_plan_add_op: bad segment id %d", seg);
+    Seg& sg = pl->segs[seg];
     const char* sig = op_signature(op);
-    BC_CHECK_ARG(sig != nullptr && (int)strlen(sig) == nargs && stream_id >= 0 && stream_id < kMaxStreams,
-                 "bc_plan_add_op: op %d takes %d arguments, got %d", op, sig ? (int)strlen(sig) : -1, nargs);
+    ADD_CHECK(sig != nullptr && (int)strlen(sig) == nargs && args != nullptr, "bc_plan_add_op: op %d takes %d arguments, got %d", op,
+              sig ? (int)strlen(sig) : -1, nargs);
+    ADD_CHECK(stream_id >= 0 && stream_id < kMaxStreams, "bc_plan_add_op: stream id %d out of range", stream_id);
     Rec r;
     r.op = op;
     r.sid = stream_id;

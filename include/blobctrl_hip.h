@@ -296,10 +296,10 @@ int bc_plan_destroy(BcPlan* plan);
 int bc_plan_segment(BcPlan* plan, const char* name);                       /* -> segment id, < 0 on error */
 int bc_plan_find_segment(BcPlan* plan, const char* name);                  /* -> segment id or -1 */
 int bc_plan_new_event(BcPlan* plan);                                       /* -> event id, < 0 on error */
-int bc_plan_add_gemm(BcPlan* plan, int seg, int stream_id, const BcGemm* g);             /* -> launch index; `slab` is taken from
+int bc_plan_add_gemm(BcPlan* plan, int seg, int stream_id, const BcGemm* g);             /* -> launch index (< 0 on error); `slab` is taken from
                                                                                           * bc_plan_set_slab(stream_id) at run time */
 /* args: the entry point's arguments in order WITHOUT the stream, one 64-bit word each (pointers as addresses, ints sign-extended,
- * floats as their 32-bit pattern); BC_OP_SIGNAL / BC_OP_WAIT take the event id. -> launch index */
+ * floats as their 32-bit pattern); BC_OP_SIGNAL / BC_OP_WAIT take the event id. -> launch index, < 0 on error */
 int bc_plan_add_op(BcPlan* plan, int seg, int stream_id, int op, const uint64_t* args, int nargs);
 int bc_plan_set_slab(BcPlan* plan, int stream_id, float* slab);
 int bc_plan_enable(BcPlan* plan, int seg, int index, int enabled);         /* diagnostics: skip / restore one launch (ablation probes) */

@@ -204,3 +204,57 @@ def test_scheduler_dropins_from_config_rules():
     copy.deepcopy(u)                                     # pipe:1021 deep-copies the scheduler
     with pytest.raises(NotImplementedError):
         UniPCMultistepScheduler(solver_order=3)
+
+
+def test_plan_runtime_op_signatures_match_the_library():
+    """Plan runtime (csrc/plan.hip) without a GPU: every recordable entry point takes exactly the argument count that the ctypes
+    signature table derives (a mismatch would scramble arguments at replay); wrong counts, unknown ops and bad ids are refused."""
+    import ctypes as C
+    lib = _lib.load()
+    plan = C.c_void_p()
+    assert lib.bc_plan_create(C.byref(plan)) == 0
+    seg = lib.bc_plan_segment(plan, b"t")
+    assert seg == 0 and lib.bc_plan_find_segment(plan, b"t") == 0 and lib.bc_plan_find_segment(plan, b"nope") == -1
+    n = 0
+    for name, op in _lib.OPS.items():
+        if name == "bc_gemm":
+            continue
+        sig = _lib.op_signature(name)
+        words = (C.c_uint64 * len(sig))()
+        assert lib.bc_plan_add_op(plan, seg, 0, op, words, len(sig)) == n, name
+        n += 1
+        assert lib.bc_plan_add_op(plan, seg, 0, op, words, len(sig) - 1) < 0, name       # wrong count is refused
+    ev = lib.bc_plan_new_event(plan)
+    one = (C.c_uint64 * 1)(ev)
+    assert lib.bc_plan_add_op(plan, seg, 1, _lib.OP_SIGNAL, one, 1) == n and lib.bc_plan_add_op(plan, seg, 0, _lib.OP_WAIT, one, 1) == n + 1
+    assert lib.bc_plan_num_launches(plan, seg) == n + 2 and lib.bc_plan_num_launches(plan, 7) == -1
+    assert lib.bc_plan_add_op(plan, seg, 0, 99, one, 1) < 0 and b"op 99" in lib.bc_last_error()
+    assert lib.bc_plan_add_op(plan, seg, 9, _lib.OP_WAIT, one, 1) < 0                    # stream id out of range
+    assert lib.bc_plan_enable(plan, seg, 0, 0) == 0 and lib.bc_plan_enable(plan, seg, 999, 0) != 0
+    g = _lib.BcGemm()
+    assert lib.bc_plan_add_gemm(plan, seg, 0, C.byref(g)) == n + 2
+    assert lib.bc_plan_destroy(plan) == 0
+
+
+def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
+    """The engine in compile-only mode records a whole tiny edit (prologue / active / inactive segments, two stream ids, events)
+    on the CPU and writes a relocatable plan file; a launch that points outside the declared buffers is refused."""
+    import struct
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from tests.common import TINY, tiny_weights
+    from tests.gpu_common import tiny_trunk_configs
+    usd, bsd = tiny_weights()
+    ucfg, bcfg = tiny_trunk_configs()
+    eng = BlobCtrlEngine(usd, bsd, ucfg, bcfg, device="cpu", scheduler="unipc", compile_only=True)
+    path = str(tmp_path / "t.bcplan")
+    seq = eng.compile_plan(path, 1, 8, 8, 7, TINY["ctx"], 6, blobnet_control_guidance_end=0.67)
+    assert seq == ["step_active"] * 4 + ["step_inactive"] * 2
+    raw = open(path, "rb").read()
+    magic, version, gsz, nbuf = struct.unpack("<IIII", raw[:16])
+    assert magic == 0x4E4C5042 and version == 1 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
+    for name in (b"latents", b"ctx", b"fg_lat", b"bg_lat", b"fg_score", b"bg_score", b"feat16", b"step_idx", b"coef", b"hist"):
+        assert name in raw
+    P = eng.plan_for(1, 8, 8, 7, TINY["ctx"], 6)
+    assert len(P.step_active) > len(P.step_inactive) > 100 and {m["sid"] for m in P.step_active.meta} == {0, 1}
+    with pytest.raises(_lib.BlobCtrlHipError):
+        BlobCtrlEngine(usd, bsd, ucfg, bcfg, device="cpu")                               # executing needs an MI355X
