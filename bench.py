@@ -164,7 +164,13 @@ def roofline(pipe, plan, res=512, batch=1):
     plan.step_active.run(s)                      # warm
     with torch.cuda.stream(pipe.stream):
         plan.step_idx.zero_()
-    timed = plan.step_active.run_timed(s)        # serial eager replay of the launch list, one HIP event pair per launch
+    # serial eager replay of the launch list, HIP events around every launch on the launch stream; a split-K GEMM is divided at an
+    # event between its main kernel and its reducer, so that every bucket below is ONE kernel, as rocprofv3 reports it
+    timed = []
+    for m, ms_main, ms_red in plan.step_active.run_timed_kernels(s):
+        timed.append((dict(m, variant=(m["variant"] or "").replace("+splitk_reduce", "")), ms_main))
+        if ms_red > 0:
+            timed.append((dict(kind="splitk_reduce", variant="splitk_reduce_kernel", flops=0, bytes=0, shape=m["shape"]), ms_red))
     pipe.stream.synchronize()
     by = {}
     for m, ms in timed:
@@ -206,7 +212,7 @@ def roofline(pipe, plan, res=512, batch=1):
         ovh.append(ms_.value)
         lib.bc_event_destroy(a_); lib.bc_event_destroy(b_)
     overhead_ms = sorted(ovh)[len(ovh) // 2]
-    cand = {k: a for k, a in by.items() if a["flops"] > 0 and "+splitk" not in k}
+    cand = {k: a for k, a in by.items() if a["flops"] > 0}
     dom = max(cand, key=lambda k: cand[k]["ms"] - cand[k]["n"] * overhead_ms)
     a = cand[dom]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12

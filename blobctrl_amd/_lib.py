@@ -97,6 +97,7 @@ _SIGNATURES = {
     "bc_plan_release": (C.c_int, [C.c_void_p, C.c_int]),
     "bc_plan_capture_loop": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "bc_plan_run_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "bc_plan_run_timed_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bc_plan_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]),
     "bc_plan_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bc_plan_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),

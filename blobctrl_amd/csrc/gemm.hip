@@ -411,6 +411,12 @@ extern "C" int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, i
     return bc_conv_halo_ok(p);
 }
 
+// Timing probe of bc_plan_run_timed_kernels: an event recorded between a split-K GEMM's main kernel and its reducer.
+static thread_local hipEvent_t tl_probe = nullptr;
+static thread_local bool tl_probe_hit = false;
+void bc_gemm_set_probe(hipEvent_t e) { tl_probe = e; tl_probe_hit = false; }
+bool bc_gemm_probe_hit() { return tl_probe_hit; }
+
 extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     BC_CHECK_ARG(pp != nullptr, "bc_gemm: null params");
@@ -525,6 +531,10 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         if (rc) return rc;
     }
     if (p.splitk > 1) {
+        if (tl_probe) {                                       // (profiling replays: where the main kernel ends and the reducer starts)
+            BC_CHECK_HIP(hipEventRecord(tl_probe, stream));
+            tl_probe_hit = true;
+        }
         if (g.vec_epilogue && p.N % 4 == 0) {
             hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(bc_ceil_div(g.n_out, 64), bc_ceil_div(p.M, SK_ROWS)), dim3(256), 0,
                                stream, g);

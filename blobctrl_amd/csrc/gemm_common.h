@@ -303,4 +303,6 @@ __device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, cons
 int bc_gemm_fast_try(const bcg::GemmArgs& g, hipStream_t stream);
 // conv_halo.hip: LDS-resident input-halo 3x3 convolution with the fused GroupNorm prologue (BC_TILE_HALO).
 int bc_conv_halo_ok(const BcGemm& p);
+void bc_gemm_set_probe(hipEvent_t e);      // gemm.hip: event recorded between the main kernel and the split-K reducer (nullptr: off)
+bool bc_gemm_probe_hit();
 int bc_conv_halo_launch(bcg::GemmArgs& g, hipStream_t stream);

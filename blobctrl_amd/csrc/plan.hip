@@ -20,6 +20,9 @@
 #include <vector>
 #include "bc_common.h"
 
+void bc_gemm_set_probe(hipEvent_t e);      // gemm.hip (timing probe between a split-K GEMM's main kernel and its reducer)
+bool bc_gemm_probe_hit();
+
 namespace {
 
 // argument kinds of the recordable entry points (stream argument excluded): p = device pointer, i = int, f = float, l = long long
@@ -389,6 +392,42 @@ extern "C" int bc_plan_run_timed(BcPlan* pl, int seg, bc_stream stream, float* m
     if (!rc) {
         BC_CHECK_HIP(hipStreamSynchronize(st[0]));
         for (size_t i = 0; i < sg.recs.size(); ++i) BC_CHECK_HIP(hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// Like bc_plan_run_timed, but a split-K GEMM's time is divided at an event recorded between its main kernel and its reducer:
+// ms_main[i] is then the duration rocprofv3 reports for the main kernel of launch i, ms_reduce[i] that of its reducer (0 if none).
+extern "C" int bc_plan_run_timed_kernels(BcPlan* pl, int seg, bc_stream stream, float* ms_main, float* ms_reduce) {
+    SEG(pl, seg);
+    BC_CHECK_ARG(ms_main != nullptr && ms_reduce != nullptr, "bc_plan_run_timed_kernels: null output");
+    hipStream_t st[kMaxStreams];
+    for (int i = 0; i < kMaxStreams; ++i) st[i] = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = sg.recs.size();
+    std::vector<hipEvent_t> ev(3 * n);
+    for (auto& e : ev) BC_CHECK_HIP(hipEventCreate(&e));
+    std::vector<char> split(n, 0);
+    int rc = 0;
+    for (size_t i = 0; i < n && !rc; ++i) {
+        BC_CHECK_HIP(hipEventRecord(ev[3 * i], st[0]));
+        bc_gemm_set_probe(ev[3 * i + 1]);
+        if (sg.recs[i].enabled) rc = launch_rec(pl, sg.recs[i], st, kMaxStreams);
+        split[i] = bc_gemm_probe_hit();
+        bc_gemm_set_probe(nullptr);
+        BC_CHECK_HIP(hipEventRecord(ev[3 * i + 2], st[0]));
+    }
+    if (!rc) {
+        BC_CHECK_HIP(hipStreamSynchronize(st[0]));
+        for (size_t i = 0; i < n; ++i) {
+            if (split[i]) {
+                BC_CHECK_HIP(hipEventElapsedTime(&ms_main[i], ev[3 * i], ev[3 * i + 1]));
+                BC_CHECK_HIP(hipEventElapsedTime(&ms_reduce[i], ev[3 * i + 1], ev[3 * i + 2]));
+            } else {
+                BC_CHECK_HIP(hipEventElapsedTime(&ms_main[i], ev[3 * i], ev[3 * i + 2]));
+                ms_reduce[i] = 0.f;
+            }
+        }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;

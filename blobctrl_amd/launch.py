@@ -113,6 +113,13 @@ class Segment:
         _lib.check(self.rec.lib.bc_plan_run_timed(self.rec.plan, self.id, stream, ms), "bc_plan_run_timed")
         return [(m, ms[i]) for i, m in enumerate(self.meta)]
 
+    def run_timed_kernels(self, stream: int):
+        """As run_timed, with every split-K GEMM divided into (main kernel, reducer): list of (meta, ms_main, ms_reduce)."""
+        n = len(self.meta)
+        a, b = (C.c_float * max(1, n))(), (C.c_float * max(1, n))()
+        _lib.check(self.rec.lib.bc_plan_run_timed_kernels(self.rec.plan, self.id, stream, a, b), "bc_plan_run_timed_kernels")
+        return [(m, a[i], b[i]) for i, m in enumerate(self.meta)]
+
     def enable(self, index: int, on: bool):
         """Diagnostics (ablation probes): skip / restore one launch; re-capture afterwards."""
         _lib.check(self.rec.lib.bc_plan_enable(self.rec.plan, self.id, index, 1 if on else 0), "bc_plan_enable")

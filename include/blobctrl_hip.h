@@ -309,6 +309,8 @@ int bc_plan_capture(BcPlan* plan, int seg, const bc_stream* streams, int nstream
 int bc_plan_release(BcPlan* plan, int seg);                                /* drop the segment's graph (back to eager replay) */
 int bc_plan_capture_loop(BcPlan* plan, const int* seg_sequence, int n, const bc_stream* streams, int nstreams, void** graph_exec_out);
 int bc_plan_run_timed(BcPlan* plan, int seg, bc_stream stream, float* ms_out /* [bc_plan_num_launches] */);
+/* same, with a split-K GEMM's time divided into its main kernel and its reducer (ms_reduce[i] = 0 when launch i has none) */
+int bc_plan_run_timed_kernels(BcPlan* plan, int seg, bc_stream stream, float* ms_main, float* ms_reduce);
 int bc_plan_save(BcPlan* plan, const char* path, const BcPlanBuffer* buffers, int nbuffers);
 int bc_plan_load(const char* path, BcPlan** out);
 int bc_plan_buffer(BcPlan* plan, const char* name, void** ptr, long long* bytes);

@@ -95,3 +95,77 @@ def pipeline_cases():
                       blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0, num_images_per_prompt=1, seed=3, rng_seed=13,
                       scheduler="unipc"),
     }
+
+
+# ------------------------------------------------------------------------------------------------ block-level cases
+# name -> (kind, parameters).  Weights come from blobctrl_amd.synth (PCG64 keyed by parameter name) on both sides; inputs from g().
+BLOCK_SEED = 31
+BLOCK_CASES = {
+    "res_320_320": ("resnet", dict(cin=320, cout=320, B=2, H=8, W=16)),
+    "res_320_640_shortcut": ("resnet", dict(cin=320, cout=640, B=2, H=8, W=16)),
+    "res_2560_1280": ("resnet", dict(cin=2560, cout=1280, B=1, H=4, W=8)),
+    "tfm_320_cross": ("transformer", dict(C=320, heads=8, ctx=768, B=2, H=8, W=16)),
+    "tfm_320_self_only": ("transformer", dict(C=320, heads=8, ctx=None, B=2, H=8, W=16)),
+    "up_scale2": ("upsample", dict(C=320, B=1, H=4, W=8, size=None)),
+    "up_explicit_size": ("upsample", dict(C=320, B=1, H=3, W=6, size=(5, 12))),
+    "down": ("downsample", dict(C=320, B=1, H=8, W=16)),
+}
+BLOCK_TIMESTEPS = (999, 981, 500, 1)
+
+
+def block_param_shapes(kind, p):
+    """Parameter names / shapes of ONE diffusers block, as its state_dict() spells them (pinned by tools/make_golden.py: strict load)."""
+    from collections import OrderedDict
+    sh = OrderedDict()
+    if kind == "resnet":
+        ci, co = p["cin"], p["cout"]
+        sh["norm1.weight"], sh["norm1.bias"] = (ci,), (ci,)
+        sh["conv1.weight"], sh["conv1.bias"] = (co, ci, 3, 3), (co,)
+        sh["time_emb_proj.weight"], sh["time_emb_proj.bias"] = (co, 1280), (co,)
+        sh["norm2.weight"], sh["norm2.bias"] = (co,), (co,)
+        sh["conv2.weight"], sh["conv2.bias"] = (co, co, 3, 3), (co,)
+        if ci != co:
+            sh["conv_shortcut.weight"], sh["conv_shortcut.bias"] = (co, ci, 1, 1), (co,)
+    elif kind == "transformer":
+        C, ctx = p["C"], p["ctx"]
+        sh["norm.weight"], sh["norm.bias"] = (C,), (C,)
+        sh["proj_in.weight"], sh["proj_in.bias"] = (C, C, 1, 1), (C,)
+        b = "transformer_blocks.0."
+        sh[b + "norm1.weight"], sh[b + "norm1.bias"] = (C,), (C,)
+        for n in ("to_q", "to_k", "to_v"):
+            sh[b + f"attn1.{n}.weight"] = (C, C)
+        sh[b + "attn1.to_out.0.weight"], sh[b + "attn1.to_out.0.bias"] = (C, C), (C,)
+        if ctx is not None:
+            sh[b + "norm2.weight"], sh[b + "norm2.bias"] = (C,), (C,)
+            sh[b + "attn2.to_q.weight"] = (C, C)
+            sh[b + "attn2.to_k.weight"], sh[b + "attn2.to_v.weight"] = (C, ctx), (C, ctx)
+            sh[b + "attn2.to_out.0.weight"], sh[b + "attn2.to_out.0.bias"] = (C, C), (C,)
+        sh[b + "norm3.weight"], sh[b + "norm3.bias"] = (C,), (C,)
+        sh[b + "ff.net.0.proj.weight"], sh[b + "ff.net.0.proj.bias"] = (8 * C, C), (8 * C,)
+        sh[b + "ff.net.2.weight"], sh[b + "ff.net.2.bias"] = (C, 4 * C), (C,)
+        sh["proj_out.weight"], sh["proj_out.bias"] = (C, C, 1, 1), (C,)
+    elif kind in ("upsample", "downsample"):
+        sh["conv.weight"], sh["conv.bias"] = (p["C"], p["C"], 3, 3), (p["C"],)
+    elif kind == "time":
+        sh["linear_1.weight"], sh["linear_1.bias"] = (1280, 320), (1280,)
+        sh["linear_2.weight"], sh["linear_2.bias"] = (1280, 1280), (1280,)
+    return sh
+
+
+def block_weights(name):
+    from blobctrl_amd import synth
+    kind, p = ("time", {}) if name == "time" else BLOCK_CASES[name]
+    # (seed differs per case so that equally named parameters of two cases are not the same numbers)
+    seed = BLOCK_SEED + (sorted(BLOCK_CASES).index(name) if name != "time" else 99)
+    return synth.synth_state_dict(block_param_shapes(kind, p), seed)
+
+
+def block_inputs(name):
+    """(x NCHW, temb [B,1280] or None, context [B,7,ctx] or None) of a block case."""
+    kind, p = BLOCK_CASES[name]
+    i = sorted(BLOCK_CASES).index(name)
+    C = p.get("cin", p.get("C"))
+    x = g(500 + i, p["B"], C, p["H"], p["W"])
+    temb = g(600 + i, p["B"], 1280) if kind == "resnet" else None
+    ctx = g(700 + i, p["B"], 7, p["ctx"]) if kind == "transformer" and p["ctx"] is not None else None
+    return x, temb, ctx

@@ -538,3 +538,22 @@ def test_lora_merged_equals_runtime_low_rank_branch_full_size(rec, kind):
     close(merged, ref, rtol=4e-3, what=f"merged LoRA {kind} vs fp32")
     close(branch, ref, rtol=6e-3, what=f"runtime LoRA branch {kind} vs fp32")
     close(merged, branch, rtol=8e-3, what=f"merged vs runtime branch {kind}")
+
+
+def test_run_timed_kernels_divides_a_splitk_gemm(rec):
+    """bc_plan_run_timed_kernels: per-launch HIP-event times with a split-K GEMM divided into main kernel and reducer (what
+    bench.py's roofline uses so that its per-kernel durations are comparable with rocprofv3's)."""
+    M, N, K = 256, 1280, 11520
+    A, W = g(1, M, K), g(2, N, K) / math.sqrt(K)
+    seg = rec.begin("timed")
+    rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), splitk=6)
+    rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), splitk=1)
+    s = torch.cuda.current_stream().cuda_stream
+    seg.run(s)
+    torch.cuda.synchronize()
+    rows = seg.run_timed_kernels(s)
+    whole = seg.run_timed(s)
+    assert len(rows) == len(whole) == 2
+    (_, main0, red0), (_, main1, red1) = rows
+    assert main0 > 0 and red0 > 0 and main1 > 0 and red1 == 0.0
+    assert abs((main0 + red0) - whole[0][1]) < 0.5 * whole[0][1] + 0.05      # same launches, separately timed replays

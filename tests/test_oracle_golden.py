@@ -146,3 +146,39 @@ def test_clip_text_oracle_vs_transformers_fixture(golden_dir):
     # both key layouts (with / without the "text_model." prefix) are accepted
     bare = {k[len("text_model."):]: v for k, v in sd.items()}
     assert torch.equal(clip_text_hidden(bare, ids, 4), clip_text_hidden(sd, ids, 4))
+
+
+def oracle_block(name):
+    """The oracle's restatement of one block case of tests/common.py BLOCK_CASES."""
+    from tests.common import BLOCK_CASES, block_inputs, block_weights
+    kind, p = BLOCK_CASES[name]
+    sd = block_weights(name)
+    x, temb, ctx = block_inputs(name)
+    if kind == "resnet":
+        return nets.resnet_block(sd, "", x, temb, 32)
+    if kind == "transformer":
+        return nets.transformer_2d(sd, "", x, ctx, p["heads"], 32)
+    if kind == "upsample":
+        return nets.upsample(sd, "", x, size=p["size"])
+    return nets.downsample(sd, "", x)
+
+
+@pytest.mark.parametrize("name", ["res_320_320", "res_320_640_shortcut", "res_2560_1280", "tfm_320_cross", "tfm_320_self_only",
+                                  "up_scale2", "up_explicit_size", "down"])
+def test_blocks_vs_reference_fixture(golden_dir, name):
+    """SURVEY 8c.2 block-level goldens (diffusers' own ResnetBlock2D / Transformer2DModel / Upsample2D / Downsample2D at SD-1.5 widths)."""
+    z = load(golden_dir, "blocks.npz")
+    y = oracle_block(name).numpy()
+    assert y.shape == z[name].shape
+    np.testing.assert_allclose(y, z[name], rtol=1e-4, atol=1e-4)
+
+
+def test_time_embedding_vs_reference_fixture(golden_dir):
+    from tests.common import BLOCK_TIMESTEPS, block_weights
+    z = load(golden_dir, "blocks.npz")
+    t = torch.tensor(BLOCK_TIMESTEPS)
+    np.testing.assert_allclose(nets.timestep_embedding(t, 320).numpy(), z["time_sinusoid"], rtol=1e-5, atol=1e-5)
+    sd = {"time_embedding." + k: v for k, v in block_weights("time").items()}
+    cfg = nets.NetConfig(in_channels=4)
+    for i, ti in enumerate(BLOCK_TIMESTEPS):
+        np.testing.assert_allclose(nets.time_embed(sd, ti, 1, cfg).numpy()[0], z["time_emb"][i], rtol=1e-4, atol=1e-4)

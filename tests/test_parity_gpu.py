@@ -114,8 +114,10 @@ def test_denoise_loop_matches_reference(golden_dir, tag, graphs):
     out = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=steps, guidance_scale=7.5,
                latents=a["latents"], blobnet_control_guidance_start=gs, blobnet_control_guidance_end=ge).cpu().numpy()
     ref = z[f"{tag}_final"]
-    assert rel_err(out, ref) < 3e-2, f"free-running rel err {rel_err(out, ref):.3e}"
-    assert psnr(out, ref) > 36.0
+    print(f"{tag}: free-running final latents rel err {rel_err(out, ref):.3e}, PSNR {psnr(out, ref):.1f} dB")
+    # the BASELINE.json bar on the free-running result too (measured: rel 3.3e-3 .. 4.2e-3, 58.5 .. 59.8 dB)
+    assert rel_err(out, ref) < 1e-2, f"free-running rel err {rel_err(out, ref):.3e}"
+    assert psnr(out, ref) > 40.0
     # determinism / idempotence of the captured graphs: a second call gives bit-identical latents
     out2 = pipe(a["prompt"], a["fg"], a["bg"], a["score"], a["dino"], num_inference_steps=steps, guidance_scale=7.5,
                 latents=a["latents"], blobnet_control_guidance_start=gs, blobnet_control_guidance_end=ge).cpu().numpy()

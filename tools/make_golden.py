@@ -502,6 +502,50 @@ def golden_pipeline_call():
     np.savez_compressed(os.path.join(OUT, "pipeline_call.npz"), **out)
 
 
+def golden_blocks():
+    """single diffusers blocks at SD-1.5 widths on small feature maps (resnet.py:320-373, transformer_2d.py:479-527,
+    upsampling.py:141-184, downsampling.py:132-149, embeddings.py:27-78 + 576-588).  Only the OUTPUTS are stored (fp32); weights and
+    inputs are regenerated from seeds on both sides (tests/common.py block_weights / block_inputs)."""
+    from diffusers.models.resnet import ResnetBlock2D
+    from diffusers.models.transformers.transformer_2d import Transformer2DModel
+    from diffusers.models.upsampling import Upsample2D
+    from diffusers.models.downsampling import Downsample2D
+    from diffusers.models.embeddings import Timesteps, TimestepEmbedding
+    from tests.common import BLOCK_CASES, BLOCK_TIMESTEPS, block_inputs, block_weights
+    out = {}
+    for name, (kind, p) in BLOCK_CASES.items():
+        x, temb, ctx = block_inputs(name)
+        if kind == "resnet":       # as the UNet blocks build it (unet_2d_blocks.py: eps=resnet_eps=1e-5, groups=32, temb 1280)
+            m = ResnetBlock2D(in_channels=p["cin"], out_channels=p["cout"], temb_channels=1280, eps=1e-5, groups=32)
+        elif kind == "transformer":
+            m = Transformer2DModel(num_attention_heads=p["heads"], attention_head_dim=p["C"] // p["heads"], in_channels=p["C"],
+                                   num_layers=1, cross_attention_dim=p["ctx"], norm_num_groups=32)
+        elif kind == "upsample":
+            m = Upsample2D(p["C"], use_conv=True, out_channels=p["C"])
+        else:
+            m = Downsample2D(p["C"], use_conv=True, out_channels=p["C"], padding=1, name="op")
+        m.eval()
+        sd = block_weights(name)
+        assert set(sd.keys()) == set(m.state_dict().keys()), (name, set(sd.keys()) ^ set(m.state_dict().keys()))
+        m.load_state_dict(sd, strict=True)
+        if kind == "resnet":
+            y = m(x, temb)
+        elif kind == "transformer":
+            y = m(x, encoder_hidden_states=ctx, return_dict=False)[0]
+        elif kind == "upsample":
+            y = m(x, output_size=p["size"])
+        else:
+            y = m(x)
+        out[name] = y.numpy().astype(np.float32)
+        print(f"block {name}: out {tuple(y.shape)} std {float(y.std()):.4f}")
+    proj, emb = Timesteps(320, True, 0), TimestepEmbedding(320, 1280).eval()
+    emb.load_state_dict(block_weights("time"), strict=True)
+    t = torch.tensor(BLOCK_TIMESTEPS)
+    out["time_sinusoid"] = proj(t).numpy()
+    out["time_emb"] = emb(proj(t)).numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for fn in sys.argv[1:]:
@@ -518,6 +562,7 @@ if __name__ == "__main__":
     golden_dinov2()
     golden_nets()
     golden_loop()
+    golden_blocks()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  %-24s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
