@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bc_gemm_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bc_conv_halo_eligible": (C.c_int, [C.c_int] * 8),
+    "bc_conv_halo_max_chunks": (C.c_int, []),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

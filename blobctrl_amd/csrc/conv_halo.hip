@@ -8,9 +8,11 @@
 // Work decomposition
 //   workgroup = 8 x 16 output pixels (BM = 128 rows) x BN = 160 output channels, 8 waves.
 //   K loop    = input channels in chunks of 64; per chunk the (8+2) x (16+2) pixel halo of the input is brought into LDS ONCE
-//               (LDS-DMA of the raw fp16 rows, then a register pass  y = silu?(a[b][c] * x + b[b][c])  that writes the swizzled
-//               operand image; out-of-image pixels are written as zeros AFTER the activation = the convolution's zero padding)
-//               and serves all nine taps; only the weights stream per tap (LDS-DMA, 3-stage ring, counted vmcnt, raw s_barrier).
+//               (LDS-DMA of the raw fp16 rows straight into their final, swizzled slots of the operand image - the swizzle is
+//               applied to the SOURCE address - then an in-place register pass  y = silu?(a[b][c] * x + b[b][c]); out-of-image
+//               pixels are written as zeros AFTER the activation = the convolution's zero padding) and serves all nine taps;
+//               only the weights stream per tap (LDS-DMA, NSTG-stage ring = NSTG-1 taps in flight, counted vmcnt, raw s_barrier:
+//               the low-resolution levels are bound by the weight bytes a CU keeps in flight).
 //               LDS-DMA pieces per MFMA are ~0.45x the implicit-GEMM kernel's, and the 9x re-read of the input from L2 is gone.
 //   waves     = 2 (pixel halves) x 2 (channel halves) x 2 (K halves of every 64-channel chunk); wave tile 64 x 80 = 4 x 5 MFMA tiles,
 //               9 ds_read_b128 per 20 MFMAs; the two K halves are summed through LDS in the epilogue.
@@ -18,7 +20,10 @@
 // Swizzle: 16-byte chunk c of a 128-byte operand row is stored at chunk c ^ (((r >> 1) & 3) << 1) with r = halo x (A image) or
 // weight row (B image): with the 16x16x32 fragment map (lane -> row l & 15, chunk l >> 4) every ds_read_b128 lane group then
 // touches 16 distinct 16-byte slots of the 256-byte bank row.
+#include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -40,21 +45,26 @@ constexpr int HBM = TW * TH;                    // 128 output pixels per workgro
 constexpr int HBN = 160;                        // output channels per workgroup
 constexpr int HSTR = TW + 2;                    // halo row stride (pixels)
 constexpr int HPIX = (TH + 2) * HSTR;           // 180 halo pixels
-constexpr int HALO_BYTES = HPIX * 128;          // one 64-channel chunk of the halo (swizzled operand image)
-constexpr int RAW_PIECES = 24;                  // raw landing area: 24 x 1 KiB = 192 pixel slots
-constexpr int RAW_BYTES = RAW_PIECES * 1024;
+constexpr int HALO_BYTES = 24 * 1024;           // one 64-channel chunk of the halo (swizzled operand image): 24 LDS-DMA pieces of 1 KiB
+                                                // = 192 pixel slots, the last 12 are padding (the DMA count per wave stays uniform)
 constexpr int B_PIECES = HBN / 8;               // 20 x 1 KiB per weight stage (one tap of one chunk)
 constexpr int STAGE_BYTES = HBN * 128;
-constexpr int MAX_CH = 40;                      // channel chunks per workgroup (the affine table of the chunk range lives in LDS)
+#ifndef BC_HALO_NSTG
+#define BC_HALO_NSTG 5
+#endif
+constexpr int NSTG = BC_HALO_NSTG;              // weight ring depth
+constexpr int DEPTH = NSTG - 1;                 // taps issued ahead
 constexpr int OFF_HALO = 0;
-constexpr int OFF_RAW = 2 * HALO_BYTES;
-constexpr int OFF_B = OFF_RAW + RAW_BYTES;
-constexpr int OFF_AB = OFF_B + 3 * STAGE_BYTES;
+constexpr int OFF_B = 2 * HALO_BYTES;
+constexpr int OFF_AB = OFF_B + NSTG * STAGE_BYTES;
+constexpr int MAX_CH = (160 * 1024 - OFF_AB) / 512 < 40 ? (160 * 1024 - OFF_AB) / 512 : 40;   // channel chunks per workgroup (the affine
+                                                // table of the chunk range lives in LDS: 64 x (a, b) x 4 bytes per chunk)
 constexpr int LDS_TOTAL = OFF_AB + MAX_CH * 64 * 8;
 constexpr int TS = HBN + 4;                     // epilogue tile row stride (floats)
 constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
 static_assert(OFF_SCR + 24 * HBN * 2 * 4 <= LDS_TOTAL, "epilogue scratch does not fit");
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+static_assert(MAX_CH >= 20 && HPIX * 128 <= HALO_BYTES, "halo layout");
 
 template <int N>
 __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -67,7 +77,16 @@ __device__ __forceinline__ void wait_vm(int n) {      // n is wave-uniform
         case 3: wait_vm_c<3>(); break;
         case 4: wait_vm_c<4>(); break;
         case 5: wait_vm_c<5>(); break;
-        default: wait_vm_c<6>(); break;
+        case 6: wait_vm_c<6>(); break;
+        case 7: wait_vm_c<7>(); break;
+        case 8: wait_vm_c<8>(); break;
+        case 9: wait_vm_c<9>(); break;
+        case 10: wait_vm_c<10>(); break;
+        case 11: wait_vm_c<11>(); break;
+        case 12: wait_vm_c<12>(); break;
+        case 13: wait_vm_c<13>(); break;
+        case 14: wait_vm_c<14>(); break;
+        default: wait_vm_c<15>(); break;
     }
 }
 
@@ -98,6 +117,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const int H = p.Hin, W = p.Win;
 
     const int dbg = g.halo_dbg;                              // BC_HALO_DBG ablation bits (diagnostics only; results are wrong when set)
+    unsigned long long* const stamps = g.halo_stamps;        // BC_HALO_STAMPS diagnostics (null in production)
+    auto stamp = [&](int i) {
+        if (stamps && tid == 0) stamps[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const int c_begin = split * g.halo_cps;
     const int nch = min(g.halo_nch, c_begin + g.halo_cps) - c_begin;
     const int NT = nch * 9;
@@ -108,18 +132,21 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const h16* zero = reinterpret_cast<const h16*>(g_zero_line_h);
 
     // ---- this lane's three halo slots: the 16 bytes it brings in by LDS-DMA are the 16 bytes it later transforms ----
-    const int sub = tid & 7;                                  // 8-channel sub-chunk of the 64-channel chunk
-    int pix[3];                                               // input pixel index (b, gy, gx) or -1
-    int hdst[3];                                              // byte offset in the swizzled halo image, or -1 (slot beyond the halo)
+    // LDS-DMA lands lane-linearly: slot (tid, q) IS bytes [tid * 16 + 8192 q, +16) of the operand image = halo pixel
+    // hp = (tid >> 3) + 64 q, 16-byte slot tid & 7; the swizzle (chunk c lives in slot c ^ swz(hx)) is therefore applied to the
+    // source: this lane fetches 8-channel sub-chunk csub = (tid & 7) ^ swz(hx).
+    int pix[3];                                               // input pixel index (b, gy, gx) or -1 (outside the image / padding slot)
+    int csub[3];                                              // 8-channel sub-chunk of the 64-channel chunk this slot holds
+    bool in_halo[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int hp = (tid >> 3) + 64 * q;
         const int hy = hp / HSTR, hx = hp - hy * HSTR;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool in_halo = hp < HPIX;
-        const bool in_img = in_halo && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        in_halo[q] = hp < HPIX;
+        const bool in_img = in_halo[q] && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         pix[q] = in_img ? (b * H + gy) * W + gx : -1;
-        hdst[q] = in_halo ? hp * 128 + ((sub ^ (((hx >> 1) & 3) << 1)) << 4) : -1;
+        csub[q] = (tid & 7) ^ (((hx >> 1) & 3) << 1);
     }
     // ---- weight pieces of this wave (1 KiB = 8 rows x 128 B; waves 0-3 carry three, waves 4-7 two) ----
     const int LB = wave < 4 ? 3 : 2;
@@ -141,16 +168,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const int nl = wn * 80 + (lane & 15);
     const int b_off = OFF_B + nl * 128 + (((4 * kg + (lane >> 4)) ^ (((nl >> 1) & 3) << 1)) << 4);
 
-    auto issue_a = [&](int cl) {                              // raw rows of chunk c_begin + cl -> landing area
+    auto issue_a = [&](int cl) {                              // raw rows of chunk c_begin + cl -> operand image (cl & 1)
         const int k0 = (c_begin + cl) * 64;
         const bool second = A2 != nullptr && k0 >= p.C1;      // wave-uniform (C1 % 64 == 0)
         const h16* src = second ? A2 : A1;
         const long long stride = second ? p.lda2 : p.lda;
-        const int kin = (second ? k0 - p.C1 : k0) + sub * 8;
+        const int kin = second ? k0 - p.C1 : k0;
+        char* dst = smem + OFF_HALO + (cl & 1) * HALO_BYTES;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const h16* s = pix[q] >= 0 ? src + (long long)pix[q] * stride + kin : zero;
-            glds16(s, smem + OFF_RAW + (wave + 8 * q) * 1024);
+            const h16* s = pix[q] >= 0 ? src + (long long)pix[q] * stride + kin + csub[q] * 8 : zero;
+            glds16(s, dst + (wave + 8 * q) * 1024);
         }
     };
     auto issue_b = [&](int kt, int stage) {                   // weights of flattened (chunk, tap) index kt -> ring stage
@@ -160,31 +188,31 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         for (int q = 0; q < 3; ++q)
             if (q < LB) glds16(Wt + woff[q] + koff, smem + OFF_B + stage * STAGE_BYTES + (wave + 8 * q) * 1024);
     };
-    const unsigned raw_addr = (unsigned)(size_t)(lptr_t)(smem) + tid * 16;      // LDS byte address of this lane's slot 0 (minus OFF_RAW)
-    const unsigned ab_base = (unsigned)(size_t)(lptr_t)(smem) + OFF_AB + sub * 64;   // this lane's 8 (a, b) pairs inside a chunk
-    // Landing area -> operand image, this lane's slot q, in two halves so that the LDS latency hides behind the tap's MFMAs:
-    //   tr_issue  (top of the tap, BEFORE the fragment reads so hipcc's own counted lgkmcnt waits stay conservative): raw slot + the
-    //             chunk's 8 (a, b) pairs, no wait;
-    //   tr_finish (after the MFMAs): wait, normalise + activate, store the swizzled slot.
+    unsigned slot_addr = (unsigned)(size_t)(lptr_t)(smem) + OFF_HALO + tid * 16;   // LDS byte address of this lane's slot 0, image 0
+    unsigned ab_base = (unsigned)(size_t)(lptr_t)(smem) + OFF_AB;
+    // In-place pass over this lane's slot q of the image that just landed, in two halves so that the LDS latency hides behind the
+    // tap's MFMAs (only with a GroupNorm in front, AFFINE != 0: a plain convolution's rows are final as they land):
+    //   tr_issue  (top of the tap, BEFORE the fragment reads so hipcc's own counted lgkmcnt waits stay conservative): the slot + the
+    //             8 (a, b) pairs of its channels, no wait;
+    //   tr_finish (after the MFMAs): wait, normalise + activate, store the slot back.
     // Inline asm throughout: hipcc orders every plain LDS access it cannot prove disjoint behind ALL LDS-DMA writes in flight
     // (`s_waitcnt vmcnt(0)`: it does not see the counted waits), which would drain the weight ring at every slice.  The lane's own
     // slot IS complete (see the wait accounting in the tap loop).
     struct Pending { u32x4v raw; f32x4v t0, t1, t2, t3; };
     auto tr_issue = [&](auto qc, int cl, Pending& pd) {
         constexpr int q = decltype(qc)::value;
-        if (hdst[q] < 0) return;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pd.raw) : "v"(raw_addr), "n"(OFF_RAW + 8192 * q) : "memory");
-        if (AFFINE) {
-            const unsigned ab_addr = ab_base + cl * 512;            // (64 channels x (a, b) x 4 bytes per chunk)
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-                         "ds_read_b128 %3, %4 offset:48"
-                         : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
-        }
+        if (!AFFINE || !in_halo[q]) return;
+        const unsigned sa = slot_addr + (cl & 1) * HALO_BYTES;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pd.raw) : "v"(sa), "n"(8192 * q) : "memory");
+        const unsigned ab_addr = ab_base + cl * 512 + csub[q] * 64;     // (64 channels x (a, b) x 4 bytes per chunk)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                     "ds_read_b128 %3, %4 offset:48"
+                     : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
     };
-    auto tr_finish = [&](auto qc, char* dst_buf, Pending& pd) {
+    auto tr_finish = [&](auto qc, int cl, Pending& pd) {
         constexpr int q = decltype(qc)::value;
-        if (hdst[q] < 0) return;
-        if (AFFINE) {
+        if (!AFFINE || !in_halo[q]) return;
+        {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3)::"memory");
             __builtin_amdgcn_sched_barrier(0);
             const float aa[8] = {pd.t0[0], pd.t0[2], pd.t1[0], pd.t1[2], pd.t2[0], pd.t2[2], pd.t3[0], pd.t3[2]};
@@ -201,28 +229,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             }
             if (pix[q] < 0) outraw = (u32x4v){0u, 0u, 0u, 0u};       // zero padding is applied AFTER norm + activation
             pd.raw = outraw;
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw)::"memory");
-            __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(lptr_t)(dst_buf) + (unsigned)hdst[q]), "v"(pd.raw) : "memory");
+        const unsigned sa = slot_addr + (cl & 1) * HALO_BYTES;
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(sa), "v"(pd.raw), "n"(8192 * q) : "memory");
     };
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
 
-    // ---- prologue: affine table of this chunk range -> LDS, first halo chunk, first two weight stages ----
-    if (AFFINE == 1) {
-        const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
-        float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
-        for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
-    }
-    issue_a(0);
-    issue_b(0, 0);
-    issue_b(1, 1);
+    // ---- prologue: affine table of this chunk range -> LDS, first halo chunk, first DEPTH weight stages ----
     if (AFFINE == 2) {
         // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the producers' per-channel
-        // partials (fixed summation order: bit-reproducible).  Scratch = the two halo buffers (no LDS-DMA lands there).
+        // partials (fixed summation order: bit-reproducible).  Scratch = the two halo images (before any LDS-DMA is issued).
         const int cpg = p.Cin / p.a_groups;
         const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
         const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
@@ -277,18 +295,29 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         }
         __syncthreads();                                                  // scratch is free again before the first halo is written
     }
-    wait_vm(2 * LB);                                          // my three halo slots have landed (weights may still fly)
+    // (the in-kernel finalize above used the halo images as scratch: the DMAs start after it)
+    stamp(1);
+    issue_a(0);
+    const int npre = DEPTH < NT ? DEPTH : NT;
+    for (int i = 0; i < npre; ++i) issue_b(i, i);
+    if (AFFINE == 1) {                                        // (its global loads fly together with the DMAs above)
+        const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
+        float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
+        for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
+    }
+    wait_vm((dbg & (3 | 64)) ? 0 : npre * LB);                // my three halo slots have landed (weights may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // affine table visible
     asm volatile("" ::: "memory");
+    stamp(2);
     {
         Pending p0, p1, p2;
         tr_issue(Q0{}, 0, p0);
         tr_issue(Q1{}, 0, p1);
         tr_issue(Q2{}, 0, p2);
-        tr_finish(Q0{}, smem + OFF_HALO, p0);
-        tr_finish(Q1{}, smem + OFF_HALO, p1);
-        tr_finish(Q2{}, smem + OFF_HALO, p2);
+        tr_finish(Q0{}, 0, p0);
+        tr_finish(Q1{}, 0, p1);
+        tr_finish(Q2{}, 0, p2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -298,26 +327,30 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
+    stamp(3);
+    int st = 0;                                               // ring stage of the current tap
     for (int cl = 0; cl < nch; ++cl) {
         const bool has_next = cl + 1 < nch;
         const char* hb = smem + OFF_HALO + (cl & 1) * HALO_BYTES;
-        char* hb_next = smem + OFF_HALO + ((cl + 1) & 1) * HALO_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kt = cl * 9 + tap;
-            // Counted wait: the weights of THIS tap must have landed; what may stay in flight is whatever this wave issued after
-            // them, in order: the next tap's stage, and (taps 1 and 2) the raw halo rows of the next chunk issued during tap 0.
-            int pend = (kt + 1 < NT) ? LB : 0;
-            if ((tap == 1 || tap == 2) && has_next) pend += 3;
+            // Counted wait: the weights of THIS tap must have landed.  What may stay in flight is whatever this wave issued after
+            // them, in order: the taps kt+1 .. kt+DEPTH-1 and - the next chunk's halo rows are issued at tap 0 BEFORE that tap's
+            // weight stage - those rows while they are younger than this tap's weights (taps 1 .. DEPTH-1), but no later than
+            // tap 2: from tap 3 on the in-place pass reads them.
+            const int ahead = NT - 1 - kt < DEPTH - 1 ? NT - 1 - kt : DEPTH - 1;
+            int pend = ahead * LB;
+            if (has_next && tap >= 1 && tap <= (DEPTH - 1 < 2 ? DEPTH - 1 : 2)) pend += 3;
             if (dbg & (3 | 64)) pend = 0;
             wait_vm(pend);
-            if (!(dbg & 16)) __builtin_amdgcn_s_barrier();    // stage `tap % 3` complete for every wave; stage (tap + 2) % 3 is free
+            if (!(dbg & 16)) __builtin_amdgcn_s_barrier();    // stage `st` complete for every wave; the stage of tap kt-1 is free
             asm volatile("" ::: "memory");
             const int ky = tap / 3, kx = tap - ky * 3;
             // next chunk's operand image, one 16-byte slot per lane at a time, spread over taps 3..8; the two waves that share a
-            // SIMD (w, w + 4) take alternate taps so one of them is always in its MFMAs.  The landing area is complete for every
-            // lane that reads its OWN slot once its tap-3 wait has passed (raw rows are older than the tap-3 weights).
-            const bool slice = has_next && tap >= 3 && ((tap - 3) & 1) == wn && !(dbg & (2 | 32));
+            // SIMD (w, w + 4) take alternate taps so one of them is always in its MFMAs.  A lane passes over its OWN slots only,
+            // which are complete once its tap-3 wait has passed; the other waves see them after the barriers that follow.
+            const bool slice = AFFINE && has_next && tap >= 3 && ((tap - 3) & 1) == wn && !(dbg & (2 | 32));
             Pending pd;
             if (slice) {
                 if (tap < 5) tr_issue(Q0{}, cl + 1, pd);
@@ -331,15 +364,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                     fa[i] = *reinterpret_cast<const h16x8*>(hb + a_off[kx] + (i + ky) * HSTR * 128);
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
-                    fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + (tap % 3) * STAGE_BYTES + j * 2048);
+                    fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + st * STAGE_BYTES + j * 2048);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(fa[i]));
 #pragma unroll
                 for (int j = 0; j < 5; ++j) asm volatile("" : "=v"(fb[j]));
             }
-            if (kt + 2 < NT && !(dbg & 1)) issue_b(kt + 2, (tap + 2) % 3);
-            if (tap == 0 && has_next && !(dbg & (2 | 64))) issue_a(cl + 1);   // (the landing area was consumed during the previous chunk)
+            if (tap == 0 && has_next && !(dbg & (2 | 64))) issue_a(cl + 1);   // (that image was consumed during the previous chunk)
+            if (kt + DEPTH < NT && !(dbg & 1)) issue_b(kt + DEPTH, st == 0 ? NSTG - 1 : st - 1);
             if (!(dbg & 4)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -353,15 +386,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 for (int j = 0; j < 5; ++j) asm volatile("" ::"v"(fb[j]));
             }
             if (slice) {
-                if (tap < 5) tr_finish(Q0{}, hb_next, pd);
-                else if (tap < 7) tr_finish(Q1{}, hb_next, pd);
-                else tr_finish(Q2{}, hb_next, pd);
+                if (tap < 5) tr_finish(Q0{}, cl + 1, pd);
+                else if (tap < 7) tr_finish(Q1{}, cl + 1, pd);
+                else tr_finish(Q2{}, cl + 1, pd);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st = st + 1 == NSTG ? 0 : st + 1;
         }
     }
 
     // ------------------------------------------------------------------------------------------------ epilogue
+    stamp(4);
     __syncthreads();
     float* tilef = reinterpret_cast<float*>(smem);
     const int er = (wm * 4) * 16 + (lane >> 4) * 4, ec = wn * 80 + (lane & 15);
@@ -383,6 +418,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + j * 16] += acc[i][j][r];
     }
     __syncthreads();
+    stamp(5);
 
     // row-major pass: 24 rows x 20 eight-column chunks per sweep (480 of the 512 threads)
     const int col8 = tid % 20, row0 = tid / 20;
@@ -400,6 +436,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 *reinterpret_cast<float4*>(dst + 4) = hi;
             }
         }
+        stamp(6);
         return;
     }
     float gs[8], gq[8];
@@ -440,9 +477,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             dst[1] = q;
         }
     }
+    stamp(6);
 }
 
 }  // namespace
+
+int bc_conv_halo_max_chunks_impl() { return MAX_CH; }
 
 // Eligibility of the halo kernel for a conv problem (the host-side planners mirror this).
 int bc_conv_halo_ok(const BcGemm& p) {
@@ -467,6 +507,35 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(halo conv): splitk=%d needs a slab", p.splitk);
     const int B = p.M / (p.Hout * p.Wout);
     dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    // BC_HALO_STAMPS=1 (diagnostics; synchronises the stream after every launch): where a workgroup's cycles go
+    static const bool want_stamps = getenv("BC_HALO_STAMPS") != nullptr;
+    static unsigned long long* stamp_buf = nullptr;
+    const size_t nwg_s = (size_t)grid.x * grid.y * grid.z;
+    g.halo_stamps = nullptr;
+    if (want_stamps && nwg_s <= 4096) {
+        if (!stamp_buf) BC_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&stamp_buf), 4096 * 8 * sizeof(unsigned long long)));
+        BC_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, nwg_s * 8 * sizeof(unsigned long long), stream));
+        g.halo_stamps = stamp_buf;
+    }
+    struct StampReport {
+        hipStream_t stream; size_t n; unsigned long long* buf; const BcGemm& p; int cps;
+        ~StampReport() {
+            if (!buf) return;
+            if (hipStreamSynchronize(stream) != hipSuccess) return;
+            std::vector<unsigned long long> h(n * 8);
+            if (hipMemcpy(h.data(), buf, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+            double d[6] = {0, 0, 0, 0, 0, 0};
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t i = 0; i < n; ++i) {
+                for (int k = 0; k < 6; ++k) d[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]);
+                t0 = std::min(t0, h[i * 8]);
+                t1 = std::max(t1, h[i * 8 + 6]);
+            }
+            fprintf(stderr, "[halo stamps] M=%d N=%d Cin=%d sk=%d cps=%d wgs=%zu | avg ticks: setup %.0f, dma+table %.0f, first halo pass %.0f, "
+                    "loop %.0f, k-half sum %.0f, stores %.0f | first entry -> last exit %llu ticks\n", p.M, p.N, p.Cin, p.splitk, cps, n,
+                    d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, t1 - t0);
+        }
+    } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
     static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
     if (p.a_part1) {
         BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && p.a_ns1 > 0 && (!p.A2 || (p.a_part2 && p.a_ns2 > 0)),

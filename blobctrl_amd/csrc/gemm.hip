@@ -411,6 +411,8 @@ extern "C" int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, i
     return bc_conv_halo_ok(p);
 }
 
+extern "C" int bc_conv_halo_max_chunks(void) { return bc_conv_halo_max_chunks_impl(); }
+
 // Timing probe of bc_plan_run_timed_kernels: an event recorded between a split-K GEMM's main kernel and its reducer.
 static thread_local hipEvent_t tl_probe = nullptr;
 static thread_local bool tl_probe_hit = false;

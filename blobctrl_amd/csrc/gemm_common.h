@@ -43,6 +43,7 @@ struct GemmArgs {
     int halo_tx, halo_tpi;   // halo conv: pixel tiles per image row / per image
     int halo_nch, halo_cps;  // halo conv: 64-channel chunks in total / per split
     int halo_dbg;            // halo conv: BC_HALO_DBG ablation bits (diagnostics)
+    unsigned long long* halo_stamps;   // halo conv: BC_HALO_STAMPS=1 -> [workgroup][8] s_memtime stamps (diagnostics), else null
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
@@ -303,6 +304,7 @@ __device__ __forceinline__ void tile_epilogue_transposed(const GemmArgs& g, cons
 int bc_gemm_fast_try(const bcg::GemmArgs& g, hipStream_t stream);
 // conv_halo.hip: LDS-resident input-halo 3x3 convolution with the fused GroupNorm prologue (BC_TILE_HALO).
 int bc_conv_halo_ok(const BcGemm& p);
+int bc_conv_halo_max_chunks_impl();
 void bc_gemm_set_probe(hipEvent_t e);      // gemm.hip: event recorded between the main kernel and the split-K reducer (nullptr: off)
 bool bc_gemm_probe_hit();
 int bc_conv_halo_launch(bcg::GemmArgs& g, hipStream_t stream);

@@ -346,7 +346,9 @@ class Recorder:
             base = (M // 128) * (N // 160)
             if splitk is None:
                 target = int(os.environ.get("BC_HALO_CTAS", "256"))
-                splitk = 1 if base * 3 >= target * 2 else max(1, min(nch // 2, -(-target // base)))
+                min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "2"))               # fewest 64-channel chunks per workgroup
+                splitk = 1 if base * 3 >= target * 2 else max(1, min(nch // min_cps, -(-target // base)))
+            splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))
             cfg, sk, bm, bn = _lib.TILE_HALO, -(-nch // cps), 128, 160
             fast, mode = True, "halo"

@@ -125,6 +125,8 @@ enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_12
        BC_TILE_HALO = 8 };
 /* 1 when a convolution can run on BC_TILE_HALO. */
 int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, int Hout, int Wout, int stride);
+/* most 64-channel chunks one workgroup of BC_TILE_HALO may take: callers keep ceil(Cin / 64 / splitk) <= this */
+int bc_conv_halo_max_chunks(void);
 /* Resolve the plan for a GEMM: in/out *tile_cfg (AUTO -> heuristic choice), in/out *splitk (<= 0 -> heuristic), out *bm,
  * *bn = tile shape (bm is the slab height of gn_part).  `fast` = 1 when the problem meets the fast-path conditions
  * (K % 64 == 0, conv Cin % 64 == 0, concat split % 64 == 0); otherwise only 128x128 / 256x64 generic tiles exist. */

@@ -12,7 +12,7 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 from blobctrl_amd import _lib  # noqa: E402
 from blobctrl_amd.launch import Recorder  # noqa: E402
-from tools.tune_gemm import time_launch  # noqa: E402
+from tools.tune_gemm import time_launch, time_launch_cold  # noqa: E402
 
 dev = torch.device("cuda:0")
 rec = Recorder(dev)
@@ -23,6 +23,8 @@ SHAPES = [(2, 64, 128, 320, 0, 320), (2, 64, 128, 640, 320, 320), (2, 64, 128, 3
           (2, 16, 32, 1280, 0, 1280), (2, 16, 32, 1280, 1280, 1280), (1, 16, 32, 1280, 0, 1280),
           (2, 8, 16, 1280, 0, 1280), (2, 8, 16, 1280, 1280, 1280), (1, 8, 16, 1280, 0, 1280)]
 only = os.environ.get("PROBE_ONLY")
+cold = os.environ.get("PROBE_COLD")            # weights from HBM (caches flushed before every launch), activations warm: as in the step
+thrash = torch.zeros(160 << 20, dtype=torch.float32, device=dev) if cold else None
 if os.environ.get("PROBE_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["PROBE_SHAPES"].split(",")]
 for (B, H, W, C1, C2, Co) in SHAPES:
@@ -46,9 +48,9 @@ for (B, H, W, C1, C2, Co) in SHAPES:
     rec.gemm(A=y, W=wt, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW, want_gn=True)
     old_variant = seg.meta[-1]["variant"] + str(seg.meta[-1]["shape"][-1])
     segs = {"old": seg}
-    for sk in ([None] if not only else [int(v) for v in only.split(",")]) + ([1, 2, 4, 5, 10] if not only else []):
+    for sk in ([None] if not only else [None if v == "auto" else int(v) for v in only.split(",")]) + ([1, 2, 4, 5, 10] if not only else []):
         nch = Cin // 64
-        if sk is not None and (sk > nch or -(-nch // sk) > 40):
+        if sk is not None and (sk > nch or -(-nch // sk) > 40 or (B * H * W // 128) * (Co // 160) * sk > 1024):
             continue
         s2 = rec.begin(f"halo_sk{sk}")
         kw = dict(A2=x2, C1=C1, lda2=C2) if C2 else {}
@@ -58,9 +60,23 @@ for (B, H, W, C1, C2, Co) in SHAPES:
         segs[f"halo_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
     for rnd in range(3):
         for k, s in segs.items():
-            res.setdefault(k, []).append(time_launch(rec, s, stream, 10))
+            res.setdefault(k, []).append(time_launch_cold(rec, s, stream, 6, thrash, [t for t in (x1, x2) if t is not None])
+                                         if cold else time_launch(rec, s, stream, 10))
     line = f"B{B} {H}x{W} {C1}+{C2}->{Co}: old[{old_variant}]"
     for k, v in res.items():
         us = sorted(v)[1]
         line += f" | {k} {us:7.1f} us {flops / us / 1e6:6.0f} TF"
     print(line, flush=True)
+    if os.environ.get("PROBE_SPLIT"):           # per-kernel HIP-event times of the halo segments (finalize | conv main | split-K reducer)
+        for k, sgm in segs.items():
+            best = None
+            for _ in range(4):
+                if cold:
+                    thrash.add_(1)
+                    for t in (x1, x2):
+                        if t is not None:
+                            t.mul_(1)
+                rows = sgm.run_timed_kernels(stream)
+                cur = [(m["variant"] or m["kind"], round(a * 1e3, 1), round(r * 1e3, 1)) for m, a, r in rows]
+                best = cur if best is None or sum(c[1] + c[2] for c in cur) < sum(c[1] + c[2] for c in best) else best
+            print("      ", k, " | ".join(f"{n.split('<')[0]} {a}" + (f" + reduce {r}" if r else "") for n, a, r in best), flush=True)
