@@ -50,7 +50,7 @@ constexpr int HALO_BYTES = 24 * 1024;           // one 64-channel chunk of the h
 constexpr int B_PIECES = HBN / 8;               // 20 x 1 KiB per weight stage (one tap of one chunk)
 constexpr int STAGE_BYTES = HBN * 128;
 #ifndef BC_HALO_NSTG
-#define BC_HALO_NSTG 5
+#define BC_HALO_NSTG 3
 #endif
 constexpr int NSTG = BC_HALO_NSTG;              // weight ring depth
 constexpr int DEPTH = NSTG - 1;                 // taps issued ahead
@@ -328,6 +328,19 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
     stamp(3);
+    // The two waves of a SIMD (w, w + 4) would run every tap in lockstep - both waiting for their fragment reads, then both in
+    // their MFMAs - so the matrix pipe idles through every read phase.  Waves 4-7 therefore run half a tap late: between two
+    // barriers they first multiply with the fragments they read at the END of the previous interval, then read this tap's; one
+    // partner's reads, DMA issue and in-place pass sit under the other's MFMAs (BC_HALO_DBG & 128 turns the stagger off).
+    const bool late = wn == 1 && !(dbg & 128);
+    h16x8 fa[4], fb[5];
+    auto mfma_tap = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
     int st = 0;                                               // ring stage of the current tap
     for (int cl = 0; cl < nch; ++cl) {
         const bool has_next = cl + 1 < nch;
@@ -346,10 +359,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             wait_vm(pend);
             if (!(dbg & 16)) __builtin_amdgcn_s_barrier();    // stage `st` complete for every wave; the stage of tap kt-1 is free
             asm volatile("" ::: "memory");
+            if (late && (tap > 0 || cl > 0) && !(dbg & 4)) mfma_tap();          // (the previous tap's fragments)
             const int ky = tap / 3, kx = tap - ky * 3;
             // next chunk's operand image, one 16-byte slot per lane at a time, spread over taps 3..8; the two waves that share a
-            // SIMD (w, w + 4) take alternate taps so one of them is always in its MFMAs.  A lane passes over its OWN slots only,
-            // which are complete once its tap-3 wait has passed; the other waves see them after the barriers that follow.
+            // SIMD take alternate taps.  A lane passes over its OWN slots only, which are complete once its tap-3 wait has
+            // passed; the other waves see them after the barriers that follow.
             const bool slice = AFFINE && has_next && tap >= 3 && ((tap - 3) & 1) == wn && !(dbg & (2 | 32));
             Pending pd;
             if (slice) {
@@ -357,7 +371,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 else if (tap < 7) tr_issue(Q1{}, cl + 1, pd);
                 else tr_issue(Q2{}, cl + 1, pd);
             }
-            h16x8 fa[4], fb[5];
             if (!(dbg & 8)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -365,35 +378,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
                     fb[j] = *reinterpret_cast<const h16x8*>(smem + b_off + st * STAGE_BYTES + j * 2048);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(fa[i]));
-#pragma unroll
-                for (int j = 0; j < 5; ++j) asm volatile("" : "=v"(fb[j]));
             }
             if (tap == 0 && has_next && !(dbg & (2 | 64))) issue_a(cl + 1);   // (that image was consumed during the previous chunk)
             if (kt + DEPTH < NT && !(dbg & 1)) issue_b(kt + DEPTH, st == 0 ? NSTG - 1 : st - 1);
-            if (!(dbg & 4)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
-#pragma unroll
-                for (int j = 0; j < 5; ++j) asm volatile("" ::"v"(fb[j]));
-            }
+            if (!late && !(dbg & 4)) mfma_tap();
             if (slice) {
                 if (tap < 5) tr_finish(Q0{}, cl + 1, pd);
                 else if (tap < 7) tr_finish(Q1{}, cl + 1, pd);
                 else tr_finish(Q2{}, cl + 1, pd);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of this stage and my slot stores are done before the next barrier
             st = st + 1 == NSTG ? 0 : st + 1;
         }
     }
+    if (late && !(dbg & 4)) mfma_tap();                       // the last tap's fragments
 
     // ------------------------------------------------------------------------------------------------ epilogue
     stamp(4);

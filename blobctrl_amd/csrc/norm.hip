@@ -70,19 +70,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x
 }
 
 // ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]) for the channel-concat of two sources, each with its own
-// per-channel partial buffer part_i[B][nslab_i][C_i][2].  grid (ceil(G/4), B), one wave per group: its lanes sweep the
-// flattened (channel-in-group, slab) items of both sources (all loads independent -> one memory latency, not cpg of them),
-// fp64 accumulation in a fixed order => deterministic.
+// per-channel partial buffer part_i[B][nslab_i][C_i][2].  grid (G, B), one 256-thread workgroup per group: its threads sweep the
+// flattened (channel-in-group, slab) items of both sources (all loads independent -> one memory latency; 640 ... 1920 items per
+// group at the 64 x 128 level, which one wave per group - the first version - walked in 10 ... 30 dependent rounds: 8 us per
+// launch, 88 launches per step), fp64 accumulation in a fixed order (thread-strided, wave butterfly, four wave sums in order)
+// => deterministic.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part1, int nslab1, int C1,
                                                             const float* __restrict__ part2, int nslab2, int C2, int HW,
                                                             int G, float eps, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ab) {
+    __shared__ double red[4][2];
     const int b = blockIdx.y;
     const int C = C1 + C2;
     const int cpg = C / G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= G) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x;
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     const int n1 = max(0, min(c_hi, C1) - c_lo);               // channels of this group living in source 1
     const int n2 = cpg - n1;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     {
         const float* base = part1 + ((size_t)b * nslab1 * C1 + c_lo) * 2;
         const int items = n1 * nslab1;
-        for (int it = lane; it < items; it += 64) {
+        for (int it = tid; it < items; it += 256) {
             const int sl = it / n1, cj = it - sl * n1;
             const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C1 + cj) * 2);
             s += v.x;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         const int c2_lo = max(c_lo, C1) - C1;
         const float* base = part2 + ((size_t)b * nslab2 * C2 + c2_lo) * 2;
         const int items = n2 * nslab2;
-        for (int it = lane; it < items; it += 64) {
+        for (int it = tid; it < items; it += 256) {
             const int sl = it / n2, cj = it - sl * n2;
             const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C2 + cj) * 2);
             s += v.x;
@@ -113,12 +115,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         s += __shfl_xor(s, o);
         q += __shfl_xor(q, o);
     }
+    if (lane == 0) {
+        red[wave][0] = s;
+        red[wave][1] = q;
+    }
+    __syncthreads();
+    s = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+    q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     const double n = (double)HW * cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int c = c_lo + lane; c < c_hi; c += 64) {
+    for (int c = c_lo + tid; c < c_hi; c += 256) {
         const float a = rstd * gamma[c];
         ab[((size_t)b * C + c) * 2] = a;
         ab[((size_t)b * C + c) * 2 + 1] = beta[c] - meanf * a;
@@ -366,7 +375,7 @@ extern "C" int bc_gn_finalize(const float* part1, int nslab1, int C1, const floa
     int C = C1 + C2;
     BC_CHECK_ARG(part1 && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0 && nslab1 > 0,
                  "bc_gn_finalize: bad args (groups <= %d, C %% G == 0)", GN_MAX_GROUPS);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(bc_ceil_div(G, 4), B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
                        gamma, beta, ab);
     BC_CHECK_LAUNCH();
     return 0;
