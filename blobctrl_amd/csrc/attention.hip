@@ -14,6 +14,7 @@
 //   V arrives TRANSPOSED from the to_v GEMM epilogue (BC_OUT_F16_T), so the V^T tile is a coalesced row copy.
 //   When D is not a multiple of 32 the padded V^T tile carries a row of ones, which makes the MFMA produce the softmax
 //   denominator for free (removes 32 v_add per tile from the VALU-bound D=40 case).
+#include <stdlib.h>
 #include <type_traits>
 #include "bc_common.h"
 
@@ -388,6 +389,15 @@ int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int he
     // A second query block per wave (template parameter QB = 2: K / V fragments read once for 64 queries) was measured slower
     // than QB = 1 at every shape of the loop once the tiles arrive by LDS-DMA (d=40 N=8192: 556 vs 613 TFLOP/s; it costs
     // occupancy), so only QB = 1 is instantiated.
+    if constexpr (D == 40) {
+        // Round 2 (tools/attn_probe.py, L0 shape B=2 / 768^2 batch 4, TFLOP/s): 4 waves x 1 query block 633 / 775; 4 x 2 blocks
+        // (each K / V^T fragment feeds two MFMAs: half the LDS reads) 634 / 793; 8 waves x 1 block (the tile is staged once for 256
+        // queries) 659 / 804; 8 x 2 660 / 737.  Halving the LDS traffic buys nothing - the kernel is VALU-issue-bound - so the
+        // 8-wave form is taken where the grid still gives every SIMD four waves, and the two-block forms are not instantiated.
+        const long long wgs8 = (long long)bc_ceil_div(Nq, QW * 8) * heads * B;
+        if (wgs8 >= 2 * 256 && Nkv >= 1024 && !causal && !getenv("BC_ATTN_NO8"))
+            return launch_attn_nw<D, 8, 1, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
+    }
     if constexpr (D <= 40) {
         // enough workgroups for 4 per CU and a long key loop: take the 128-VGPR build (4 waves per SIMD)
         const long long wgs = (long long)bc_ceil_div(Nq, QW * 4) * heads * B;

@@ -346,9 +346,13 @@ def test_attention(rec, B, heads, d, Nq, Nkv):
     close(out, ref, rtol=2e-3, atol=3e-3, what=f"attention d={d} Nq={Nq} Nkv={Nkv}")
 
 
-def test_attention_large_ragged_uses_128_vgpr_build(rec):
-    """B=2, 8 heads, d=40, 8450 tokens (a 65 x 130 canvas): the grid is large enough for the 128-VGPR (4 waves per SIMD) build, and
-    8450 % 64 != 0 sends its last tile through the masked tail - the path where that build keeps its few register spills."""
+@pytest.mark.parametrize("eight_waves", [True, False])
+def test_attention_large_ragged_uses_128_vgpr_build(rec, eight_waves, monkeypatch):
+    """B=2, 8 heads, d=40, 8450 tokens (a 65 x 130 canvas): the grid is large enough for the 128-VGPR (4 waves per SIMD) builds -
+    the 8-wave workgroup (256 queries) the loop uses, and the 4-wave one (BC_ATTN_NO8) - and 8450 % 64 != 0 sends the last key tile
+    through the masked tail (the path where those builds keep their few register spills); 8450 % 256 != 0 leaves a ragged query block."""
+    if not eight_waves:
+        monkeypatch.setenv("BC_ATTN_NO8", "1")
     B, heads, d, N = 2, 8, 40, 8450
     Cc = heads * d
     q, k, v = (g(s_, B, N, Cc).half().cuda() for s_ in (1, 2, 3))
