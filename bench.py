@@ -220,8 +220,15 @@ def roofline(pipe, plan, res=512, batch=1):
                      gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
              for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
     traffic, traffic_source = pmc_traffic(dom, res, batch)
+    # algorithmic HBM bytes per launch of the dominant kernel (operands once: activation + weights + fp16 result), to read `traffic` against
+    alg = []
+    for m, _ in timed:
+        if (m["variant"] or m["kind"]) == dom and m.get("shape") and len(m["shape"]) >= 4 and isinstance(m["shape"][1], int):
+            mode, M_, N_, K_ = m["shape"][:4]
+            alg.append(2 * (M_ * (K_ // 9 if mode in ("halo", "conv1", "conv2", "ups") else K_) + N_ * K_ + M_ * N_))
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source, launches_per_step=a["n"],
+                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                algorithmic_bytes_per_launch=int(sum(alg) / len(alg)) if alg else None, launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3), event_overhead_us=round(overhead_ms * 1e3, 2)), \
         dict(by_kernel=table, top_shapes=detail)

@@ -66,5 +66,40 @@ def main():
     print("summaries:", os.listdir(d))
 
 
+def publish(src, tag):
+    """Build container: copy the summaries of gpurun_out/prof into profiles/<tag>_* and write <tag>_kernel_summary.md."""
+    import shutil
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = os.path.join(repo, "profiles")
+    shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_rocprofv3_kernel_stats_bench_steps1.csv"))
+    shutil.copy(os.path.join(src, "pmc_hbm_traffic.json"), os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"))
+    shutil.copy(os.path.join(src, "pmc_mfma_util.json"), os.path.join(dst, f"{tag}_pmc_mfma_util_per_kernel.json"))
+    shutil.copy(os.path.join(src, "stats_bench.json"), os.path.join(dst, f"{tag}_bench_under_rocprofv3.json"))
+    traffic = {r["kernel"]: r for r in json.load(open(os.path.join(src, "pmc_hbm_traffic.json")))["kernels"]}
+    util = {r["kernel"]: r for r in json.load(open(os.path.join(src, "pmc_mfma_util.json")))["kernels"]}
+    sha = json.load(open(os.path.join(src, "pmc_hbm_traffic.json")))["csrc_sha"]
+    rows = list(csv.DictReader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))))
+    lines = [f"# {tag} per-kernel summary (one MI355X, `bench.py --steps 1 --warmup 1`, 2 edits x 50 DDIM steps under rocprofv3; kernel sources {sha})", "",
+             f"Sources: `{tag}_rocprofv3_kernel_stats_bench_steps1.csv` (durations), `{tag}_pmc_hbm_traffic.json` (HBM/fabric bytes per launch = "
+             "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate PMC passes on a 2-step edit), "
+             f"`{tag}_pmc_mfma_util_per_kernel.json` (SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE/8)).  Produced by "
+             "`tools/profile_round.sh` + `tools/summarize_profile.py --publish`.", "",
+             "| kernel | calls | avg us | % of kernel time | HBM+fabric MB / launch | GB/s | MFMA busy | VALU issue | LDS |", "|---|---|---|---|---|---|---|---|---|"]
+    for r in rows[:28]:
+        name = r["Name"]
+        t, u = traffic.get(name), util.get(name)
+        avg = float(r["AverageNs"]) / 1e3
+        mb = t["hbm_bytes_per_launch_corrected"] / 1e6 if t else float("nan")
+        short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")
+        short = short.split("(")[0][:64]
+        lines.append(f"| `{short}` | {r['Calls']} | {avg:.1f} | {float(r['Percentage']):.2f} | {mb:.1f} | {mb * 1e3 / avg:.0f} | "
+                     + (f"{100 * u['mfma_busy_frac']:.0f} % | {100 * u['valu_issue_busy_frac']:.0f} % | {100 * u['lds_busy_frac']:.0f} % |" if u else "- | - | - |"))
+    open(os.path.join(dst, f"{tag}_kernel_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("published", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 3 and sys.argv[1] == "--publish":
+        publish(sys.argv[2], sys.argv[3])
+    else:
+        main()
