@@ -264,4 +264,17 @@ def synth_tensor(name: str, shape: tuple, seed: int) -> np.ndarray:
 
 
 def synth_state_dict(shapes: "OrderedDict[str, tuple]", seed: int) -> Dict[str, torch.Tensor]:
-    return OrderedDict((k, torch.from_numpy(synth_tensor(k, v, seed))) for k, v in shapes.items())
+    """Every parameter has its own stream (keyed by its name), so the tensors are generated on a thread pool (numpy's Generator
+    releases the GIL) - same bits as a serial loop, a fraction of the 20 s that 860 M parameters take on one core."""
+    items = list(shapes.items())
+    if sum(int(np.prod(v)) for _, v in items) < (1 << 22):
+        return OrderedDict((k, torch.from_numpy(synth_tensor(k, v, seed))) for k, v in items)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, ncpu))) as ex:
+        arrs = list(ex.map(lambda kv: synth_tensor(kv[0], kv[1], seed), items))
+    return OrderedDict((k, torch.from_numpy(a)) for (k, _), a in zip(items, arrs))
