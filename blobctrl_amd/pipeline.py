@@ -395,8 +395,8 @@ class BlobCtrlEngine:
             P.hist.zero_()
         P.guidance[0] = float(guidance_scale)
         s, side = self._streams()
-        self.stream.synchronize()
-        if teacher_latents is None and callback_on_step_end is None and trace is None:
+        if teacher_latents is None and callback_on_step_end is None and trace is None and not P.captured:
+            self.stream.synchronize()
             self._capture(P)
             # captured segments left the step counter advanced by the warm-up runs: reset per-edit state
             with torch.cuda.stream(self.stream):
@@ -416,9 +416,7 @@ class BlobCtrlEngine:
                 torch.cuda.synchronize(self.device)
                 g = P.loop_graphs[key] = P.rec.capture_loop(segs, s, side, self._extra())
             _lib.check(self.lib.bc_graph_launch(g, s), "bc_graph_launch")
-            torch.cuda.synchronize(self.device)
-            out = P.latents.clone()
-            return out if output_type == "latent" else self.decode_latents(out, output_type)
+            return self._result(P, output_type)
         P.prologue.run(s)
         for i in range(n):
             if teacher_latents is not None:
@@ -435,8 +433,20 @@ class BlobCtrlEngine:
                 if isinstance(ret, dict) and ret.get("latents") is not None and ret["latents"] is not P.latents:
                     with torch.cuda.stream(self.stream):                         # pipe:1112 `latents = callback_outputs.pop(...)`
                         P.latents.copy_(ret["latents"].to(dev, torch.float32))
-        torch.cuda.synchronize(self.device)
-        out = P.latents.clone()
+        return self._result(P, output_type)
+
+    def _result(self, P, output_type):
+        """The final latents as a fresh tensor with ordinary stream semantics: the copy is enqueued behind the edit on the engine's
+        stream and the CALLER's current stream is made to wait for it - no host synchronisation here, so the next edit's inputs and
+        graph launch are enqueued while this edit's tail still runs (a host sync per edit drained the device for ~20 ms of a 550 ms
+        edit).  Reading the tensor (`.cpu()`, `torch.cuda.synchronize()`) synchronises as for any torch op."""
+        with torch.cuda.stream(self.stream):
+            out = P.latents.clone()
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.stream)
+        out.record_stream(cur)                              # (allocated on the engine's stream, consumed on the caller's)
+        if os.environ.get("BC_SYNC_EDIT"):                  # diagnostics: the pre-round-2 behaviour (host sync per edit)
+            torch.cuda.synchronize(self.device)
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
     __call__ = denoise
