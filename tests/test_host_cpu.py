@@ -258,3 +258,43 @@ def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
     assert len(P.step_active) > len(P.step_inactive) > 100 and {m["sid"] for m in P.step_active.meta} == {0, 1}
     with pytest.raises(_lib.BlobCtrlHipError):
         BlobCtrlEngine(usd, bsd, ucfg, bcfg, device="cpu")                               # executing needs an MI355X
+
+
+def test_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/timeline.py (rocprofv3 kernel trace -> per-queue busy time / gaps / overlap of one step) on a hand-made trace."""
+    import importlib.util
+    import json
+    import os
+    rows = ["Kind,Agent_Id,Queue_Id,Stream_Id,Thread_Id,Dispatch_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    k = 0
+    for step in range(4):                         # four steps, each: 3 kernels on queue 1, 2 overlapping on queue 2, then cfg_step
+        for i in range(3):
+            rows.append(f"KERNEL_DISPATCH,1,1,0,1,{k},{k},gemm_kernel(args),{k},{t},{t + 10_000}")
+            t += 10_000 + 1_000                    # 1 us gap
+            k += 1
+        for i in range(2):
+            s0 = t - 30_000 + i * 12_000
+            rows.append(f"KERNEL_DISPATCH,1,2,0,1,{k},{k},conv_halo_kernel<1>(args),{k},{s0},{s0 + 8_000}")
+            k += 1
+        rows.append(f"KERNEL_DISPATCH,1,1,0,1,{k},{k},cfg_step_kernel(args),{k},{t},{t + 2_000}")
+        t += 5_000
+        k += 1
+    d = tmp_path / "trace"
+    d.mkdir()
+    (d / "x_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    spec = importlib.util.spec_from_file_location("timeline", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           "tools", "timeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sys
+    argv = sys.argv
+    sys.argv = ["timeline.py", str(d), str(tmp_path / "out.json")]
+    try:
+        mod.main()
+    finally:
+        sys.argv = argv
+    out = json.loads((tmp_path / "out.json").read_text())
+    assert out["kernels_in_step"] == 6 and set(out["queues"]) == {"1", "2"}
+    assert out["queues"]["1"]["kernels"] == 4 and abs(out["queues"]["1"]["busy_us"] - 32.0) < 1e-6
+    assert out["queues"]["2"]["busy_us"] == 16.0 and out["two_or_more_running_us"] > 0
