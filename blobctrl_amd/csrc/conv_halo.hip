@@ -109,8 +109,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
     const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
     const int lin = lin3 % plane;
     const int split = lin3 / plane;
-    const int tile = lin / (int)gridDim.x;               // an XCD owns a contiguous band of pixel tiles, all their column tiles
-    const int n0 = (lin % (int)gridDim.x) * HBN;
+    // an XCD owns a contiguous band of pixel tiles with all their column tiles, or (g.nband: the weights are the larger operand)
+    // a band of column tiles with all their pixel tiles - see gemm_fast.hip
+    const int tile = g.nband ? lin % (int)gridDim.y : lin / (int)gridDim.x;
+    const int ntile = g.nband ? lin / (int)gridDim.y : lin % (int)gridDim.x;
+    const int n0 = ntile * HBN;
     const int b = tile / g.halo_tpi;
     const int tin = tile - b * g.halo_tpi;
     const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
@@ -505,6 +508,11 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(halo conv): splitk=%d needs a slab", p.splitk);
     const int B = p.M / (p.Hout * p.Wout);
     dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    {
+        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
+        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
+        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && grid.x >= 4);
+    }
     // BC_HALO_STAMPS=1 (diagnostics; synchronises the stream after every launch): where a workgroup's cycles go
     static const bool want_stamps = getenv("BC_HALO_STAMPS") != nullptr;
     static unsigned long long* stamp_buf = nullptr;

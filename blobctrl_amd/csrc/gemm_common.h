@@ -43,6 +43,8 @@ struct GemmArgs {
     int halo_tx, halo_tpi;   // halo conv: pixel tiles per image row / per image
     int halo_nch, halo_cps;  // halo conv: 64-channel chunks in total / per split
     int halo_dbg;            // halo conv: BC_HALO_DBG ablation bits (diagnostics)
+    int nband;               // fast GEMM: 1 = an XCD owns a band of COLUMN tiles (all row tiles): it fetches 1/8 of the weights and the
+                             // whole activation - chosen when the weight matrix is the larger operand (low-resolution levels)
     unsigned long long* halo_stamps;   // halo conv: BC_HALO_STAMPS=1 -> [workgroup][8] s_memtime stamps (diagnostics), else null
 };
 

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
     const int plane = gridDim.x * gridDim.y;
     const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
     const int lin = lin3 % plane;
-    const int m0 = (lin / (int)gridDim.x) * BM;        // an XCD owns a contiguous band of row tiles, all their column tiles
-    const int n0 = (lin % (int)gridDim.x) * BN;
+    // an XCD (a run of consecutive `lin`) owns a contiguous band of row tiles with all their column tiles - its L2 then fetches 1/8
+    // of the activation and the whole weight matrix - or, when the weights are the larger operand (g.nband), a band of column tiles
+    // with all their row tiles: 1/8 of the weights, the whole activation
+    const int m0 = (g.nband ? lin % (int)gridDim.y : lin / (int)gridDim.x) * BM;
+    const int n0 = (g.nband ? lin / (int)gridDim.y : lin % (int)gridDim.x) * BN;
     const int split = lin3 / plane;
 
     const h16* __restrict__ A = reinterpret_cast<const h16*>(p.A);
@@ -301,9 +304,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
 }
 
 template <int BM, int BN, int WM, int WN, int NS, bool CONV, bool UPS>
-int launch_fast(const GemmArgs& g, hipStream_t stream) {
+int launch_fast(const GemmArgs& g_in, hipStream_t stream) {
+    GemmArgs g = g_in;
     const BcGemm& p = g.p;
     dim3 grid(bc_ceil_div(p.N, BN), bc_ceil_div(p.M, BM), p.splitk);
+    {
+        // operand bytes one split touches: activation rows (a convolution's nine taps re-read the same pixels) vs weights
+        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
+        const double a_bytes = (double)p.M * (CONV ? p.Cin : p.K) / p.splitk, w_bytes = (double)p.N * p.K / p.splitk;
+        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
+        g.nband = nband_env >= 0 ? nband_env : (w_bytes > ratio * a_bytes && grid.x >= 8);
+    }
     dim3 block(64 * WM * WN);
     size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BN * (BM + 4) * 4);   // stages | epilogue tile (| transposed, padded)
     static std::atomic<unsigned long long> lds_set{0};       // one bit per device ordinal
