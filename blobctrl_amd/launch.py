@@ -347,9 +347,10 @@ class Recorder:
             if splitk is None:
                 target = int(os.environ.get("BC_HALO_CTAS", "256"))
                 min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "2"))               # fewest 64-channel chunks per workgroup
-                # workgroups from which one pass is taken unsplit: half the CUs - the other trunk's kernels fill the rest, and the fp32
-                # slab round trip is saved (same box: 11.45 vs 11.52 ms per step against the round-1 rule of 2/3)
-                full = int(os.environ.get("BC_HALO_FULL", str(target // 2)))
+                # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the step gains
+                # 0.5 % because the other trunk's kernels fill the idle CUs, but this kernel's own efficiency drops from 0.22 to 0.19 of
+                # peak: DESIGN 3.5.)
+                full = int(os.environ.get("BC_HALO_FULL", str(target * 2 // 3)))
                 splitk = 1 if base >= full else max(1, min(nch // min_cps, -(-target // base)))
             splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))
