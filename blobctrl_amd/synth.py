@@ -263,6 +263,24 @@ def synth_tensor(name: str, shape: tuple, seed: int) -> np.ndarray:
     return (x * (gain / np.sqrt(fan_in))).astype(np.float32)
 
 
+def contractive_variant(usd: Dict[str, torch.Tensor], bsd: Dict[str, torch.Tensor], conv_out_scale: float = 0.25,
+                        zero_conv_scale: float = 1.0):
+    """Synthetic weights whose 50-step edit does not blow small differences up (SURVEY 7 hard part (ii)): the UNet's last convolution
+    (and optionally BlobNet's zero-convs) scaled down, everything else unchanged.  With variance-preserving random weights the guided
+    noise prediction has a Jacobian gain of 1.8 w.r.t. the latents at the first step (CFG 7.5 amplifies the branch difference), which
+    compounds over 50 steps; scaled, eps stays O(1) and a perturbation grows only with the scheduler's own sqrt(abar_prev / abar_t)
+    factors (tools/amplification_probe.py measures it).  Returns NEW dicts (the inputs are not modified)."""
+    u = OrderedDict(usd)
+    u["conv_out.weight"] = usd["conv_out.weight"] * conv_out_scale
+    u["conv_out.bias"] = usd["conv_out.bias"] * conv_out_scale
+    b = OrderedDict(bsd)
+    if zero_conv_scale != 1.0:
+        for k in bsd:
+            if k.startswith("blobnet_"):
+                b[k] = bsd[k] * zero_conv_scale
+    return u, b
+
+
 def synth_state_dict(shapes: "OrderedDict[str, tuple]", seed: int) -> Dict[str, torch.Tensor]:
     """Every parameter has its own stream (keyed by its name), so the tensors are generated on a thread pool (numpy's Generator
     releases the GIL) - same bits as a serial loop, a fraction of the 20 s that 860 M parameters take on one core."""

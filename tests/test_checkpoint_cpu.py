@@ -124,3 +124,26 @@ def test_load_unet_blobnet_from_disk_with_surgery_and_lora(tmp_path):
     json.dump({"in_channels": 4, "conditioning_channels": 3}, open(bd / "config.json", "w"))
     with pytest.raises(ValueError):
         ck.load_blobnet(str(bd))
+
+
+@pytest.mark.parametrize("kind", ["lin", "conv"])
+@pytest.mark.parametrize("tag", ["noalpha", "alpha"])
+def test_lora_merge_matches_reference_fuse_and_runtime_branch(golden_dir, kind, tag):
+    """f2 pinned: `weights.merge_lora` against the adapter arithmetic the reference tree holds itself -
+    D/models/lora.py LoRALinearLayer / LoRAConv2dLayer forward (base(x) + lora_scale * up(down(x)) [* network_alpha / rank],
+    :175-233, :235-297) and LoRACompatible*._fuse_lora (:317-340, :398-424); fixture tests/golden/lora_merge.npz from those classes
+    (tools/make_golden.py golden_lora_merge), Linear and Conv2d 3x3, with and without network_alpha, lora_scale 0.7."""
+    z = np.load(os.path.join(golden_dir, "lora_merge.npz"))
+    t = lambda n: torch.from_numpy(z[f"{kind}_{tag}_{n}"])
+    rank = t("down").shape[0]
+    # peft naming: lora_A = down, lora_B = up (D/utils/state_dict_utils.py UNET_TO_PEFT); alpha defaults to the rank (no scaling)
+    alpha = float(z["network_alpha"]) if tag == "alpha" else float(rank)
+    merged = merge_lora({"m.weight": t("w"), "m.bias": t("b")}, {"m.lora_A.weight": t("down"), "m.lora_B.weight": t("up")},
+                        {"m": alpha}, adapter_scale=float(z["lora_scale"]))
+    assert torch.equal(merged["m.bias"], t("b"))
+    assert (merged["m.weight"] - t("w_fused")).abs().max().item() < 1e-6
+    x = t("x")
+    y = torch.nn.functional.linear(x, merged["m.weight"], merged["m.bias"]) if kind == "lin" else \
+        torch.nn.functional.conv2d(x, merged["m.weight"], merged["m.bias"], padding=1)
+    assert (y - t("y_fused")).abs().max().item() < 1e-5
+    assert (y - t("y_runtime")).abs().max().item() < 1e-5          # fused == the runtime low-rank branch, as the reference executes it

@@ -544,6 +544,35 @@ def test_lora_merged_equals_runtime_low_rank_branch_full_size(rec, kind):
     close(merged, branch, rtol=8e-3, what=f"merged vs runtime branch {kind}")
 
 
+@pytest.mark.parametrize("tag", ["noalpha", "alpha"])
+def test_lora_merged_layers_match_reference_lora_fixture(rec, golden_dir, tag):
+    """f2 on the GPU: the merged Linear / Conv2d 3x3 of tests/golden/lora_merge.npz (outputs of the reference's own LoRA layers,
+    D/models/lora.py) through bc_gemm - channels padded to the kernels' 8-element granularity."""
+    from blobctrl_amd.weights import merge_lora, pack_conv3x3, pack_matrix
+    z = np.load(os.path.join(golden_dir, "lora_merge.npz"))
+    for kind in ("lin", "conv"):
+        t = lambda n: torch.from_numpy(z[f"{kind}_{tag}_{n}"])
+        rank = t("down").shape[0]
+        alpha = float(z["network_alpha"]) if tag == "alpha" else float(rank)
+        sd = merge_lora({"m.weight": t("w")}, {"m.lora_A.weight": t("down"), "m.lora_B.weight": t("up")}, {"m": alpha},
+                        adapter_scale=float(z["lora_scale"]))
+        x, ref = t("x"), t("y_fused")
+        if kind == "lin":
+            M, K, N = x.shape[0] * x.shape[1], x.shape[2], ref.shape[-1]
+            out = run(rec, lambda: rec.gemm(A=h(x.reshape(M, K)), W=h(pack_matrix(sd["m.weight"])), M=M, N=N, K=K,
+                                            out=rec.empty(M, N), bias=t("b").cuda()))
+            close(out, ref.reshape(M, N), rtol=4e-3, what=f"merged LoRA linear ({tag}) vs the reference layer")
+        else:
+            B, C, H, W = x.shape
+            Cp, N, M = 8, ref.shape[1], B * H * W
+            xp = torch.zeros(B, H, W, Cp)
+            xp[..., :C] = x.permute(0, 2, 3, 1)
+            out = run(rec, lambda: rec.gemm(A=h(xp.reshape(M, Cp)), W=h(pack_conv3x3(sd["m.weight"])), M=M, N=N, K=9 * Cp,
+                                            out=rec.empty(M, N), bias=t("b").cuda(),
+                                            conv=dict(Cin=Cp, Hin=H, Win=W, Hout=H, Wout=W, stride=1)))
+            close(out, ref.permute(0, 2, 3, 1).reshape(M, N), rtol=4e-3, what=f"merged LoRA conv3x3 ({tag}) vs the reference layer")
+
+
 def test_run_timed_kernels_divides_a_splitk_gemm(rec):
     """bc_plan_run_timed_kernels: per-launch HIP-event times with a split-K GEMM divided into main kernel and reducer (what
     bench.py's roofline uses so that its per-kernel durations are comparable with rocprofv3's)."""

@@ -425,6 +425,58 @@ def golden_lora_keys():
     print("lora keys:", len(out["pairs"]), "pairs;", out["kwargs_no_alpha"], out["kwargs_alpha"])
 
 
+def golden_lora_merge():
+    """The adapter arithmetic as the REFERENCE tree states it (peft is absent, but the vendored diffusers keeps its
+    own LoRA layers): D/models/lora.py LoRALinearLayer / LoRAConv2dLayer forward (runtime branch: base(x) + lora_scale * up(down(x))
+    [* network_alpha / rank]) and LoRACompatibleLinear / LoRACompatibleConv._fuse_lora (w + lora_scale * (alpha / r) * up . down).
+    Linear and Conv2d 3x3, with and without network_alpha.  Stored: the factors, the input, the reference's runtime output, its fused
+    weight and the fused layer's output."""
+    import warnings
+    from diffusers.models.lora import LoRACompatibleConv, LoRACompatibleLinear, LoRAConv2dLayer, LoRALinearLayer
+    out = {}
+    warnings.simplefilter("ignore")
+    for tag, alpha in (("noalpha", None), ("alpha", 2.0)):
+        # Linear 24 -> 20, rank 4
+        lin = LoRACompatibleLinear(24, 20, bias=True)
+        lin.weight.data = g(901, 20, 24) * 0.2
+        lin.bias.data = g(902, 20) * 0.1
+        ll = LoRALinearLayer(24, 20, rank=4, network_alpha=alpha)
+        ll.down.weight.data = g(903, 4, 24) * 0.3
+        ll.up.weight.data = g(904, 20, 4) * 0.3
+        lin.set_lora_layer(ll)
+        x = g(905, 3, 7, 24)
+        y_rt = lin(x, 0.7)
+        w0 = lin.weight.data.clone()
+        lin._fuse_lora(lora_scale=0.7)
+        y_f = lin(x)
+        out.update({f"lin_{tag}_w": w0.numpy(), f"lin_{tag}_b": lin.bias.data.numpy(), f"lin_{tag}_down": ll.down.weight.data.numpy(),
+                    f"lin_{tag}_up": ll.up.weight.data.numpy(), f"lin_{tag}_x": x.numpy(), f"lin_{tag}_y_runtime": y_rt.numpy(),
+                    f"lin_{tag}_w_fused": lin.weight.data.numpy(), f"lin_{tag}_y_fused": y_f.numpy()})
+        # Conv2d 3x3 6 -> 8, rank 4 (down is 3x3, up is 1x1: lora.py:275-278)
+        cv = LoRACompatibleConv(6, 8, kernel_size=3, padding=1, bias=True)
+        cv.weight.data = g(911, 8, 6, 3, 3) * 0.2
+        cv.bias.data = g(912, 8) * 0.1
+        cl = LoRAConv2dLayer(6, 8, rank=4, kernel_size=(3, 3), stride=(1, 1), padding=1, network_alpha=alpha)
+        cl.down.weight.data = g(913, 4, 6, 3, 3) * 0.3
+        cl.up.weight.data = g(914, 8, 4, 1, 1) * 0.3
+        cv.set_lora_layer(cl)
+        xc = g(915, 2, 6, 5, 9)
+        y_rt = cv(xc, 0.7)
+        w0 = cv.weight.data.clone()
+        cv._fuse_lora(lora_scale=0.7)
+        y_f = cv(xc)
+        out.update({f"conv_{tag}_w": w0.numpy(), f"conv_{tag}_b": cv.bias.data.numpy(), f"conv_{tag}_down": cl.down.weight.data.numpy(),
+                    f"conv_{tag}_up": cl.up.weight.data.numpy(), f"conv_{tag}_x": xc.numpy(), f"conv_{tag}_y_runtime": y_rt.numpy(),
+                    f"conv_{tag}_w_fused": cv.weight.data.numpy(), f"conv_{tag}_y_fused": y_f.numpy()})
+        for k in ("lin", "conv"):
+            d = np.abs(out[f"{k}_{tag}_y_runtime"] - out[f"{k}_{tag}_y_fused"]).max()
+            assert d < 1e-5, (k, tag, d)
+    out["lora_scale"] = np.float32(0.7)
+    out["network_alpha"] = np.float32(2.0)
+    np.savez_compressed(os.path.join(OUT, "lora_merge.npz"), **out)
+    print("lora merge:", sorted(out)[:4], "...")
+
+
 def golden_pipeline_call():
     """The REFERENCE pipeline's own `__call__` (pipe:743-1166) end to end on tiny components: PIL images + prompt strings in, latents
     (and one decoded image) out - tokenizer stand-in, CLIP, VAE encode (global-generator posterior samples), DINOv2 processor + model,
@@ -554,6 +606,7 @@ if __name__ == "__main__":
     check_full_schema()
     golden_pipeline_call()
     golden_lora_keys()
+    golden_lora_merge()
     golden_blob_edit()
     golden_clip_text()
     golden_vae()

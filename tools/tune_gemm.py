@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--gn-penalty-us", type=float, default=0.0,
                     help="extra cost charged to split-K on convolutions (0: the split-K reducer emits the GroupNorm partials too)")
+    ap.add_argument("--dump", default=None, help="also write EVERY candidate's time (us, cfg, splitk, workgroups) per shape to this JSON")
     ap.add_argument("--cold", action="store_true", help="flush the caches before every timed launch (weights cold, activations warm)")
     args = ap.parse_args()
     os.environ["BC_NO_TUNING"] = "1"
@@ -109,7 +110,7 @@ def main():
     shapes = collect_shapes(args.res)
     if args.res == 512:
         shapes.update(collect_shapes(768)) if os.environ.get("BC_TUNE_768") else None
-    table, report = {}, []
+    table, report, dump = {}, [], {}
     t0 = time.time()
     thrash = torch.zeros(160 * 1024 * 1024, dtype=torch.float32, device=dev) if args.cold else None      # 640 MB
     for (mode, M, N, K), conv in sorted(shapes.items()):
@@ -141,6 +142,7 @@ def main():
                 us = time_launch_cold(rec, seg, stream, args.iters, thrash, (A,)) if args.cold else \
                     time_launch(rec, seg, stream, args.iters)
                 results.append((us, cfg, sk))
+                dump.setdefault(f"{mode}|{M}|{N}|{K}", []).append([round(us, 2), cfg, sk, nblk])
                 cost = us + (args.gn_penalty_us if (sk > 1 and mode != "dense") else 0.0)
                 if best is None or cost < best[3]:
                     best = (us, cfg, sk, cost)
@@ -154,6 +156,9 @@ def main():
         print(report[-1], flush=True)
     with open(args.out, "w") as f:
         json.dump(dict(device="MI355X gfx950", res=args.res, shapes=table), f, indent=0, sort_keys=True)
+    if args.dump:
+        with open(args.dump, "w") as f:
+            json.dump(dump, f)
     print(f"wrote {len(table)} shapes to {args.out} in {time.time() - t0:.0f} s")
 
 
