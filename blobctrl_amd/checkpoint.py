@@ -142,7 +142,12 @@ def load_lora(path: str, unet_identifier_key: str = "unet") -> Tuple[Dict[str, t
     """-> (lora, alphas): `lora` has `<module>.lora_A.weight` / `<module>.lora_B.weight`; `alphas[<module>]` is the effective
     lora_alpha of each module, so `merge_lora(sd, lora, alphas)` applies W + (alpha / r) * B @ A exactly like the peft
     adapter the reference injects."""
-    raw = read_safetensors(_model_file(path))
+    return lora_from_state_dict(read_safetensors(_model_file(path)), unet_identifier_key, what=path)
+
+
+def lora_from_state_dict(raw: Dict[str, torch.Tensor], unet_identifier_key: str = "unet", what: str = "state dict"):
+    """The same conversion for an in-memory state dict (`pipeline.load_lora_weights(dict)`, lora_pipeline.py:94-100)."""
+    path = what
     pre = unet_identifier_key + "."
     keys = [k for k in raw if k.startswith(pre)]
     sd = OrderedDict((k[len(pre):], raw[k]) for k in keys) if keys else raw           # unet.py:289-301

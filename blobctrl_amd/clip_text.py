@@ -15,8 +15,7 @@ from .launch import Recorder, run_graphed
 class CLIPTextModel:
     def __init__(self, state_dict, num_heads: int = 12, eps: float = 1e-5, device="cuda:0"):
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.BlobCtrlHipError("blobctrl_amd.CLIPTextModel runs on MI355X only; there is no CPU fallback")
+        # (a host device is accepted for CONSTRUCTION only - loading / inspecting checkpoints; running refuses it: `_need_gpu`)
         _lib.load()
         # on-disk layout has a "text_model." prefix (transformers 4.x); 5.x dropped it
         sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v.detach().float().cpu()
@@ -58,7 +57,15 @@ class CLIPTextModel:
         return cls(read_safetensors(_model_file(d)), num_heads=cfg.get("num_attention_heads", 12),
                    eps=cfg.get("layer_norm_eps", 1e-5), device=device)
 
+    def to(self, *a, **k):
+        return self
+
+    def _need_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.BlobCtrlHipError("blobctrl_amd.CLIPTextModel runs on MI355X only; there is no CPU fallback")
+
     def _plan(self, B, T):
+        self._need_gpu()
         key = (B, T)
         if key in self._plans:
             return self._plans[key]

@@ -17,8 +17,7 @@ from .weights import pad8
 class Dinov2Model:
     def __init__(self, state_dict, num_heads: int, patch_size: int = 14, eps: float = 1e-6, device="cuda:0"):
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.BlobCtrlHipError("blobctrl_amd.Dinov2Model runs on MI355X only; there is no CPU fallback")
+        # (a host device is accepted for CONSTRUCTION only - loading / inspecting checkpoints; running refuses it: `_need_gpu`)
         _lib.load()
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.sd = sd
@@ -72,7 +71,15 @@ class Dinov2Model:
             pos = torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, -1, self.D)], dim=1)
         return pos.reshape(-1, self.D).contiguous().to(self.device)
 
+    def to(self, *a, **k):
+        return self
+
+    def _need_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.BlobCtrlHipError("blobctrl_amd.Dinov2Model runs on MI355X only; there is no CPU fallback")
+
     def _plan(self, B, H, W):
+        self._need_gpu()
         key = (B, H, W)
         if key in self._plans:
             return self._plans[key]

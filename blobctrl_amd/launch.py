@@ -245,6 +245,11 @@ class Recorder:
         self.loop_graphs.append(g)
         return g
 
+    def destroy_loop_graph(self, g):
+        """Destroy one whole-loop graph exec (the caller has synchronised the device) and forget its handle."""
+        self.lib.bc_graph_destroy(g)
+        self.loop_graphs = [h for h in self.loop_graphs if h is not g]
+
     def save(self, path: str):
         """Write the relocatable plan file: buffer table (named I/O buffers, weights / tables with their contents, zero-filled
         workspace) + launch records with (buffer, offset) pointers.  Loaded by `bc_plan_load` (C hosts: tests/c/plan_edit.c)."""

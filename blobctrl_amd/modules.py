@@ -9,6 +9,7 @@ Tensors cross this boundary as NCHW torch tensors (fp32 or fp16) exactly like th
 NHWC fp16 and runs through libblobctrl_hip.  These shells are the module-level boundary; the captured-loop engine
 (pipeline.py) bypasses them and chains the plans directly.
 """
+from collections import OrderedDict
 from typing import List, Optional
 
 import torch
@@ -16,7 +17,7 @@ import torch
 from . import _lib
 from .engine import Residuals, TrunkConfig, TrunkPlan
 from .launch import Recorder, run_graphed
-from .weights import PackedTrunk, pad8
+from .weights import PackedTrunk, merge_lora, pad8
 
 
 def _stream():
@@ -40,26 +41,112 @@ class _TrunkModule(torch.nn.Module):
     they are exposed as two frozen Parameters that SHARE the arenas' storage.  `.to()` / `.half()` / `.float()` are no-ops: the layouts
     are fixed at construction (device = the one given to the constructor)."""
 
-    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0"):
+    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0", lazy: bool = False):
+        """`lazy=True` (what `from_pretrained` uses): the reference-schema state dict stays on the host and is packed on first
+        use, so that the script's post-load edits - the conv_in surgery (inf:233-249), `load_lora_weights` (inf:270-273) - are
+        cheap host operations; any later edit drops the packed copy and every cached plan (`_invalidate`)."""
         super().__init__()
         self._device = torch.device(device)
-        if self._device.type != "cuda":
-            raise _lib.BlobCtrlHipError("blobctrl_amd modules run on MI355X only; there is no CPU fallback")
-        _lib.load()
         self.trunk_config = config
+        self._sd = None if isinstance(state_dict, PackedTrunk) else OrderedDict(state_dict)
+        self._packed = state_dict if isinstance(state_dict, PackedTrunk) else None
+        self._adapters = OrderedDict()          # name -> dict(lora=, alphas=, weight=, active=)
+        self._version = 0
+        self._plans = {}
+        self._make_config()
+        if not lazy and self._packed is None:
+            if self._device.type != "cuda":
+                raise _lib.BlobCtrlHipError("blobctrl_amd modules run on MI355X only; there is no CPU fallback")
+            self.weights                         # pack now
+
+    def _make_config(self):
+        config = self.trunk_config
         latent = config.out_channels if config.out_channels else 4
         self.config = ModelConfig(
             # the reference script leaves unet.config.in_channels at the LATENT channel count (4) although conv_in has 5 inputs
             # (scripts/blobctrl_inference.py:233-249); BlobNet: in_channels=4, conditioning_channels=1+F (bn config)
-            in_channels=latent if config.is_blobnet or config.in_channels == latent + 1 else config.in_channels,
+            in_channels=latent if config.is_blobnet or config.in_channels in (latent, latent + 1) else config.in_channels,
             conv_in_channels=config.in_channels, out_channels=config.out_channels, block_out_channels=tuple(config.block_out_channels),
             layers_per_block=config.layers_per_block, attention_head_dim=config.num_heads, norm_num_groups=config.norm_num_groups,
             cross_attention_dim=config.cross_attention_dim, time_cond_proj_dim=None, sample_size=64,
             conditioning_channels=(config.in_channels - latent) if config.is_blobnet else None)
-        self.weights = state_dict if isinstance(state_dict, PackedTrunk) else PackedTrunk(state_dict, self._device, config.block_out_channels)
-        self.packed_fp16 = torch.nn.Parameter(self.weights.h_arena, requires_grad=False)
-        self.packed_fp32 = torch.nn.Parameter(self.weights.f_arena, requires_grad=False)
+
+    # ---- weights: packed lazily from the host state dict + the active LoRA adapters
+    def effective_state_dict(self):
+        """The host state dict with every ACTIVE adapter merged (W + weight * (alpha / r) * B A, weights.merge_lora)."""
+        if self._sd is None:
+            raise _lib.BlobCtrlHipError("this module was built from packed weights: no host state dict to edit")
+        sd = self._sd
+        for ad in self._adapters.values():
+            if ad["active"] and ad["weight"] != 0.0:
+                sd = merge_lora(sd, ad["lora"], ad["alphas"], adapter_scale=ad["weight"])
+        return sd
+
+    @property
+    def weights(self) -> PackedTrunk:
+        if self._packed is None:
+            _lib.load()
+            self._packed = PackedTrunk(self.effective_state_dict(), self._device, self.trunk_config.block_out_channels)
+        return self._packed
+
+    @property
+    def packed_fp16(self):
+        return self.weights.h_arena
+
+    @property
+    def packed_fp32(self):
+        return self.weights.f_arena
+
+    def parameters(self, recurse: bool = True):
+        """The packed fp16 / fp32 arenas as two frozen Parameters sharing the arenas' storage."""
+        w = self.weights
+        return iter([torch.nn.Parameter(w.h_arena, requires_grad=False), torch.nn.Parameter(w.f_arena, requires_grad=False)])
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
+        return iter(zip((prefix + "packed_fp16", prefix + "packed_fp32"), self.parameters()))
+
+    def _invalidate(self):
+        """The host weights changed: drop the packed copy and every plan compiled against it (their graphs hold its addresses)."""
+        if self._device.type == "cuda" and (self._packed is not None or self._plans):
+            torch.cuda.synchronize(self._device)
+        for P in self._plans.values():
+            P.rec.close()
         self._plans = {}
+        self._packed = None
+        self._version += 1
+
+    # ---- LoRA (D/loaders/unet.py:271-340 semantics: W + (alpha / r) * B A per target module; merged when the weights are packed)
+    def load_lora_adapter(self, lora, alphas, adapter_name="default", weight: float = 1.0):
+        if self._sd is None:
+            raise _lib.BlobCtrlHipError("this module was built from packed weights: LoRA must be merged before packing")
+        missing = [m for m in alphas if m + ".weight" not in self._sd]
+        if missing:
+            raise KeyError(f"LoRA targets not present in the model: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+        if adapter_name in self._adapters:
+            raise ValueError(f"Adapter name {adapter_name} already in use in the model - please select a new adapter name.")
+        self._adapters[adapter_name] = dict(lora=lora, alphas=alphas, weight=float(weight), active=True)
+        self._invalidate()
+
+    def set_adapters(self, adapter_names, weights=None):
+        names = [adapter_names] if isinstance(adapter_names, str) else list(adapter_names)
+        ws = [1.0] * len(names) if weights is None else ([weights] * len(names) if not isinstance(weights, (list, tuple)) else list(weights))
+        if len(ws) != len(names):
+            raise ValueError(f"Length of adapter names {len(names)} is not equal to the length of their weights {len(ws)}.")
+        unknown = [n for n in names if n not in self._adapters]
+        if unknown:
+            raise ValueError(f"Adapter name(s) {set(unknown)} not in the list of present adapters: {set(self._adapters)}.")
+        before = [(n, a["active"], a["weight"]) for n, a in self._adapters.items()]
+        for n, a in self._adapters.items():
+            a["active"] = n in names
+        for n, w in zip(names, ws):
+            self._adapters[n]["weight"] = 1.0 if w is None else float(w)
+        if before != [(n, a["active"], a["weight"]) for n, a in self._adapters.items()]:
+            self._invalidate()
+
+    def unload_lora(self):
+        if self._adapters:
+            self._adapters.clear()
+            self._invalidate()
 
     @property
     def device(self):
@@ -93,9 +180,9 @@ class _TrunkModule(torch.nn.Module):
 
 
 class BlobNetModel(_TrunkModule):
-    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0"):
+    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0", lazy: bool = False):
         assert config.is_blobnet
-        super().__init__(state_dict, config, device)
+        super().__init__(state_dict, config, device, lazy)
 
     @classmethod
     def from_pretrained(cls, path, device="cuda:0", **_ignored):
@@ -103,7 +190,7 @@ class BlobNetModel(_TrunkModule):
         config.json + diffusion_pytorch_model.safetensors, or the .safetensors file itself."""
         from .checkpoint import load_blobnet
         sd, cfg = load_blobnet(path)
-        return cls(sd, cfg, device)
+        return cls(sd, cfg, device, lazy=True)
 
     def _plan(self, B, H, W):
         key = (B, H, W)
@@ -147,19 +234,47 @@ class BlobNetModel(_TrunkModule):
 
 
 class UNet2DConditionModel(_TrunkModule):
-    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0"):
+    def __init__(self, state_dict, config: TrunkConfig, device="cuda:0", lazy: bool = False):
         assert not config.is_blobnet
-        super().__init__(state_dict, config, device)
+        super().__init__(state_dict, config, device, lazy)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, extra_in_channels=1, lora_path=None, lora_scale=1.0, device="cuda:0", **_ignored):
-        """`UNet2DConditionModel.from_pretrained(sd15_path, subfolder="unet")` + the conv_in 4 -> 5 surgery (inf:229-249) +
-        `load_lora_weights(unet_lora_path)` (inf:270-273) in one step: the packed weights are immutable, so the surgery and the
-        LoRA merge happen before packing (`extra_in_channels=0` / `lora_path=None` skip them)."""
+    def from_pretrained(cls, path, subfolder=None, extra_in_channels=0, lora_path=None, lora_scale=1.0, device="cuda:0", **_ignored):
+        """`UNet2DConditionModel.from_pretrained(sd15_path, subfolder="unet")` (inf:229-232): the file's own 4-channel UNet, held on
+        the host until first use, so that the script's next statements - the conv_in 4 -> 5 surgery through `unet.conv_in`
+        (inf:233-249) and `pipeline.load_lora_weights` (inf:270-273) - work on it unchanged.  `extra_in_channels=1` /
+        `lora_path=` do both in this call instead."""
         import os
         from .checkpoint import load_unet
         sd, cfg = load_unet(os.path.join(path, subfolder) if subfolder else path, extra_in_channels, lora_path, lora_scale)
-        return cls(sd, cfg, device)
+        return cls(sd, cfg, device, lazy=True)
+
+    # ---- `unet.conv_in` as the script uses it (inf:233-249): reads .weight / .bias / .out_channels, assigns a wider Conv2d
+    @property
+    def conv_in(self):
+        if self._sd is None:
+            raise _lib.BlobCtrlHipError("this UNet was built from packed weights: conv_in is not editable")
+        w, b = self._sd["conv_in.weight"], self._sd.get("conv_in.bias")
+        conv = torch.nn.Conv2d(w.shape[1], w.shape[0], kernel_size=3, stride=1, padding=1, bias=b is not None)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            if b is not None:
+                conv.bias.copy_(b)
+        return conv
+
+    def __setattr__(self, name, value):
+        if name == "conv_in" and isinstance(value, torch.nn.Module):
+            w = value.weight.detach().float().cpu()
+            if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] != self._sd["conv_in.weight"].shape[0]:
+                raise ValueError(f"conv_in must be a 3x3 convolution with {self._sd['conv_in.weight'].shape[0]} output channels")
+            self._sd["conv_in.weight"] = w.clone()
+            if value.bias is not None:
+                self._sd["conv_in.bias"] = value.bias.detach().float().cpu().clone()
+            self.trunk_config.in_channels = w.shape[1]
+            self._make_config()
+            self._invalidate()
+            return
+        super().__setattr__(name, value)
 
     def _res_shapes(self, H, W):
         boc = self.trunk_config.block_out_channels

@@ -57,6 +57,7 @@ class BlobCtrlEngine:
         self.blob_w = blobnet_state_dict if isinstance(blobnet_state_dict, PackedTrunk) else \
             PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
         self.scheduler_kind = scheduler
+        self.scheduler_params = (1000, 0.00085, 0.012)               # (num_train_timesteps, beta_start, beta_end): SD-1.5 values
         self.use_graphs = use_graphs
         if self.device.type == "cuda":
             self.stream = torch.cuda.Stream(device=self.device)
@@ -66,6 +67,7 @@ class BlobCtrlEngine:
         self.loop_graph = os.environ.get("BC_LOOP_GRAPH", "1") != "0"     # whole-edit graph (one launch per edit) vs one graph per step
         self._plans = {}                                              # (batch, canvas, steps, ...) -> plan, least recently used first
         self.max_cached_plans = max(1, int(max_cached_plans))         # a 512^2 batch-1 plan holds ~2.5 GB of activations
+        self.max_loop_graphs = 4                                      # whole-edit graphs kept per plan (one per active / inactive pattern)
         self._sched_cache = {}
         self.feat_dim = blobnet_config.in_channels - 5
         self.vae = vae                                                # optional blobctrl_amd.vae.AutoencoderKL
@@ -205,6 +207,40 @@ class BlobCtrlEngine:
         P.captured = False
         self._plans[key] = P
         return P
+
+    def set_scheduler(self, kind, params=None):
+        """`kind` "unipc" | "ddim"; `params` = (num_train_timesteps, beta_start, beta_end) of the scheduler's configuration (the
+        drop-in scheduler objects accept non-default betas: the engine must tabulate the SAME alphas)."""
+        if kind not in ("unipc", "ddim"):
+            raise NotImplementedError(f"scheduler {kind!r} has no coefficient table (UniPC and DDIM have)")
+        self.scheduler_kind = kind
+        if params is not None:
+            self.scheduler_params = (int(params[0]), float(params[1]), float(params[2]))
+
+    def _scheduler_table(self, n):
+        """Coefficient tables depend only on (scheduler, its beta configuration, steps)."""
+        key = (self.scheduler_kind, self.scheduler_params, n)
+        sched = self._sched_cache.get(key)
+        if sched is None:
+            nt, b0, b1 = self.scheduler_params
+            cls = UniPCTable if self.scheduler_kind == "unipc" else DDIMTable
+            sched = cls(num_train_timesteps=nt, beta_start=b0, beta_end=b1)
+            sched.set_timesteps(n)
+            self._sched_cache[key] = sched
+        return sched
+
+    def set_weights(self, unet_w=None, blob_w=None):
+        """New packed weights (LoRA loaded / unloaded, conv_in edited): every cached plan and its graphs hold the old addresses."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        for P in self._plans.values():
+            P.rec.close()
+        self._plans = {}
+        if unet_w is not None:
+            self.unet_w = unet_w
+        if blob_w is not None:
+            self.blob_w = blob_w
+            self.feat_dim = self.blob_cfg.in_channels - 5
 
     def _capture(self, P):
         if P.captured or not self.use_graphs:
@@ -359,11 +395,7 @@ class BlobCtrlEngine:
             raise ValueError(f"blobnet_conditioning_scale: expected {Bi} values, got {len(req_scales)}")
         P = self._plan(B, h, w, T, Dc, n, per_request)
         dev = self.device
-        sched = self._sched_cache.get((self.scheduler_kind, n))       # coefficient tables depend only on (scheduler, steps)
-        if sched is None:
-            sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
-            sched.set_timesteps(n)
-            self._sched_cache[(self.scheduler_kind, n)] = sched
+        sched = self._scheduler_table(n)
         self.timesteps = sched.timesteps
         if latents is None:                                                          # pipe:438-453
             latents = torch.randn((B, 4, h, w), generator=generator, device=generator.device if generator else "cpu",
@@ -408,13 +440,14 @@ class BlobCtrlEngine:
             # the WHOLE edit (prologue + n steps) as ONE hipGraph per (plan, active / inactive pattern): one launch per edit; the
             # per-step scalars (timestep, scheduler coefficients, conditioning scale) are read through the device step counter
             key = tuple(v != 0.0 for v in scales)
-            g = P.loop_graphs.get(key)
+            g = P.loop_graphs.pop(key, None)
             if g is None:
-                if len(P.loop_graphs) >= 4:
-                    P.loop_graphs.clear()                                      # (handles stay owned by the recorder until close)
-                segs = [P.prologue] + [P.step_active if a else P.step_inactive for a in key]
                 torch.cuda.synchronize(self.device)
-                g = P.loop_graphs[key] = P.rec.capture_loop(segs, s, side, self._extra())
+                while len(P.loop_graphs) >= self.max_loop_graphs:              # least recently used pattern: destroy its graph exec
+                    P.rec.destroy_loop_graph(P.loop_graphs.pop(next(iter(P.loop_graphs))))
+                segs = [P.prologue] + [P.step_active if a else P.step_inactive for a in key]
+                g = P.rec.capture_loop(segs, s, side, self._extra())
+            P.loop_graphs[key] = g                                             # (re-inserted: most recently used last)
             _lib.check(self.lib.bc_graph_launch(g, s), "bc_graph_launch")
             return self._result(P, output_type)
         P.prologue.run(s)
@@ -461,8 +494,7 @@ class BlobCtrlEngine:
         segment names (which steps run BlobNet)."""
         n = num_inference_steps
         P = self._plan(B, h, w, T, ctx_dim, n, False)
-        sched = UniPCTable() if self.scheduler_kind == "unipc" else DDIMTable()
-        sched.set_timesteps(n)
+        sched = self._scheduler_table(n)
         keep = blobnet_keep(n, blobnet_control_guidance_start, blobnet_control_guidance_end)
         P.t_table.copy_(sched.timesteps.to(torch.float32))
         coef = sched.table().clone()
@@ -519,13 +551,71 @@ class StableDiffusionBlobNetPipeline:
         self.dinov2, self.dinov2_processor = dinov2, dinov2_processor if dinov2_processor is not None else Dinov2ImageProcessor()
         self.safety_checker = None
         self.device = unet.device
-        self.engine = BlobCtrlEngine(unet.weights, blobnet.weights, unet.trunk_config, blobnet.trunk_config, device=str(unet.device),
-                                     scheduler=scheduler.kind, use_graphs=use_graphs, vae=vae, text_encoder=text_encoder)
+        self._use_graphs = use_graphs
+        self._engine, self._engine_versions = None, None
         self._scheduler = scheduler
         nblocks = len(getattr(vae.config, "block_out_channels", (0, 0, 0, 0))) if vae is not None else 4
         self.vae_scale_factor = 2 ** (nblocks - 1)                                                  # pipe:241
         self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)    # pipe:242
         self._guidance_scale, self._clip_skip, self._num_timesteps = 7.5, None, 0
+
+    # ---- construction as the scripts do it (inf:260-279)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, unet=None, blobnet=None, dinov2_processor=None, dinov2=None,
+                        vae=None, text_encoder=None, tokenizer=None, scheduler=None, safety_checker=None, torch_dtype=None,
+                        device="cuda:0", **_ignored):
+        """`StableDiffusionBlobNetPipeline.from_pretrained(sd15_path, unet=, blobnet=, torch_dtype=, dinov2_processor=, dinov2=)`
+        (inf:260-267; D/pipelines/pipeline_utils.py from_pretrained): components that are not passed are built from the sub-folders
+        of the model directory - `vae/`, `text_encoder/`, `tokenizer/` (vocab.json + merges.txt), `scheduler/scheduler_config.json`,
+        `unet/` - with this package's classes.  `torch_dtype` is accepted and ignored (the kernels compute in fp16 / fp32
+        accumulate); the safety checker stays off as in the reference (pipe:1133-1135)."""
+        import os
+        from .clip_text import CLIPTextModel
+        from .modules import UNet2DConditionModel
+        from .schedulers import scheduler_from_config_dir
+        from .vae import AutoencoderKL
+        root = pretrained_model_name_or_path
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"{root}: not a local model directory (there is no hub download here)")
+        sub = lambda name: os.path.isdir(os.path.join(root, name))
+        dev = str(unet.device) if unet is not None else device
+        if unet is None:
+            unet = UNet2DConditionModel.from_pretrained(root, subfolder="unet", device=dev)
+        if blobnet is None:
+            raise ValueError("blobnet= is required (the SD-1.5 directory does not hold one; inf:252)")
+        if vae is None and sub("vae"):
+            vae = AutoencoderKL.from_pretrained(root, subfolder="vae", device=dev)
+        if text_encoder is None and sub("text_encoder"):
+            text_encoder = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", device=dev)
+        if tokenizer is None and sub("tokenizer"):
+            from .clip_tokenizer import CLIPTokenizer
+            tokenizer = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer")
+        if scheduler is None:
+            scheduler = scheduler_from_config_dir(os.path.join(root, "scheduler"))
+        return cls(vae=vae, unet=unet, tokenizer=tokenizer, text_encoder=text_encoder, blobnet=blobnet, scheduler=scheduler,
+                   safety_checker=None, dinov2_processor=dinov2_processor, dinov2=dinov2)
+
+    @property
+    def engine(self) -> BlobCtrlEngine:
+        """The captured-plan loop engine over the CURRENT packed weights of `unet` / `blobnet`: built on first use, re-pointed (plans
+        dropped) whenever a module's host weights changed (LoRA loaded / unloaded, conv_in surgery)."""
+        versions = (self.unet._version, self.blobnet._version)
+        if self._engine is None:
+            kind = self._scheduler.kind or "unipc"
+            self._engine = BlobCtrlEngine(self.unet.weights, self.blobnet.weights, self.unet.trunk_config, self.blobnet.trunk_config,
+                                          device=str(self.unet.device), scheduler=kind, use_graphs=self._use_graphs, vae=self.vae,
+                                          text_encoder=self.text_encoder)
+            self._engine_versions = versions
+        elif versions != self._engine_versions:
+            self._engine.unet_cfg, self._engine.blob_cfg = self.unet.trunk_config, self.blobnet.trunk_config
+            self._engine.set_weights(None, None)                     # frees the plans that point into the old arenas first
+            self._engine.unet_w = self._engine.blob_w = None
+            self._engine.set_weights(self.unet.weights, self.blobnet.weights)
+            self._engine_versions = versions
+        if self._scheduler.kind is not None:
+            self._engine.set_scheduler(self._scheduler.kind, self._scheduler.table_params()
+                                       if hasattr(self._scheduler, "table_params") else None)
+        return self._engine
 
     # ---- attribute plumbing the scripts touch (inf:276-279)
     @property
@@ -538,7 +628,6 @@ class StableDiffusionBlobNetPipeline:
         if not isinstance(s, TableScheduler):
             raise TypeError("scheduler must be blobctrl_amd.schedulers.UniPCMultistepScheduler or DDIMScheduler")
         self._scheduler = s
-        self.engine.scheduler_kind = s.kind
 
     def to(self, *a, **k):
         return self
@@ -546,9 +635,36 @@ class StableDiffusionBlobNetPipeline:
     def set_progress_bar_config(self, **k):
         pass
 
-    def load_lora_weights(self, *a, **k):
-        raise NotImplementedError("LoRA is merged when the UNet is packed: UNet2DConditionModel.from_pretrained(..., lora_path=...) "
-                                  "(the packed layouts are immutable)")
+    # ---- LoRA (D/loaders/lora_pipeline.py:60-117 -> D/loaders/unet.py:271-340): UNet adapters only, merged when the UNet is packed
+    def load_lora_weights(self, pretrained_model_name_or_path_or_dict, adapter_name=None, weight_name=None, **kwargs):
+        """`pipeline.load_lora_weights(unet_lora_path, adapter_name="default")` (inf:270-273).  A directory (with
+        `pytorch_lora_weights.safetensors` or `weight_name`), a .safetensors file, or a state dict; keys under `unet.` go to the
+        UNet (lora_pipeline.py:102-110); text-encoder LoRA keys are refused (the released BlobCtrl adapter has none)."""
+        import os
+        from .checkpoint import load_lora, lora_from_state_dict
+        src = pretrained_model_name_or_path_or_dict
+        if isinstance(src, dict):
+            if any(k.startswith("text_encoder.") for k in src):
+                raise NotImplementedError("text-encoder LoRA is not supported")
+            lora, alphas = lora_from_state_dict(src)
+        else:
+            path = os.path.join(src, weight_name) if weight_name and os.path.isdir(src) else src
+            lora, alphas = load_lora(path)
+        name = adapter_name if adapter_name is not None else f"default_{len(self.unet._adapters)}"
+        self.unet.load_lora_adapter(lora, alphas, adapter_name=name)
+
+    def set_adapters(self, adapter_names, adapter_weights=None):
+        """`pipeline.set_adapters(["default"])` (inf:274): the active adapters and their weights (merged on the next call)."""
+        self.unet.set_adapters(adapter_names, adapter_weights)
+
+    def fuse_lora(self, *a, **k):
+        """Adapters are always merged into the packed weights: nothing to do."""
+
+    def unload_lora_weights(self):
+        self.unet.unload_lora()
+
+    def get_active_adapters(self):
+        return [n for n, a in self.unet._adapters.items() if a["active"]]
 
     @property
     def guidance_scale(self):

@@ -254,6 +254,10 @@ class _ConfiguredScheduler(TableScheduler):
         src.update(kw)
         return cls(**{k: v for k, v in src.items() if k in known})
 
+    def table_params(self):
+        """(num_train_timesteps, beta_start, beta_end): what the engine builds its coefficient table from."""
+        return (int(self.config["num_train_timesteps"]), float(self.config["beta_start"]), float(self.config["beta_end"]))
+
     @property
     def kind(self):
         return self._kind
@@ -261,6 +265,43 @@ class _ConfiguredScheduler(TableScheduler):
     @kind.setter
     def kind(self, v):
         pass
+
+
+class PNDMScheduler(_ConfiguredScheduler):
+    """What SD-1.5's `scheduler/scheduler_config.json` names.  The reference scripts only read its `.config` and build UniPC (or
+    DDIM) from it (inf:276-277), so this class carries the configuration and refuses to step."""
+    _kind = None
+    _defaults = dict(skip_prk_steps=True, set_alpha_to_one=False, timestep_spacing="leading", clip_sample=False)
+
+    def __init__(self, **kw):
+        cfg = dict(_SD15)
+        cfg.update(self._defaults)
+        cfg.update({k: v for k, v in kw.items() if v is not None})
+        self.config = SchedulerConfig(cfg)
+        self.config["_use_default_values"] = sorted(k for k in cfg if k not in kw or kw[k] is None)
+        self.timesteps = None
+        self.table_impl = None
+
+    def set_timesteps(self, *a, **k):
+        raise NotImplementedError("PNDM is not tabulated: replace it as the scripts do, "
+                                  "pipeline.scheduler = UniPCMultistepScheduler.from_config(pipeline.scheduler.config)")
+
+    step = set_timesteps
+
+
+def scheduler_from_config_dir(path):
+    """`<model>/scheduler/scheduler_config.json` -> the scheduler object its `_class_name` names (PNDM / UniPC / DDIM)."""
+    import json
+    import os
+    with open(os.path.join(path, "scheduler_config.json")) as f:
+        cfg = json.load(f)
+    name = cfg.get("_class_name", "PNDMScheduler")
+    classes = {"PNDMScheduler": PNDMScheduler, "UniPCMultistepScheduler": UniPCMultistepScheduler, "DDIMScheduler": DDIMScheduler}
+    if name not in classes:
+        raise NotImplementedError(f"scheduler class {name} is not available (PNDM config holder, UniPC and DDIM are)")
+    cls = classes[name]
+    known = set(_SD15) | set(cls._defaults)
+    return cls(**{k: v for k, v in cfg.items() if k in known})
 
 
 class UniPCMultistepScheduler(_ConfiguredScheduler):

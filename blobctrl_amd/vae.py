@@ -57,8 +57,7 @@ class AutoencoderKL:
 
     def __init__(self, state_dict, norm_num_groups: int = 32, layers_per_block: int = 2, device="cuda:0"):
         self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.BlobCtrlHipError("blobctrl_amd.AutoencoderKL runs on MI355X only; there is no CPU fallback")
+        # (a host device is accepted for CONSTRUCTION only - loading / inspecting checkpoints; running refuses it: `_need_gpu`)
         self.lib = _lib.load()
         self.config = self._Cfg()
         self.G, self.lpb = norm_num_groups, layers_per_block
@@ -163,7 +162,15 @@ class AutoencoderKL:
         return self._res(rec, B, p + "resnets.1.", _Act(out, Cc, x.H, x.W), Cc)
 
     # ------------------------------------------------------------------------------------------------ plans
+    def to(self, *a, **k):
+        return self
+
+    def _need_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.BlobCtrlHipError("blobctrl_amd.AutoencoderKL runs on MI355X only; there is no CPU fallback")
+
     def _plan_decode(self, B, h, w):
+        self._need_gpu()
         key = ("dec", B, h, w)
         if key in self._plans:
             return self._plans[key]
@@ -192,6 +199,7 @@ class AutoencoderKL:
         return P
 
     def _plan_encode(self, B, H, W):
+        self._need_gpu()
         key = ("enc", B, H, W)
         if key in self._plans:
             return self._plans[key]

@@ -169,3 +169,87 @@ def block_inputs(name):
     temb = g(600 + i, p["B"], 1280) if kind == "resnet" else None
     ctx = g(700 + i, p["B"], 7, p["ctx"]) if kind == "transformer" and p["ctx"] is not None else None
     return x, temb, ctx
+
+
+# ------------------------------------------------------------------------------------------------ on-disk model tree (construction path)
+CLIP_TEST_WORDS = ["a", "frog", "sits", "on", "rock", "in", "pond", "with", "top", "hat", "beside", "it", "the", "butterflies", "and",
+                   "flowers", "blurry", "low", "quality"]
+
+
+def tiny_clip_vocab():
+    """A synthetic CLIP BPE vocabulary: single characters (bare and word-final), a few merges, the two special tokens.  Small enough that
+    every id stays below the tiny text encoder's 99-entry embedding table."""
+    chars = sorted(set("".join(CLIP_TEST_WORDS)) | set(",.'"))
+    merges = [("t", "h"), ("th", "e</w>"), ("o", "n</w>"), ("i", "n</w>"), ("a", "n"), ("an", "d</w>"), ("f", "r"), ("fr", "o"),
+              ("fro", "g</w>"), ("r", "o"), ("ro", "c"), ("roc", "k</w>"), ("h", "a"), ("ha", "t</w>"), ("p", "o"), ("po", "n"),
+              ("pon", "d</w>"), ("l", "o"), ("lo", "w</w>"), ("i", "t</w>"), ("e", "r")]
+    toks = chars + [c + "</w>" for c in chars]
+    for a, b in merges:
+        toks.append(a + b)
+    toks += ["<|startoftext|>", "<|endoftext|>"]
+    return {t: i for i, t in enumerate(toks)}, merges
+
+
+def write_model_tree(root, lora=True):
+    """<root>/sd15/{unet (4-channel conv_in), vae, text_encoder, tokenizer, scheduler}, <root>/blobnet, <root>/dinov2,
+    <root>/unet_lora/pytorch_lora_weights.safetensors: the tiny nets in the layout `scripts/blobctrl_inference.py:220-279` loads.
+    Returns (paths, pieces) where pieces holds the in-memory state dicts / LoRA tensors for cross-checks."""
+    import json
+    import os
+    from blobctrl_amd import checkpoint as ck
+    c, p = TINY, PIPE
+    root = str(root)
+    mk = lambda *a: (os.makedirs(os.path.join(root, *a), exist_ok=True), os.path.join(root, *a))[1]
+    base_unet = synth.synth_state_dict(synth.trunk_param_shapes(4, c["boc"], 2, c["ctx"], 4, blobnet=False), 5)
+    _, bsd = tiny_weights()
+    vsd, csd, dsd = tiny_pipeline_weights()
+    d = mk("sd15", "unet")
+    ck.write_safetensors(os.path.join(d, "diffusion_pytorch_model.safetensors"), base_unet)
+    json.dump({"_class_name": "UNet2DConditionModel", "block_out_channels": list(c["boc"]), "attention_head_dim": c["heads"],
+               "norm_num_groups": c["groups"], "cross_attention_dim": c["ctx"], "in_channels": 4, "out_channels": 4},
+              open(os.path.join(d, "config.json"), "w"))
+    d = mk("sd15", "vae")
+    ck.write_safetensors(os.path.join(d, "diffusion_pytorch_model.safetensors"), vsd)
+    json.dump({"_class_name": "AutoencoderKL", "block_out_channels": list(p["vae_boc"]), "norm_num_groups": p["vae_groups"],
+               "layers_per_block": 2, "scaling_factor": 0.18215, "latent_channels": 4}, open(os.path.join(d, "config.json"), "w"))
+    d = mk("sd15", "text_encoder")
+    ck.write_safetensors(os.path.join(d, "model.safetensors"), csd)
+    json.dump({"num_attention_heads": p["clip"]["heads"], "hidden_size": p["clip"]["hidden"], "layer_norm_eps": 1e-5,
+               "num_hidden_layers": p["clip"]["layers"], "intermediate_size": p["clip"]["inter"], "vocab_size": p["clip"]["vocab"]},
+              open(os.path.join(d, "config.json"), "w"))
+    d = mk("sd15", "tokenizer")
+    vocab, merges = tiny_clip_vocab()
+    assert len(vocab) <= p["clip"]["vocab"], len(vocab)
+    json.dump(vocab, open(os.path.join(d, "vocab.json"), "w"))
+    with open(os.path.join(d, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    json.dump({"bos_token": "<|startoftext|>", "eos_token": "<|endoftext|>", "pad_token": "<|endoftext|>", "unk_token": "<|endoftext|>"},
+              open(os.path.join(d, "special_tokens_map.json"), "w"))
+    json.dump({"model_max_length": 77, "tokenizer_class": "CLIPTokenizer", "pad_token": "<|endoftext|>", "bos_token": "<|startoftext|>",
+               "eos_token": "<|endoftext|>", "unk_token": "<|endoftext|>"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+    d = mk("sd15", "scheduler")
+    json.dump({"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+               "trained_betas": None, "clip_sample": False}, open(os.path.join(d, "scheduler_config.json"), "w"))
+    d = mk("blobnet")
+    ck.write_safetensors(os.path.join(d, "diffusion_pytorch_model.safetensors"), bsd)
+    json.dump({"block_out_channels": list(c["boc"]), "attention_head_dim": c["heads"], "norm_num_groups": c["groups"],
+               "in_channels": 4, "conditioning_channels": 1 + c["feat"]}, open(os.path.join(d, "config.json"), "w"))
+    d = mk("dinov2")
+    ck.write_safetensors(os.path.join(d, "model.safetensors"), dsd)
+    json.dump({"num_attention_heads": p["dino"]["heads"], "patch_size": p["dino"]["patch"], "layer_norm_eps": 1e-6,
+               "hidden_size": p["dino"]["hidden"]}, open(os.path.join(d, "config.json"), "w"))
+    json.dump({"crop_size": {"height": 224, "width": 224}, "size": {"shortest_edge": 256}, "image_mean": [0.485, 0.456, 0.406],
+               "image_std": [0.229, 0.224, 0.225], "rescale_factor": 1 / 255, "image_processor_type": "BitImageProcessor"},
+              open(os.path.join(d, "preprocessor_config.json"), "w"))
+    wq = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    ff = "mid_block.attentions.0.transformer_blocks.0.ff.net.2"
+    lora_t = {f"unet.{wq}.lora_A.weight": g(1, 4, c["boc"][0]) * 0.2, f"unet.{wq}.lora_B.weight": g(2, c["boc"][0], 4) * 0.2,
+              "unet.conv_in.lora_A.weight": g(3, 4, 5, 3, 3) * 0.2, "unet.conv_in.lora_B.weight": g(4, c["boc"][0], 4, 1, 1) * 0.2,
+              f"unet.{ff}.lora_A.weight": g(5, 4, 4 * c["boc"][-1]) * 0.1, f"unet.{ff}.lora_B.weight": g(6, c["boc"][-1], 4) * 0.1}
+    if lora:
+        d = mk("unet_lora")
+        ck.write_safetensors(os.path.join(d, "pytorch_lora_weights.safetensors"), lora_t)
+    paths = dict(sd15=os.path.join(root, "sd15"), blobnet=os.path.join(root, "blobnet"), dinov2=os.path.join(root, "dinov2"),
+                 unet_lora=os.path.join(root, "unet_lora"))
+    return paths, dict(unet4=base_unet, blobnet=bsd, vae=vsd, clip=csd, dino=dsd, lora=lora_t)

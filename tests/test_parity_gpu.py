@@ -272,7 +272,7 @@ def test_modules_from_pretrained_round_trip(tmp_path):
     ld = tmp_path / "unet_lora"
     ld.mkdir()
     ck.write_safetensors(str(ld / "pytorch_lora_weights.safetensors"), lora)
-    unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "sd15"), subfolder="unet", lora_path=str(ld))
+    unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "sd15"), subfolder="unet", extra_in_channels=1, lora_path=str(ld))
     assert unet.config.in_channels == 4 and unet.trunk_config.in_channels == 5      # the reference leaves config at the latent count (inf:233-249)
     sd5 = ck.expand_conv_in(base, 1)
     sd5 = merge_lora(sd5, {k[len("unet."):]: v for k, v in lora.items()})

@@ -40,7 +40,7 @@ def main():
     t0 = sync()
     if args.models:
         sd15 = os.path.join(args.models, "stable-diffusion-v1-5")
-        unet = UNet2DConditionModel.from_pretrained(sd15, subfolder="unet", lora_path=os.path.join(args.models, "unet_lora"))
+        unet = UNet2DConditionModel.from_pretrained(sd15, subfolder="unet", extra_in_channels=1, lora_path=os.path.join(args.models, "unet_lora"))
         blob = BlobNetModel.from_pretrained(os.path.join(args.models, "blobnet"))
         vae = AutoencoderKL.from_pretrained(sd15, subfolder="vae")
         clip = CLIPTextModel.from_pretrained(sd15, subfolder="text_encoder")

@@ -239,6 +239,75 @@ def golden_loop():
     np.savez_compressed(os.path.join(OUT, "loop_tiny.npz"), **out)
 
 
+def golden_fullsize_loop(variants=None):
+    """The north star's own parity statement: a FREE-RUNNING 50-step 512x512 edit on the full-size SD-1.5 UNet +
+    BlobNet (reference classes, CPU fp32, the loop body of pipe:1025-1102 as golden_loop drives it), bench.py's synthetic weights and
+    inputs, CFG 7.5, guidance window [0, 0.9] (45 BlobNet-active steps + 5 UNet-only).  Only the final latents and three intermediate
+    checkpoints per run are stored (4 x 64 KB).  ~25-40 min per run on 8 cores.  Variants: "<scheduler>:<conv_out_scale>", default
+    all four of {unipc, ddim} x {1.0 (the benchmark's weights), 0.3 (synth.contractive_variant)}; runs already in the file are kept.
+    tools/amplification_probe.py measured how much the edit amplifies a perturbation of its start latents: 2.6 (DDIM) / 3.2 (UniPC)
+    on the benchmark's weights, 1.3 / 1.5 at conv_out_scale 0.3."""
+    import time
+    import bench
+    variants = variants or ["unipc:1.0", "ddim:1.0", "unipc:0.3", "ddim:0.3"]
+    path = os.path.join(OUT, "loop_fullsize.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    h = w = 64
+    steps, ge = 50, 0.9
+    inp = bench.synth_inputs(h, w)
+    usd0, bsd0 = bench.synth_weights()
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(in_channels=5, out_channels=4, cross_attention_dim=768, attention_head_dim=8)
+        blob = BlobNetModel(in_channels=4, conditioning_channels=1025, cross_attention_dim=None, attention_head_dim=8)
+    pipe = StableDiffusionBlobNetPipeline.__new__(StableDiffusionBlobNetPipeline)
+    ell = [[361.1067, 367.8526], [85.4812, 103.6543], 87.3739]
+    mean, cov = ref_inf.get_gs_from_ellipse(ell)
+    nm, nc = ref_inf.normalize_gs(mean, cov, 512, 512)
+    gs_score = splat_features(**ref_inf.get_blob_dict_from_norm_gs(nm, nc), score_size=(h, w), return_d_score=True)
+    bg_s, fg_s = gs_score.unbind(dim=1)
+    bg_s, fg_s = bg_s.unsqueeze(1).repeat(2, 1, 1, 1).float(), fg_s.unsqueeze(1).repeat(2, 1, 1, 1).float()
+    fg_lat, bg_lat = inp["fg"].repeat(2, 1, 1, 1), inp["bg"].repeat(2, 1, 1, 1)
+    feats = pipe.splat_features_from_scores(fg_s, inp["dino"].repeat(2, 1, 1), size=h, channels_last=False)
+    loaded = None
+    for var in variants:
+        sname, scale = var.split(":")
+        scale = float(scale)
+        tag = f"{sname}_s{scale:g}"
+        if f"{tag}_final" in out:
+            print("have", tag)
+            continue
+        if loaded != scale:
+            usd, bsd = synth.contractive_variant(usd0, bsd0, conv_out_scale=scale) if scale != 1.0 else (usd0, bsd0)
+            unet.load_state_dict(usd, strict=True, assign=True)
+            blob.load_state_dict(bsd, strict=True, assign=True)
+            unet.eval(); blob.eval()
+            loaded = scale
+        sch = (UniPCMultistepScheduler(**SD_SCHED) if sname == "unipc" else DDIMScheduler(**SD_SCHED, clip_sample=False, set_alpha_to_one=False))
+        sch.set_timesteps(steps)
+        latents = inp["latents"] * sch.init_noise_sigma
+        keep = [1.0 - float(i / steps < 0.0 or (i + 1) / steps > ge) for i in range(steps)]
+        t0 = time.time()
+        for i, t in enumerate(sch.timesteps):
+            lmi = sch.scale_model_input(torch.cat([latents] * 2), t)
+            bi = pipe.construct_blobnet_input(lmi, fg_s, fg_lat, feats, background=False)
+            d, m, u = blob(bi, t, conditioning_scale=1.0 * keep[i], return_dict=False)
+            ui = pipe.construct_blobnet_input(lmi, bg_s, bg_lat, background=True)
+            npred = unet(ui, t, encoder_hidden_states=inp["prompt"], down_block_add_samples=[x[..., -x.shape[-2]:] for x in d],
+                         mid_block_add_sample=m[..., -m.shape[-2]:], up_block_add_samples=[x[..., -x.shape[-2]:] for x in u],
+                         return_dict=False)[0]
+            npred = npred[..., :, npred.shape[-1] // 2:]
+            nu, nt = npred.chunk(2)
+            npred = nu + 7.5 * (nt - nu)
+            latents = sch.step(npred, t, latents, return_dict=False)[0]
+            if i + 1 in (1, 10, 25, 40):
+                out[f"{tag}_x{i + 1}"] = latents.numpy().copy()
+            print(f"{tag} step {i + 1}/{steps} |x| max {latents.abs().max():.2f} ({time.time() - t0:.0f} s)", flush=True)
+        out[f"{tag}_final"] = latents.numpy().copy()
+        out["window_end"] = np.float32(ge)
+        np.savez_compressed(path, **out)                      # after every run: a later interruption keeps the finished ones
+        print("wrote", tag, "->", path)
+
+
 # ------------------------------------------------------------------------------------------------ 5. dinov2
 def golden_dinov2():
     from transformers import Dinov2Config, Dinov2Model
@@ -600,6 +669,9 @@ def golden_blocks():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
+        if sys.argv[1] == "golden_fullsize_loop":             # python tools/make_golden.py golden_fullsize_loop [unipc:1.0 ...]
+            golden_fullsize_loop(sys.argv[2:] or None)
+            sys.exit(0)
         for fn in sys.argv[1:]:
             globals()[fn]()
         sys.exit(0)
