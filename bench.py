@@ -53,10 +53,9 @@ def synth_inputs(h, w, T=77, ctx=768, feat=1024, batch=1):
 
 def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
     """The CPU oracle (oracle/, kind 'port') timed on the host cores: FULL denoise steps of the same workload as the reference
-    executes them (BlobNet AND UNet at CFG batch 2, fp32, pipe:1043-1090), one warm-up step, then the median of `timed_steps`
-    steps.  The thread count is chosen once by a sweep over {16, 32, 64, 128} on a proxy (one ResBlock
-    convolution, one GEGLU projection, one self-attention of the step); it is recorded in `cores`.  The 50-step edit and the C1 (20-step) edit are extrapolations of
-    the measured step time and are labelled as such."""
+    executes them (BlobNet AND UNet at CFG batch 2, fp32, pipe:1043-1090).  The thread count is chosen on the measured step itself
+    (one step per candidate), it is recorded in `cores` next to the physical core count.  The 50-step edit and the C1 (20-step)
+    edit are extrapolations of the measured step time and are labelled as such."""
     import statistics
     from oracle import blob_splat
     from oracle.nets import NetConfig
@@ -65,26 +64,7 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    sweep = {}
-    # proxy = one convolution, one GEGLU projection and one self-attention of the step's mix (a convolution alone favours thread
-    # counts at which the attention / linear layers of the full nets oversubscribe: 64 threads won the conv and lost the step)
-    xs, ws = torch.randn(2, 320, h, 2 * w), torch.randn(320, 320, 3, 3)
-    xl, wl = torch.randn(2 * h * 2 * w, 320), torch.randn(2560, 320)
-    q = torch.randn(2, 8, (h // 2) * w, 80)
-
-    def proxy():
-        torch.nn.functional.conv2d(xs, ws, padding=1)
-        torch.nn.functional.linear(xl, wl)
-        torch.nn.functional.scaled_dot_product_attention(q, q, q)
-    for nt in sorted({min(avail, c) for c in (16, 32, 64, 128)}):
-        torch.set_num_threads(nt)
-        proxy()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            proxy()
-        sweep[nt] = (time.perf_counter() - t0) / 2
-    cores = min(sweep, key=sweep.get)
-    torch.set_num_threads(cores)
+    physical = physical_cores() or avail
     ucfg = NetConfig(in_channels=5, cross_attention_dim=768)
     bcfg = NetConfig(in_channels=1029, cross_attention_dim=None)
     b = inp["blob"]
@@ -99,20 +79,156 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
         """pipe:1031-1098: BlobNet on the CFG batch, right-square slices of its residuals into the UNet, crop + CFG."""
         return noise_pred_step(usd, ucfg, bsd, bcfg, inp["latents"], t, inp["prompt"], fg, bg, fg_s, bg_s, feats, 1.0, 7.5)
 
-    times = []
+    # The thread count is chosen on the MEASURED quantity (VERDICT r2): one full step at each candidate (32 threads - the round-1/2
+    # optimum on the 2 x 64-core hosts - and one thread per physical core, capped by the CPUs this process may use), then two more
+    # (`timed_steps` - candidates, at least one) at the faster one; the reported step time is the median of the steps taken at the chosen
+    # count.  One untimed warm-up step comes first.
+    cands = sorted({min(avail, 32), min(avail, max(1, physical))})
+    per_thread, all_times = {}, []
     with torch.no_grad():
-        for i in range(1 + timed_steps):
+        torch.set_num_threads(cands[0])
+        t0 = time.perf_counter()
+        one_step(torch.tensor(999))                      # warm-up step (primitive creation, first touch): not used
+        all_times.append(("warm-up", time.perf_counter() - t0))
+        for k, nt in enumerate(cands):
+            torch.set_num_threads(nt)
             t0 = time.perf_counter()
-            one_step(torch.tensor(999 - 20 * i))
-            times.append(time.perf_counter() - t0)
-    t_step = statistics.median(times[1:])
-    sample = (f"{timed_steps} full denoise steps after 1 warm-up step (BlobNet + UNet at CFG batch 2 as the reference executes "
-              f"them, fp32, {8*h}x{8*w}): median {t_step:.2f} s/step on {cores} threads (warm-up {times[0]:.2f} s; thread sweep on a "
-              f"conv + linear + attention proxy {{{', '.join(f'{k}: {v*1e3:.0f} ms' for k, v in sorted(sweep.items()))}}}); value = 1 / (s/step x {steps}) "
+            one_step(torch.tensor(999 - 20 * k))
+            per_thread[nt] = [time.perf_counter() - t0]
+            all_times.append((nt, per_thread[nt][0]))
+        cores = min(per_thread, key=lambda n_: per_thread[n_][0])
+        torch.set_num_threads(cores)
+        for i in range(max(1, timed_steps - len(cands))):
+            t0 = time.perf_counter()
+            one_step(torch.tensor(959 - 20 * i))
+            per_thread[cores].append(time.perf_counter() - t0)
+            all_times.append((cores, per_thread[cores][-1]))
+    t_step = statistics.median(per_thread[cores])
+    sample = (f"{len(per_thread[cores])} full denoise steps (BlobNet + UNet at CFG batch 2 as the reference executes them, fp32, "
+              f"{8*h}x{8*w}) at the chosen thread count: median {t_step:.2f} s/step on {cores} threads; thread count chosen on the step "
+              f"itself, one step per candidate {{{', '.join(f'{k}: {v[0]:.1f} s' for k, v in sorted(per_thread.items()))}}} "
+              f"({physical} physical cores, {avail} CPUs visible); value = 1 / (s/step x {steps}) "
               "is an EXTRAPOLATION of the measured step time to the whole edit (the scheduler update is negligible)")
     return dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
-                host_cpus_visible=avail, s_per_step=round(t_step, 3), step_times_s=[round(x, 3) for x in times],
+                host_cpus_visible=avail, physical_cores=physical, s_per_step=round(t_step, 3),
+                step_times_s=[[n_, round(x, 3)] for n_, x in all_times],
                 c1_20step_edit_s_extrapolated=round(t_step * 20, 1), edit_s_extrapolated=round(t_step * steps, 1)), None
+
+
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo, restricted to nothing (the affinity mask caps the choice separately)."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen)
+    except OSError:
+        return 0
+
+
+def make_request_batch(ids, h, w, dev):
+    """BASELINE configs[2] / [3]: `ids` independent edit requests as ONE per-request batch (own fg / bg latents, ellipse,
+    DINO vector, prompt, noise; every 4th request is a `remove`: strength 0.0 and gs_score = (bg 1, fg 0), inf:175-188)."""
+    import numpy as np
+    from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
+    gen = lambda seed, *shape: torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
+    fg, bg, sc, dino, lat, neg, pos, strength = [], [], [], [], [], [], [], []
+    for i in ids:
+        sx = (8 * w) / 512.0
+        ell = [[(200.0 + 23.0 * (i % 9)) * sx, (180.0 + 31.0 * (i % 7)) * sx], [(60.0 + 5.0 * (i % 11)) * sx, (90.0 + 3.0 * (i % 13)) * sx],
+               float((17 * i) % 180)]
+        sco = splat_features(**blob_dict_from_ellipse(ell, 8 * w, 8 * h), score_size=(h, w), return_d_score=True, device=str(dev))
+        remove = i % 4 == 1
+        if remove:
+            sco = torch.stack([torch.ones_like(sco[:, 0]), torch.zeros_like(sco[:, 1])], 1)
+        sc.append(sco)
+        strength.append(0.0 if remove else 1.0)
+        fg.append(gen(10_000 + i, 1, 4, h, w) * 0.18215 * 5)
+        bg.append(gen(20_000 + i, 1, 4, h, w) * 0.18215 * 5)
+        dino.append(gen(30_000 + i, 1, 1, 1024))
+        lat.append(gen(40_000 + i, 1, 4, h, w))
+        neg.append(gen(50_000, 1, 77, 768))
+        pos.append(gen(60_000 + i, 1, 77, 768))
+    cat = lambda xs: torch.cat(xs, 0).to(dev)
+    return dict(prompt=cat(neg + pos), fg=cat(fg), bg=cat(bg), score=torch.cat(sc, 0), dino=cat(dino), latents=cat(lat),
+                strength=strength)
+
+
+def other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, denoise_steps, scheduler):
+    """The other BASELINE configurations on the driver's clock, 1 warm-up + 2 timed edits each, inputs
+    resident in HBM, same engine and packed weights as the headline run:
+      c3  configs[2]: batch 8, MIXED operations (per-request inputs and strengths, two `remove`), 512^2, hipGraph-captured loop
+      c5  configs[4]: 768^2, batch 4
+      unipc: the headline workload with the scheduler the reference scripts run (inf:276)."""
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import splat_features
+    out = {}
+
+    def timed(fn, edits=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(edits):
+            o = fn()
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        return (time.perf_counter() - t0) / edits
+
+    rb = make_request_batch(list(range(8)), 64, 64, dev)
+    dt = timed(lambda: pipe(rb["prompt"], rb["fg"], rb["bg"], rb["score"], rb["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
+                            latents=rb["latents"], blobnet_conditioning_scale=rb["strength"]))
+    out["c3_batch8_mixed_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
+    out["c3_batch8_mixed_images_per_s"] = round(8 / dt, 4)
+    h5 = 96
+    i5 = synth_inputs(h5, h5, batch=4)
+    d5 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in i5.items()}
+    s5 = splat_features(**i5["blob"], score_size=(h5, h5), return_d_score=True, device=str(dev))
+    dt = timed(lambda: pipe(d5["prompt"], d5["fg"], d5["bg"], s5, d5["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
+                            latents=d5["latents"], blobnet_conditioning_scale=1.0))
+    out["c5_768_batch4_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
+    out["c5_768_batch4_images_per_s"] = round(4 / dt, 4)
+    other = "unipc" if scheduler == "ddim" else "ddim"
+    eng = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=other)
+    i1 = synth_inputs(64, 64)
+    d1 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in i1.items()}
+    s1 = splat_features(**i1["blob"], score_size=(64, 64), return_d_score=True, device=str(dev))
+    dt = timed(lambda: eng(d1["prompt"], d1["fg"], d1["bg"], s1, d1["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
+                           latents=d1["latents"], blobnet_conditioning_scale=1.0))
+    out[f"{other}_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
+    out["note"] = (f"1 warm-up + 2 timed edits each, {denoise_steps} steps, guidance window [0,1], CFG 7.5; c3 / c5 with the "
+                   f"{scheduler.upper()} scheduler of the headline run; ms per denoise step of the WHOLE batch")
+    return out
+
+
+def metric_name(args):
+    """The headline metric name is reserved for the headline workload (512^2, batch 1, 50 steps, --steps edits per rank); anything
+    else carries its parameters in the name so that it is never filed under the headline."""
+    name = f"{args.res}x{args.res}_{args.denoise_steps}step_blobctrl_edits_per_sec"
+    if args.batch != 1:
+        name += f"_batch{args.batch}"
+    if args.requests:
+        name += f"_requests{args.requests}"
+    return name
+
+
+def device_identity(dev):
+    """(local device index, PCI bus id, uuid when the runtime exposes one) of this rank's GPU: the bench line proves N distinct devices."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(idx)
+    bdf = None
+    try:
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}"
+    except AttributeError:
+        pass
+    return dict(local_device=idx, pci_bdf=bdf, uuid=str(getattr(props, "uuid", "")) or None, name=props.name)
 
 
 def csrc_sha():
@@ -133,12 +249,16 @@ def pmc_traffic(kernel_label, res, batch):
     kernel sources (csrc hash) at the headline shape; otherwise `traffic` is null and `traffic_source` says why."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")))      # by name (r1_, r2_, ...), never by mtime
     if not files:
         return None, "no profiles/*pmc_hbm_traffic.json"
-    with open(files[-1]) as f:
-        doc = json.load(f)
-    name = os.path.relpath(files[-1], REPO)
+    docs = []
+    for fn in files:
+        with open(fn) as f:
+            docs.append((fn, json.load(f)))
+    match = [fd for fd in docs if fd[1].get("csrc_sha") == csrc_sha()]
+    fn, doc = (match or docs)[-1]                      # the summary measured on THESE kernel sources, else the newest round's (refused below)
+    name = os.path.relpath(fn, REPO)
     if (res, batch) != (512, 1):
         return None, f"{name} was measured at 512x512 batch 1, this run is {res}x{res} batch {batch}"
     if doc.get("csrc_sha") != csrc_sha():
@@ -300,13 +420,36 @@ def _free_port():
     return port
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT touching HIP or torch (the launcher parent must stay GPU-free by construction: a
+    fork + exec of a GPU-initialised process takes the box down on this pool).  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when set, else the KFD topology in sysfs (nodes with simd_count > 0 are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                pass
+    except OSError:
+        return 0
+    return n
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without torchrun: start N fresh worker processes (one per GPU, LOCAL_RANK = GPU index) from
     this parent, which has made NO GPU call (never re-exec a process that touched the GPU), relay rank 0's JSON line, and
     fail if any worker fails.  With fewer than N GPUs visible (a 1-GPU box) the workers share devices and use gloo, because
     RCCL refuses two ranks on one device; BC_DIST_BACKEND overrides."""
     import subprocess
-    ngpu = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    ngpu = visible_gpu_count()                  # sysfs / environment only: the parent makes no HIP and no torch GPU call
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     if "BC_DIST_BACKEND" not in env and ngpu < n:
@@ -335,9 +478,16 @@ def stub_worker(args):
     mine = bdist.shard_requests(args.requests, rank, world) if args.requests else list(range(args.steps))
     dt = bdist.barrier_max_seconds(0.01 * (1 + rank))
     total = args.requests if args.requests else world * args.steps
+    ident = dict(rank=rank, local_rank=local, backend=(tdist.get_backend() if world > 1 else None), local_device=local, pci_bdf=None)
+    ranks = [ident]
+    if world > 1:
+        ranks = [None] * world
+        tdist.all_gather_object(ranks, ident)
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": total / dt, "n_gpus": world, "steps": args.steps, "local_requests": len(mine),
-                          "gpus_arg": args.gpus}), flush=True)
+                          "gpus_arg": args.gpus, "metric_name": metric_name(args),
+                          "config": {"ranks": ranks, "distinct_devices": len({r["local_device"] for r in ranks}),
+                                     "workload": f"BASELINE configs[{3 if args.requests else 1}]"}}), flush=True)
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
@@ -355,6 +505,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (splat + DINOv2 + CLIP + VAE + loop) timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C5 / other-scheduler timings (`configs` block of the line)")
     ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE configs[3]: this many independent edit requests in total, sharded round-robin over the ranks "
@@ -404,32 +555,7 @@ def main():
                     guidance_scale=7.5, latents=lat, blobnet_conditioning_scale=1.0,
                     blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0)
 
-    def request_batch(ids):
-        """BASELINE configs[2] / [3]: `ids` independent edit requests as ONE per-request batch (own fg / bg latents, ellipse,
-        DINO vector, prompt, noise; every 4th request is a `remove`: strength 0.0 and gs_score = (bg 1, fg 0), inf:175-188)."""
-        import numpy as np
-        from blobctrl_amd.splat import blob_dict_from_ellipse
-        gen = lambda seed, *shape: torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(shape).astype(np.float32))
-        fg, bg, sc, dino, lat, neg, pos, strength = [], [], [], [], [], [], [], []
-        for i in ids:
-            sx = (8 * w) / 512.0
-            ell = [[(200.0 + 23.0 * (i % 9)) * sx, (180.0 + 31.0 * (i % 7)) * sx], [(60.0 + 5.0 * (i % 11)) * sx, (90.0 + 3.0 * (i % 13)) * sx],
-                   float((17 * i) % 180)]
-            sco = splat_features(**blob_dict_from_ellipse(ell, 8 * w, 8 * h), score_size=(h, w), return_d_score=True, device=str(dev))
-            remove = i % 4 == 1
-            if remove:
-                sco = torch.stack([torch.ones_like(sco[:, 0]), torch.zeros_like(sco[:, 1])], 1)
-            sc.append(sco)
-            strength.append(0.0 if remove else 1.0)
-            fg.append(gen(10_000 + i, 1, 4, h, w) * 0.18215 * 5)
-            bg.append(gen(20_000 + i, 1, 4, h, w) * 0.18215 * 5)
-            dino.append(gen(30_000 + i, 1, 1, 1024))
-            lat.append(gen(40_000 + i, 1, 4, h, w))
-            neg.append(gen(50_000, 1, 77, 768))
-            pos.append(gen(60_000 + i, 1, 77, 768))
-        cat = lambda xs: torch.cat(xs, 0).to(dev)
-        return dict(prompt=cat(neg + pos), fg=cat(fg), bg=cat(bg), score=torch.cat(sc, 0), dino=cat(dino), latents=cat(lat),
-                    strength=strength)
+    request_batch = lambda ids: make_request_batch(ids, h, w, dev)
 
     def run_requests(rb):
         return pipe(rb["prompt"], rb["fg"], rb["bg"], rb["score"], rb["dino"], num_inference_steps=args.denoise_steps,
@@ -460,15 +586,18 @@ def main():
         tdist.barrier()
     dt = bdist.barrier_max_seconds(time.perf_counter() - t0, dev)
     weights_s = [round(t_weights, 2)]
+    ident = dict(rank=rank, local_rank=local, backend=(tdist.get_backend() if world > 1 else None), **device_identity(dev))
+    ranks = [ident]
     if world > 1:
         weights_s = [None] * world
         tdist.all_gather_object(weights_s, round(t_weights, 2))
+        ranks = [None] * world
+        tdist.all_gather_object(ranks, ident)
     units = args.requests if args.requests else world * args.steps * args.batch
 
     plan = pipe.plan_for(args.batch, h, w, 77, 768, args.denoise_steps, per_request=bool(args.requests))
     line = {
-        "metric": "512x512_50step_blobctrl_edits_per_sec" if args.res == 512
-        else f"{args.res}x{args.res}_{args.denoise_steps}step_blobctrl_edits_per_sec",
+        "metric": metric_name(args),
         "value": units / dt, "unit": "edits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / (len(batches) if args.requests else args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp16", "data": "synthetic",
@@ -481,6 +610,7 @@ def main():
                    "denoise_step_ms": dt / (len(batches) if args.requests else args.steps) / args.denoise_steps * 1e3,
                    "algorithmic_tflop_per_edit": plan.step_active.flops * args.denoise_steps / 1e12 / args.batch,
                    "dist_backend": (tdist.get_backend() if world > 1 else None),
+                   "ranks": ranks, "distinct_devices": len({(r["local_device"], r["pci_bdf"]) for r in ranks}),
                    "weights_s": weights_s},
     }
     if rank == 0 and not args.no_roofline:
@@ -488,6 +618,8 @@ def main():
         line["roofline"] = rl
         if args.table:
             print(json.dumps(table, indent=1), file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_configs and args.batch == 1 and not args.requests and args.res == 512:
+        line["configs"] = other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, args.denoise_steps, args.scheduler)
     if rank == 0 and world == 1 and not args.no_e2e and args.batch == 1 and not args.requests:
         e2e = end_to_end(pw_u, pw_b, ucfg, bcfg, dev, args.res, args.denoise_steps)
         line["edit_ms_end_to_end"] = e2e["edit_ms_end_to_end"]

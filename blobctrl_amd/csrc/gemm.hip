@@ -492,8 +492,10 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     }
     const bool halo = p.tile_cfg == BC_TILE_HALO;
     if (halo) {
-        if (p.lda <= 0 || !p.A2) p.lda = p.A2 ? p.C1 : p.Cin;
+        if (p.lda <= 0) p.lda = p.A2 ? p.C1 : p.Cin;          // pixel stride of A: 0 = its channel count (a wider NHWC view passes its own)
         if (p.A2 && p.lda2 <= 0) p.lda2 = p.Cin - p.C1;
+        BC_CHECK_ARG(p.lda >= (p.A2 ? p.C1 : p.Cin) && p.lda % 8 == 0, "bc_gemm: BC_TILE_HALO lda=%d must be >= the channel count and a multiple of 8", p.lda);
+        BC_CHECK_ARG(!p.A2 || (p.lda2 >= p.Cin - p.C1 && p.lda2 % 8 == 0), "bc_gemm: BC_TILE_HALO lda2=%d must be >= Cin - C1 and a multiple of 8", p.lda2);
         BC_CHECK_ARG(bc_conv_halo_ok(p), "bc_gemm: BC_TILE_HALO needs a 3x3 stride-1 pad-1 convolution with Cin%%64==0, N%%160==0, "
                                          "Wout%%16==0, Hout%%8==0 (Cin=%d N=%d %dx%d)", p.Cin, p.N, p.Hout, p.Wout);
         BC_CHECK_ARG(!p.a_affine || p.a_act == BC_ACT_NONE || p.a_act == BC_ACT_SILU, "bc_gemm: a_act must be NONE or SILU");

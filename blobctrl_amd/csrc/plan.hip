@@ -66,6 +66,13 @@ struct Rec {
     BcGemm g;                    // BC_OP_GEMM
 };
 
+struct EventSet {                // events of a timed replay: destroyed on every exit path
+    std::vector<hipEvent_t> ev;
+    explicit EventSet(size_t n) : ev(n, nullptr) {}
+    ~EventSet() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+    hipEvent_t& operator[](size_t i) { return ev[i]; }
+};
+
 struct Seg {
     std::string name;
     std::vector<Rec> recs;
@@ -381,8 +388,8 @@ extern "C" int bc_plan_run_timed(BcPlan* pl, int seg, bc_stream stream, float* m
     BC_CHECK_ARG(ms_out != nullptr, "bc_plan_run_timed: null output");
     hipStream_t st[kMaxStreams];
     for (int i = 0; i < kMaxStreams; ++i) st[i] = reinterpret_cast<hipStream_t>(stream);   // serial: isolates every launch
-    std::vector<hipEvent_t> ev(2 * sg.recs.size());
-    for (auto& e : ev) BC_CHECK_HIP(hipEventCreate(&e));
+    EventSet ev(2 * sg.recs.size());
+    for (auto& e : ev.ev) BC_CHECK_HIP(hipEventCreate(&e));
     int rc = 0;
     for (size_t i = 0; i < sg.recs.size() && !rc; ++i) {
         BC_CHECK_HIP(hipEventRecord(ev[2 * i], st[0]));
@@ -393,7 +400,6 @@ extern "C" int bc_plan_run_timed(BcPlan* pl, int seg, bc_stream stream, float* m
         BC_CHECK_HIP(hipStreamSynchronize(st[0]));
         for (size_t i = 0; i < sg.recs.size(); ++i) BC_CHECK_HIP(hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -405,8 +411,8 @@ extern "C" int bc_plan_run_timed_kernels(BcPlan* pl, int seg, bc_stream stream, 
     hipStream_t st[kMaxStreams];
     for (int i = 0; i < kMaxStreams; ++i) st[i] = reinterpret_cast<hipStream_t>(stream);
     const size_t n = sg.recs.size();
-    std::vector<hipEvent_t> ev(3 * n);
-    for (auto& e : ev) BC_CHECK_HIP(hipEventCreate(&e));
+    EventSet ev(3 * n);
+    for (auto& e : ev.ev) BC_CHECK_HIP(hipEventCreate(&e));
     std::vector<char> split(n, 0);
     int rc = 0;
     for (size_t i = 0; i < n && !rc; ++i) {
@@ -429,7 +435,6 @@ extern "C" int bc_plan_run_timed_kernels(BcPlan* pl, int seg, bc_stream stream, 
             }
         }
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -498,6 +503,10 @@ extern "C" int bc_plan_load(const char* path, BcPlan** out) {
     FILE* f = fopen(path, "rb");
     BC_CHECK_ARG(f != nullptr, "bc_plan_load: cannot open %s", path);
     Reader rd{f};
+    if (fseek(f, 0, SEEK_END)) { fclose(f); bc_set_error("bc_plan_load(%s): seek failed", path); return 1; }
+    const uint64_t file_bytes = (uint64_t)ftell(f);
+    rewind(f);
+    constexpr uint64_t kMaxArena = 1ull << 40;       // 1 TiB: far above any real plan, far below overflow of the running sum
     BcPlan* pl = new BcPlan();
     auto fail = [&](const char* why) { fclose(f); bc_plan_destroy(pl); bc_set_error("bc_plan_load(%s): %s", path, why); return 1; };
     if (rd.u32() != kMagic) return fail("not a plan file");
@@ -513,9 +522,15 @@ extern "C" int bc_plan_load(const char* path, BcPlan** out) {
         Buf& b = pl->bufs[i];
         b.name = rd.str();
         b.bytes = rd.u64();
+        if (!rd.ok || b.bytes > kMaxArena) return fail("corrupt buffer size");
         b.arena_off = total;
         total += (b.bytes + 255) & ~255ull;
-        if (rd.u32()) { data_pos[i] = ftell(f); if (fseek(f, (long)b.bytes, SEEK_CUR)) return fail("truncated buffer data"); }
+        if (total > kMaxArena) return fail("buffer table larger than any device");
+        if (rd.u32()) {
+            data_pos[i] = ftell(f);
+            if (data_pos[i] < 0 || (uint64_t)data_pos[i] + b.bytes > file_bytes) return fail("buffer data runs past the end of the file");
+            if (fseek(f, (long)b.bytes, SEEK_CUR)) return fail("truncated buffer data");
+        }
         if (!rd.ok) return fail("truncated buffer table");
     }
     if (hipMalloc(&pl->arena, (size_t)std::max<uint64_t>(total, 256)) != hipSuccess) return fail("hipMalloc of the plan arena failed");
@@ -556,7 +571,10 @@ extern "C" int bc_plan_load(const char* path, BcPlan** out) {
         if (!rd.ok || nr > (1u << 22)) return fail("corrupt launch count");
         sg.recs.resize(nr);
         for (Rec& r : sg.recs) {
-            r.op = (int)rd.u32(); r.sid = (int)rd.u32(); r.enabled = (int)rd.u32();
+            const uint32_t op = rd.u32(), sid = rd.u32(), enabled = rd.u32();
+            if (!rd.ok || sid >= (uint32_t)kMaxStreams) return fail("stream id out of range");
+            if (op != (uint32_t)BC_OP_GEMM && !op_signature((int)op)) return fail("unknown op code");
+            r.op = (int)op; r.sid = (int)sid; r.enabled = enabled ? 1 : 0;
             if (r.op == BC_OP_GEMM) {
                 rd.raw(&r.g, sizeof(r.g));
                 for (size_t fo : kGemmPtrFields) {

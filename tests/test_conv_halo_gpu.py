@@ -112,3 +112,21 @@ def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec):
         return fused, plain
     fused, plain = run(rec, fn)
     close(fused, plain, rtol=4e-3, what="fused vs unfused resblock conv")
+
+
+def test_halo_conv_single_source_with_a_wider_pixel_stride(rec):
+    """`lda` is the PIXEL stride of A (blobctrl_hip.h): a single-source halo convolution over the first 128 channels of a
+    192-channel NHWC buffer (lda = 192 > Cin = 128) must read that view, not a packed 128-channel image."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv3x3
+    B, H, W, Cwide, Cin, Cout = 2, 8, 16, 192, 128, 160
+    x, w, b = g(1, B, Cwide, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
+    M = B * H * W
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), lda=Cwide, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
+                                    bias=b.cuda(), conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
+                                    tile_cfg=_lib.TILE_HALO))
+    close(from_nhwc(out, B, H, W), conv_ref(x[:, :Cin], w, b), what="halo conv over a strided single-source view")
+    with pytest.raises(_lib.BlobCtrlHipError):
+        run(rec, lambda: rec.gemm(A=nhwc(x), lda=64, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
+                                  conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
+                                  tile_cfg=_lib.TILE_HALO))

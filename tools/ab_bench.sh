@@ -5,7 +5,7 @@ mkdir -p $OUT
 for rnd in 1 2; do
   i=0
   for e in "$@"; do
-    env $e timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e > $OUT/v${i}_r${rnd}.json 2> $OUT/v${i}_r${rnd}.err
+    env $e timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-configs > $OUT/v${i}_r${rnd}.json 2> $OUT/v${i}_r${rnd}.err
     python3 - "$OUT/v${i}_r${rnd}.json" "$e" <<'PY'
 import json,sys
 try:
