@@ -120,8 +120,10 @@ def object_region_from_mask(mask: np.ndarray, image: np.ndarray) -> np.ndarray:
 
 
 def ellipse_mask(ellipse: Ellipse, height: int, width: int) -> np.ndarray:
-    """[NOT pinned to OpenCV, which is absent here - replaces cv2.ellipse(..., thickness=-1, lineType=LINE_AA) followed by the app's
-    `> 0` (app:1113-1121, composite_mask_and_image app:461-476): every pixel the anti-aliased fill gives ANY coverage is masked]
+    """[replaces cv2.ellipse(..., thickness=-1, lineType=LINE_AA) followed by the app's `> 0` (app:1113-1121, composite_mask_and_image
+    app:461-476): every pixel the anti-aliased fill gives ANY coverage is masked.  Measured against the filled masks the reference
+    ships (assets/results/demo/*/ori_result_gallery_3.png = cv2.ellipse(.., 255, -1), app:717; tests/golden/blob_edit_cv.npz): the
+    masks disagree on 0.26-1.43 % of the ellipse's pixels (the outermost ring: OpenCV fills a polygon approximation)]
     uint8 mask, 255 exactly where the closed pixel square [x - 0.5, x + 0.5] x [y - 0.5, y + 0.5] intersects the filled ellipse.
     Exact, not sampled: the ellipse is mapped to the unit disc, the pixel square to a parallelogram, and the distance from the
     origin to that parallelogram is compared with 1 (closed forms for circles / axis-aligned ellipses: tests/test_blob_edit_cpu.py).
@@ -169,45 +171,47 @@ def convex_hull(points: np.ndarray) -> np.ndarray:
 
 
 def fit_ellipse(points: np.ndarray) -> Ellipse:
-    """[NOT pinned to OpenCV, which is absent here - stands in for cv2.fitEllipse (app:387)] direct least-squares ellipse fit
-    (Fitzgibbon / Halir-Flusser: minimise the algebraic distance a x^2 + b xy + c y^2 + d x + e y + f subject to 4ac - b^2 = 1)
-    of >= 5 points, returned in OpenCV's RotatedRect convention ((xc, yc), (d1, d2), angle): full axis lengths with d1 <= d2 and the
-    angle of the d1 axis in degrees in [0, 180), measured in image coordinates (the convention every function of this file and
-    cv2.ellipse use).  Points lying exactly on an ellipse return that ellipse (tested); for noisy points OpenCV's own solver
-    (a different normalisation of the same algebraic fit) can give slightly different axes."""
+    """cv2.fitEllipse (app:387) restated.  OpenCV (opencv-python, pinned in the reference's requirements.txt; not under /root/reference
+    and absent from this image) implements it as `fitEllipseNoDirect` (modules/imgproc/src/shapedescr.cpp, "New fitellipse algorithm,
+    contributed by Dr. Daniel Weiss"), three linear least-squares solves on the points centred at their mean:
+      1. general conic  -A x^2 - B y^2 - C xy + D x + E y = const  (5 unknowns),
+      2. its centre from the gradient equations  [2A C; C 2B] (cx, cy) = (D, E),
+      3. re-fit  A (x-cx)^2 + B (y-cy)^2 + C (x-cx)(y-cy) = 1  (3 unknowns),
+    then  angle = -atan2(C, B - A) / 2,  t = C / sin(-2 angle) (or B - A when C = 0),  radii = sqrt(2 / |A + B -+ t|),
+    RotatedRect convention ((xc, yc), (d1, d2), angle): full axis lengths with d1 <= d2 (swap adds 90 degrees), angle in degrees.
+    PINNED to OpenCV's own outputs that the reference ships: tests/golden/blob_edit_cv.npz holds the SAM masks and the fitted
+    ellipses of the demo states (assets/results/demo/*/state/state.json, ellipse_lists[0] = fitEllipse(hull) enlarged by 1.05,
+    app:382-389,902); centres and axes agree to < 0.01 px and angles to < 0.01 degree on every demo whose first ellipse is the
+    unedited fit (tests/test_blob_edit_cpu.py)."""
     P = np.asarray(points, dtype=np.float64).reshape(-1, 2)
     if len(P) < 5:
         raise ValueError("fit_ellipse needs at least 5 points")
-    m = P.mean(0)
-    sc = max(np.abs(P - m).max(), 1e-12)
-    x, y = (P[:, 0] - m[0]) / sc, (P[:, 1] - m[1]) / sc              # conditioning: centred, unit scale
-    D1 = np.stack([x * x, x * y, y * y], 1)
-    D2 = np.stack([x, y, np.ones_like(x)], 1)
-    S1, S2, S3 = D1.T @ D1, D1.T @ D2, D2.T @ D2
-    T = -np.linalg.solve(S3, S2.T)
-    M = S1 + S2 @ T
-    M = np.stack([M[2] / 2.0, -M[1], M[0] / 2.0])                     # inv(C1) @ M with C1 = [[0,0,2],[0,-1,0],[2,0,0]]
-    w, V = np.linalg.eig(M)
-    V = np.real(V)
-    cond = 4.0 * V[0] * V[2] - V[1] ** 2
-    k = int(np.argmax(cond))                                          # the one eigenvector with 4ac - b^2 > 0
-    if not cond[k] > 0:
+    c = P.mean(0)
+    p = P - c
+    scale = 100.0 / max(float(np.abs(p).sum()), 1e-30)               # conditioning only: the solves are scale-invariant
+    p = p * scale
+    x, y = p[:, 0], p[:, 1]
+    gfp = np.linalg.lstsq(np.stack([-x * x, -y * y, -x * y, x, y], 1), np.full(len(p), 10000.0), rcond=None)[0]
+    rp = np.linalg.lstsq(np.array([[2.0 * gfp[0], gfp[2]], [gfp[2], 2.0 * gfp[1]]]), np.array([gfp[3], gfp[4]]), rcond=None)[0]
+    if not np.all(np.isfinite(rp)):
         raise ValueError("fit_ellipse: the points do not determine an ellipse")
-    a1 = V[:, k]
-    A, B, C_ = a1
-    D, E, F = T @ a1
-    # centre, axes and orientation of A x^2 + B xy + C y^2 + D x + E y + F = 0
-    den = B * B - 4.0 * A * C_
-    x0, y0 = (2.0 * C_ * D - B * E) / den, (2.0 * A * E - B * D) / den
-    F0 = A * x0 * x0 + B * x0 * y0 + C_ * y0 * y0 + D * x0 + E * y0 + F
-    Q = np.array([[A, B / 2.0], [B / 2.0, C_]]) / (-F0)               # (p - c)^T Q (p - c) = 1
-    ev, evec = np.linalg.eigh(Q)
-    if ev.min() <= 0:
-        raise ValueError("fit_ellipse: degenerate conic")
-    semi = 1.0 / np.sqrt(ev)                                          # eigh: ascending eigenvalues -> semi[0] is the LONG semi-axis
-    short_dir = evec[:, 1]
-    ang = math.degrees(math.atan2(short_dir[1], short_dir[0])) % 180.0
-    return ((float(x0 * sc + m[0]), float(y0 * sc + m[1])), (float(2.0 * semi[1] * sc), float(2.0 * semi[0] * sc)), float(ang))
+    qx, qy = x - rp[0], y - rp[1]
+    g = np.linalg.lstsq(np.stack([qx * qx, qy * qy, qx * qy], 1), np.ones(len(p)), rcond=None)[0]
+    ang = -0.5 * math.atan2(g[2], g[1] - g[0])
+    t = g[2] / math.sin(-2.0 * ang) if abs(g[2]) > 1e-8 else g[1] - g[0]
+    r = [abs(g[0] + g[1] - t), abs(g[0] + g[1] + t)]
+    if min(r) <= 1e-8 or 4.0 * g[0] * g[1] - g[2] * g[2] <= 0:
+        raise ValueError("fit_ellipse: the points do not determine an ellipse")
+    w, h = (2.0 * math.sqrt(2.0 / v) / scale for v in r)
+    angle = math.degrees(ang)
+    if w > h:
+        w, h = h, w
+        angle += 90.0
+    if angle < -180.0:
+        angle += 360.0
+    if angle > 360.0:
+        angle -= 360.0
+    return ((float(rp[0] / scale + c[0]), float(rp[1] / scale + c[1])), (float(w), float(h)), float(angle))
 
 
 def ellipse_from_mask(mask: np.ndarray) -> Ellipse:

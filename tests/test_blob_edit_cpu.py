@@ -125,3 +125,58 @@ def test_fit_ellipse_recovers_exact_ellipses_and_mask_hulls():
     assert sorted(map(tuple, hull)) == [(0.0, 0.0), (0.0, 4.0), (4.0, 0.0), (4.0, 4.0)]
     with pytest.raises(ValueError):
         be.fit_ellipse(np.zeros((4, 2)))
+
+
+def _cv_fixture(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "blob_edit_cv.npz"))
+    out = {}
+    for name in [str(n) for n in z["names"]]:
+        H, W = [int(v) for v in z[f"{name}_shape"]]
+        unpack = lambda k: np.unpackbits(z[f"{name}_{k}"])[: H * W].reshape(H, W).astype(bool)
+        e = z[f"{name}_ellipse0"]
+        out[name] = dict(mask=unpack("mask"), filled=unpack("filled"), ellipse=((e[0], e[1]), (e[2], e[3]), e[4]))
+    return out, float(z["enlarge_factor"])
+
+
+# demos whose first state ellipse is the unedited fit x 1.05 (the others were enlarged further by the app's blob-resize walk or
+# edited before the state was saved: their centre and angle still match, their axes carry another factor)
+FIT_PINNED = ["move_hat", "remove_cow", "replace_knife", "resize_teddy_bear"]
+
+
+def test_ellipse_from_mask_matches_the_opencv_fits_the_reference_ships(golden_dir):
+    """f4 pinned to reference-held OpenCV outputs: SAM mask -> convex hull -> fitEllipse against the ellipses in
+    assets/results/demo/*/state/state.json (cv2.fitEllipse(cv2.convexHull(contours)) x 1.05, app:382-389,902)."""
+    cases, factor = _cv_fixture(golden_dir)
+    for name in FIT_PINNED:
+        (xc, yc), (d1, d2), ang = be.ellipse_from_mask(cases[name]["mask"])
+        (rx, ry), (r1, r2), ra = cases[name]["ellipse"]
+        assert abs(xc - rx) < 0.01 and abs(yc - ry) < 0.01, (name, xc, yc, rx, ry)
+        assert abs(d1 * factor - r1) < 0.01 and abs(d2 * factor - r2) < 0.01, (name, d1 * factor, d2 * factor, r1, r2)
+        assert abs(ang - ra) < 0.01, (name, ang, ra)
+    # enlarged / edited states: same centre and orientation (the fit), other axis factors (measured 1.09 - 1.26, per axis for shrink_dragon)
+    for name in ("enlarge_deer", "remove_shit", "shrink_dragon"):
+        (xc, yc), (d1, d2), ang = be.ellipse_from_mask(cases[name]["mask"])
+        (rx, ry), (r1, r2), ra = cases[name]["ellipse"]
+        assert abs(xc - rx) < 0.01 and abs(yc - ry) < 0.01 and abs(ang - ra) < 0.01, name
+        assert 1.04 < r1 / d1 < 1.3 and 1.04 < r2 / d2 < 1.3, (name, r1 / d1, r2 / d2)
+    # move_cup: the shipped mask image is not the one the state was fitted on (centre 0.25 / 0.41 px off, angle 1.03 degrees across
+    # the 0 / 180 wrap: OpenCV reports 0.83 where the d1 <= d2 normalisation of this mask gives 179.80) - documented, not pinned
+    (xc, yc), (d1, d2), ang = be.ellipse_from_mask(cases["move_cup"]["mask"])
+    (rx, ry), (r1, r2), ra = cases["move_cup"]["ellipse"]
+    assert abs(xc - rx) < 0.5 and abs(yc - ry) < 0.5 and abs(d1 * factor - r1) < 1.0 and abs(d2 * factor - r2) < 1.0
+    assert min(abs(ang - ra), 180.0 - abs(ang - ra)) < 1.5
+
+
+def test_ellipse_mask_against_the_reference_held_cv2_ellipse_fills(golden_dir):
+    """`ellipse_mask` (any-coverage rule) against cv2.ellipse(mask, ellipse, 255, -1) (app:717) as shipped in
+    ori_result_gallery_3.png: disagreement in % of the ellipse's pixels, per case (measured 0.26 - 1.43; bound 1.5)."""
+    cases, _ = _cv_fixture(golden_dir)
+    worst = 0.0
+    for name in FIT_PINNED + ["remove_shit", "move_cup"]:
+        c = cases[name]
+        mine = be.ellipse_mask(c["ellipse"], *c["filled"].shape) > 0
+        pct = 100.0 * float((mine != c["filled"]).sum()) / float(c["filled"].sum())
+        worst = max(worst, pct)
+        assert pct < 1.5, (name, pct)
+    assert worst > 0.0                      # (not the same rasteriser: documented deviation, not bit equality)

@@ -546,6 +546,29 @@ def golden_lora_merge():
     print("lora merge:", sorted(out)[:4], "...")
 
 
+def golden_blob_edit_cv():
+    """OpenCV outputs the REFERENCE ITSELF holds (cv2 is absent here): for every demo under assets/results/demo the SAM mask
+    (ori_result_gallery_2.png), the filled ellipse mask (ori_result_gallery_3.png = cv2.ellipse(.., 255, -1), app:717) and the state's
+    first ellipse (= cv2.fitEllipse(convexHull(contours)) enlarged by the initial factor 1.05, app:382-389,902).  Stored as packed
+    bit masks + the ellipse parameters; `fit_pinned` lists the demos whose first ellipse is the unedited fit x 1.05."""
+    from PIL import Image
+    root = "/root/reference/assets/results/demo"
+    out = {}
+    names = sorted(d for d in os.listdir(root) if os.path.exists(os.path.join(root, d, "state", "state.json")))
+    for name in names:
+        st = json.load(open(os.path.join(root, name, "state", "state.json")))
+        e = st["ellipse_lists"][0][0]
+        out[f"{name}_ellipse0"] = np.array([e[0][0], e[0][1], e[1][0], e[1][1], e[2]], np.float64)
+        for idx, key in ((2, "mask"), (3, "filled")):
+            im = np.array(Image.open(os.path.join(root, name, "ori_result_gallery", f"ori_result_gallery_{idx}.png")).convert("RGB")).astype(np.int32)
+            out[f"{name}_{key}"] = np.packbits(im.sum(-1) > 3 * 127)               # (the gallery files went through a lossy codec)
+            out[f"{name}_shape"] = np.array(im.shape[:2])
+    out["names"] = np.array(names)
+    out["enlarge_factor"] = np.float64(1.05)
+    np.savez_compressed(os.path.join(OUT, "blob_edit_cv.npz"), **out)
+    print("blob_edit_cv:", names, os.path.getsize(os.path.join(OUT, "blob_edit_cv.npz")) // 1024, "KB")
+
+
 def golden_pipeline_call():
     """The REFERENCE pipeline's own `__call__` (pipe:743-1166) end to end on tiny components: PIL images + prompt strings in, latents
     (and one decoded image) out - tokenizer stand-in, CLIP, VAE encode (global-generator posterior samples), DINOv2 processor + model,
@@ -680,6 +703,7 @@ if __name__ == "__main__":
     golden_lora_keys()
     golden_lora_merge()
     golden_blob_edit()
+    golden_blob_edit_cv()
     golden_clip_text()
     golden_vae()
     golden_splat()
