@@ -96,6 +96,8 @@ def test_fifty_step_edit_teacher_forced_at_spread_steps(full, sched, check):
         print(f"{sched} step {i:2d} (t={int(tab.timesteps[i])}, BlobNet {'on' if active else 'off'}, |x| max {np.abs(x_got).max():.1f}): guided eps "
               f"max-abs/scale {rel:.3e} PSNR {psnr(got, ref.numpy()):.1f} dB | latents after the step max-abs/scale {rel_x:.3e} "
               f"PSNR {psnr(x_got, x_ref):.1f} dB", flush=True)
+        # the guided EPS is not the quantity the north star bounds (that is the latent, next line): CFG multiplies the difference of two
+        # fp16 branch outputs by 7.5, so its max-abs error is held to 2e-2 of scale (measured up to 1.03e-2) and its PSNR to 40 dB
         assert psnr(got, ref.numpy()) > 40.0 and rel < 2e-2, (sched, i, rel)
         assert rel_x < 1e-2 and psnr(x_got, x_ref) > 40.0, (sched, i, rel_x)
     print(f"{sched}: worst guided eps {worst_eps:.3e}, worst latents {worst_lat:.3e}, worst scheduler-update error {worst_step:.2e} "

@@ -166,7 +166,7 @@ def test_remove_edit_skips_blobnet():
     ucfg, bcfg = tiny_cfgs()
     ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 3, a["latents"], a["prompt"], a["fg"], a["bg"],
                               a["score"].float(), a["dino"], 7.5, 0.0)
-    assert rel_err(out0.numpy(), ref.numpy()) < 2e-2
+    assert rel_err(out0.numpy(), ref.numpy()) < 1e-2, rel_err(out0.numpy(), ref.numpy())
 
 
 @pytest.mark.parametrize("tag", ["native", "interp"])
@@ -210,7 +210,7 @@ def test_captured_graph_follows_per_call_arguments():
                    latents=a["latents"], blobnet_conditioning_scale=cs).cpu().numpy()
         ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 3, a["latents"], a["prompt"], a["fg"], a["bg"],
                                   a["score"].float(), a["dino"], gs, cs).numpy()
-        assert rel_err(out, ref) < 2e-2, (gs, cs, rel_err(out, ref))
+        assert rel_err(out, ref) < 1e-2, (gs, cs, rel_err(out, ref))
 
 
 @pytest.mark.parametrize("h,w", [(8, 16), (16, 8), (24, 8), (10, 12), (9, 7)])
@@ -230,7 +230,8 @@ def test_non_square_edits_match_oracle(h, w):
     ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 2, a["latents"], a["prompt"], a["fg"], a["bg"],
                               score.float(), a["dino"], 3.0).numpy()
     assert out.shape == (1, 4, h, w)
-    assert rel_err(out, ref) < 2e-2 and psnr(out, ref) > 38.0, f"{h}x{w}: rel {rel_err(out, ref):.3e} psnr {psnr(out, ref):.1f}"
+    print(f"{h}x{w}: rel {rel_err(out, ref):.3e} psnr {psnr(out, ref):.1f}")
+    assert rel_err(out, ref) < 1e-2 and psnr(out, ref) > 40.0, f"{h}x{w}: rel {rel_err(out, ref):.3e} psnr {psnr(out, ref):.1f}"
 
 
 def test_guidance_scale_at_most_one_disables_cfg():
@@ -249,7 +250,7 @@ def test_guidance_scale_at_most_one_disables_cfg():
     assert rel_err(pos_only, one) < 1e-3           # (same arithmetic; the uncond half of the batch holds other data)
     ref = o_pipe.denoise_loop(usd, ucfg, bsd, bcfg, o_sched.DDIMOracle(), 2, a["latents"], a["prompt"], a["fg"], a["bg"],
                               a["score"].float(), a["dino"], 1.0).numpy()
-    assert rel_err(one, ref) < 2e-2 and psnr(one, ref) > 38.0
+    assert rel_err(one, ref) < 1e-2 and psnr(one, ref) > 40.0, (rel_err(one, ref), psnr(one, ref))
 
 
 def test_modules_from_pretrained_round_trip(tmp_path):

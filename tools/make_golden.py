@@ -633,11 +633,34 @@ def golden_pipeline_call():
                                               scheduler=sch, safety_checker=None, dinov2_processor=proc, dinov2=dino,
                                               requires_safety_checker=False)
         pipe.set_progress_bar_config(disable=True)
+        # record what the reference's own front ends hand to its loop (the LOOP-ENTRY tensors): prompt embeddings, image latents in
+        # call order (fg, then bg), DINOv2 feature - so that the GPU test can bound the front ends and the loop separately
+        entry = {"lat": []}
+
+        def tap(fn, key):
+            def wrapped(*a, **k_):
+                r_ = fn(*a, **k_)
+                if key == "lat":
+                    entry["lat"].append(r_.detach().clone())
+                else:
+                    entry[key] = r_
+                return r_
+            return wrapped
+        pipe.encode_prompt = tap(pipe.encode_prompt, "prompt")
+        pipe.encode_latents = tap(pipe.encode_latents, "lat")
+        pipe.encode_image_dinov2 = tap(pipe.encode_image_dinov2, "dino")
         seed, rng_seed = kw.pop("seed"), kw.pop("rng_seed")
         common = dict(fg_image=Image.fromarray(out["fg"]), bg_image=Image.fromarray(out["bg"]), gs_score=gs, height=64, width=64, **kw)
         torch.manual_seed(rng_seed)           # the VAE posterior samples come from the GLOBAL generator (pipe:304)
         r = pipe(generator=torch.Generator().manual_seed(seed), output_type="latent", **common)
         out[f"{name}_latents"] = r.images.numpy()
+        pe, ne = entry["prompt"]
+        out[f"{name}_entry_prompt_embeds"] = pe.numpy()
+        if ne is not None:
+            out[f"{name}_entry_negative_prompt_embeds"] = ne.numpy()
+        out[f"{name}_entry_fg_latents"] = entry["lat"][0][:1].numpy()
+        out[f"{name}_entry_bg_latents"] = entry["lat"][1][:1].numpy()
+        out[f"{name}_entry_dino"] = entry["dino"].numpy()
         if name == "unipc":
             torch.manual_seed(rng_seed)
             r = pipe(generator=torch.Generator().manual_seed(seed), output_type="np", **common)
