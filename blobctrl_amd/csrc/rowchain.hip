@@ -1,0 +1,571 @@
+// Row-chain kernel: the per-token part of a Transformer2D / BasicTransformerBlock as ONE launch per attention boundary.
+//
+// Reference ops (diffusers/src/diffusers/models/): transformers/transformer_2d.py:479-527 (GroupNorm -> proj_in ... proj_out +
+// residual), attention.py:421-541 (norm1 -> attn1 -> +, norm2 -> attn2 -> +, norm3 -> ff -> +), attention_processor.py:2154-2236
+// (to_q / to_k / to_v, to_out), activations.py:113-123 + attention.py:1161-1167 (GEGLU feed-forward); BlobNet's zero-conv
+// (blobctrl/models/blobnet.py:860-864, 921-924, 936-938).  Everything between two attention calls acts on token rows independently,
+// so a workgroup keeps a block of 64 token rows resident and runs the whole chain on it:
+//   BC_CHAIN_IN   x -> GroupNorm affine -> proj_in -> h0 ; LayerNorm1 -> to_q | to_k (row-major) , to_v (written transposed)
+//   BC_CHAIN_MID  attn1 out -> to_out + h0 -> h1 ; LayerNorm2 -> attn2.to_q                                        (UNet only)
+//   BC_CHAIN_OUT  attn out -> to_out + h -> h2 ; LayerNorm3 -> GEGLU feed-forward (hidden in chunks of 128: the [rows x 4C]
+//                 intermediate never exists) + h2 -> h3 ; proj_out + x (+ BlobNet right-half residual) -> out (+ GroupNorm partials)
+//                 [BlobNet: -> zero-conv * conditioning scale -> residual tensor]
+// replacing 14 launches (12 GEMMs, 3 LayerNorms, 1 GroupNorm pass) per UNet block by 3, and the HBM round trips between them.
+//
+// Structure (C = 320, 4 waves = 256 threads, 64 rows per workgroup, v_mfma_f32_16x16x32_f16):
+//   * activations live in LDS as the B operand: X = [K/32][64 rows][32 k] fp16 (64-byte rows, 16-byte chunks XOR-swizzled so that
+//     every ds_read_b128 fragment read is conflict-free); the product is SWAPPED (D^T = W . X^T) so that a lane ends up with 4
+//     consecutive output channels of one token: 8-byte LDS writes into the next GEMM's operand image, row statistics by two
+//     cross-lane adds;
+//   * a wave owns 80 of the 320 output channels for all 64 rows (5 x 4 accumulator tiles), so weights are never shared between
+//     waves: they stream HBM/L2 -> VGPR directly (no LDS, no barrier in any k-loop) from a per-wave stream that the host packs in
+//     exact consumption order - every wave-instruction reads one contiguous KiB - through a register ring that stays R fragments
+//     ahead of the MFMAs ACROSS GEMM boundaries;
+//   * row-major global inputs / outputs go through an LDS staging image S in full 16-byte accesses (640-byte rows coalesced);
+//   * LDS = X (40 KiB) + S (40 KiB; aliases the feed-forward's double-buffered hidden chunk) = 80 KiB: two workgroups per CU.
+#include "bc_common.h"
+
+namespace {
+
+constexpr int RC_C = 320;              // channels
+constexpr int RC_BM = 64;              // rows per workgroup
+constexpr int RC_KS = RC_C / 32;       // k-steps of a K = C GEMM
+constexpr int RC_NT = RC_C / 64;       // 16-channel tiles per wave of an N = C GEMM (4 waves x 5 tiles x 16)
+constexpr int RC_HC = 128;             // feed-forward hidden chunk
+constexpr int RC_NCH = 4 * RC_C / RC_HC;
+constexpr int RC_R = 12;               // weight ring: fragments (1 KiB per wave) in flight ahead of the MFMAs
+constexpr int RC_X_BYTES = RC_KS * 4096;
+constexpr int RC_S_BYTES = RC_BM * RC_C * 2;
+constexpr int RC_LDS = RC_X_BYTES + RC_S_BYTES;
+
+struct RowChainArgs {
+    int kind, M, rows_per_batch;
+    const h16* x;            // IN: block input rows [M][C]; MID / OUT: attention output rows
+    const float* affine;     // IN: GroupNorm affine [B][C][2] or null
+    const h16* res;          // MID / OUT: residual stream before this attention [M][C]
+    const h16* res2;         // OUT: the block's input x (added after proj_out)
+    const h16* r2;           // OUT: BlobNet residual [bmod][rows_per_batch][C] added where pixel x >= r2_xmin, or null
+    int r2_xmin, r2_bmod, out_w;
+    const uint4* wstream;    // [4 waves][fragments in consumption order (+ RC_R of padding)][64 lanes] 16-byte fragments
+    long long wave_frags;    // fragments per wave stream (incl. padding)
+    const float* vec;        // fp32 vectors (biases, LayerNorm affine) in consumption order
+    h16* out0;               // IN: h0 [M][C]; MID: h1; OUT: block output
+    h16* out1;               // IN: q|k [M][2C]; MID: q [M][C]; OUT (BlobNet): zero-conv residual [M][C]
+    h16* out2;               // IN: V^T [B][C][ldvt]
+    int ldvt;
+    float* gn_part;          // OUT: per-channel (sum, sum of squares) of the block output per 64-row slab [B][rpb/64][C][2], or null
+    float ln_eps;
+    float alpha;             // OUT (BlobNet): zero-conv scale
+    const float* alpha_dev;
+    const int* alpha_idx;
+    int alpha_bstride;
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ h16x8 as_h8(uint4 v) { return __builtin_bit_cast(h16x8, v); }
+
+__device__ __forceinline__ void lds_barrier() {
+    // LDS visibility only: the weight ring's global loads stay in flight across it (a __syncthreads() would drain them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ---- weight ring: R fragments ahead of the consumer, static indices only ------------------------------------------------------
+struct WRing {
+    uint4 f[RC_R];
+    const uint4* p;          // this lane's next fragment to LOAD
+};
+
+__device__ __forceinline__ void ring_fill(WRing& r) {
+#pragma unroll
+    for (int i = 0; i < RC_R; ++i) r.f[i] = r.p[i * 64];
+    r.p += RC_R * 64;
+}
+
+// One GEMM segment: acc[t][mt] += W-tile t (16 channels) x rows-tile mt (16 rows) over KS k-steps of 32.
+// POS = ring index of the segment's first fragment (compile time); returns through the template chain: (POS + NT*KS) % R.
+// SWAP: D^T[channel][row] (lane: 4 consecutive channels of one row); !SWAP: D[row][channel] (lane: 4 consecutive rows of one channel).
+template <int NT, int KS, int POS, bool SWAP>
+__device__ __forceinline__ void gemm_seg(f32x4v (&acc)[NT][4], WRing& r, const char* xb) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        h16x8 xf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const h16x8*>(xb + s * 4096 + mt * 1024);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h16x8 w = as_h8(r.f[(POS + s * NT + t) % RC_R]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[t][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[mt], acc[t][mt], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mt], w, acc[t][mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r.f[(POS + s * NT + t) % RC_R] = r.p[t * 64];
+        r.p += NT * 64;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4v (&acc)[NT][4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+}
+
+// ---- LDS images -----------------------------------------------------------------------------------------------------------------
+// X / P operand image: [k-step][row][32 k]: byte offset of the 16-byte chunk kc (0..3) of `row` in k-step s
+__device__ __forceinline__ int x_off(int s, int row, int kc) { return s * 4096 + row * 64 + ((kc ^ ((0 - ((row & 15) >> 2)) & 3)) << 4); }
+// S staging image: [row][320] fp16, 8-byte units XOR-swizzled by ((row >> 1) & 7)
+__device__ __forceinline__ int s_off8(int row, int unit) { return row * (RC_C * 2) + ((unit ^ ((row >> 1) & 7)) << 3); }
+
+__device__ __forceinline__ uint4 swap_halves(uint4 d) { return make_uint4(d.z, d.w, d.x, d.y); }
+
+// ---- coalesced 16-byte copies between global rows and the LDS images ------------------------------------------------------------------
+// Thread (v8 = tid & 7, r5 = tid >> 3) moves the chunks v = v8 + 8 k (k < 5) of the rows r5 + 32 j (j < 2): the swizzles depend on row
+// bits 1..3 only, so every address is a per-thread base plus a compile-time offset (an idx / 40 mapping made the compiler keep twenty
+// 64-bit addresses alive across the whole kernel - spills).
+struct CopyMap {
+    int row, v8, sw;         // sw = (row >> 1) & 7
+    int s_base, x_base;
+};
+
+__device__ __forceinline__ CopyMap copy_map(int tid) {
+    CopyMap c;
+    c.row = tid >> 3;
+    c.v8 = tid & 7;
+    c.sw = (c.row >> 1) & 7;
+    c.s_base = c.row * (RC_C * 2) + ((c.v8 ^ (c.sw >> 1)) << 4);
+    c.x_base = x_off(c.v8 >> 2, c.row, c.v8 & 3);
+    return c;
+}
+
+// global rows [64][C] (ld = C) -> S; rows whose pixel x < xmin are staged as zeros when `masked`
+__device__ __forceinline__ void rows_to_S(const h16* __restrict__ src, char* S, const CopyMap& c, bool masked = false, int pix0 = 0,
+                                          int out_w = 1, int xmin = 0) {
+    const h16* g = src + (size_t)c.row * RC_C + c.v8 * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool zero = masked && ((pix0 + c.row + 32 * j) % out_w) < xmin;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(g + j * 32 * RC_C + k * 64);
+            if (zero) d = make_uint4(0u, 0u, 0u, 0u);
+            if (c.sw & 1) d = swap_halves(d);
+            *reinterpret_cast<uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128) = d;
+        }
+    }
+}
+
+// S -> global rows (row stride ld elements)
+__device__ __forceinline__ void S_to_rows(h16* __restrict__ dst, int ld, const char* S, const CopyMap& c) {
+    h16* g = dst + (size_t)c.row * ld + c.v8 * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128);
+            if (c.sw & 1) d = swap_halves(d);
+            *reinterpret_cast<uint4*>(g + (size_t)j * 32 * ld + k * 64) = d;
+        }
+}
+
+// global rows -> X operand image, optionally through the per-(image, channel) GroupNorm affine y = a x + b
+__device__ __forceinline__ void rows_to_X(const h16* __restrict__ src, char* X, const CopyMap& c, const float* __restrict__ ab) {
+    const h16* g = src + (size_t)c.row * RC_C + c.v8 * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float4 a4[4];
+        if (ab) {
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) a4[j4] = reinterpret_cast<const float4*>(ab + (c.v8 + 8 * k) * 16)[j4];   // (a, b) of 8 channels
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint4 d = *reinterpret_cast<const uint4*>(g + j * 32 * RC_C + k * 64);
+            if (ab) {
+                h16* e = reinterpret_cast<h16*>(&d);
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    e[2 * j4] = (h16)fmaf((float)e[2 * j4], a4[j4].x, a4[j4].y);
+                    e[2 * j4 + 1] = (h16)fmaf((float)e[2 * j4 + 1], a4[j4].z, a4[j4].w);
+                }
+            }
+            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * 32 * 64) = d;
+        }
+    }
+}
+
+// S -> X (the block output as the zero-conv's operand)
+__device__ __forceinline__ void S_to_X(const char* S, char* X, const CopyMap& c) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128);
+            if (c.sw & 1) d = swap_halves(d);
+            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * 32 * 64) = d;
+        }
+}
+
+__device__ __forceinline__ h16x4 pack4(const float (&v)[4]) { return (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]}; }
+
+// ---- epilogues on the swapped accumulator layout: acc[t][mt][r] = (channel 80w + 16t + 4q + r, row 16mt + m) ----------------------
+// acc += bias (+ the fp16 rows staged in S when RES)
+template <bool RES>
+__device__ __forceinline__ void epi_bias_res(f32x4v (&acc)[RC_NT][4], const float* __restrict__ bias, const char* S, int wave, int m, int q) {
+#pragma unroll
+    for (int t = 0; t < RC_NT; ++t) {
+        const int c0 = 80 * wave + 16 * t + 4 * q;
+        const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            acc[t][mt][0] += b.x; acc[t][mt][1] += b.y; acc[t][mt][2] += b.z; acc[t][mt][3] += b.w;
+            if (RES) {
+                const h16x4 rr = *reinterpret_cast<const h16x4*>(S + s_off8(16 * mt + m, c0 >> 2));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][mt][r] += (float)rr[r];
+            }
+        }
+    }
+}
+
+// acc (scaled) -> fp16 -> S
+__device__ __forceinline__ void acc_to_S(const f32x4v (&acc)[RC_NT][4], char* S, int wave, int m, int q, float scale = 1.0f) {
+#pragma unroll
+    for (int t = 0; t < RC_NT; ++t) {
+        const int c0 = 80 * wave + 16 * t + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float v[4] = {acc[t][mt][0] * scale, acc[t][mt][1] * scale, acc[t][mt][2] * scale, acc[t][mt][3] * scale};
+            *reinterpret_cast<h16x4*>(S + s_off8(16 * mt + m, c0 >> 2)) = pack4(v);
+        }
+    }
+}
+
+// acc -> fp16 -> X operand image
+__device__ __forceinline__ void acc_to_X(const f32x4v (&acc)[RC_NT][4], char* X, int wave, int m, int q) {
+#pragma unroll
+    for (int t = 0; t < RC_NT; ++t) {
+        const int c0 = 80 * wave + 16 * t + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+            *reinterpret_cast<h16x4*>(X + x_off(c0 >> 5, 16 * mt + m, (c0 & 31) >> 3) + ((c0 >> 2) & 1) * 8) = pack4(v);
+        }
+    }
+}
+
+// LayerNorm over the 320 channels of every row (two passes, fp32), written as the next GEMM's operand image.  `gb` = gamma | beta.
+// Statistics cross the four waves through the head of X, which is free between the barriers below.
+__device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], const float* __restrict__ gb, float eps, char* X, int wave,
+                                               int m, int q) {
+    float* st = reinterpret_cast<float*>(X);                       // [2][64 rows][4 waves]
+    float mean[4], rstd[4];
+    lds_barrier();                                                  // every wave has left the k-loop that read X
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < RC_NT; ++t) s += (acc[t][mt][0] + acc[t][mt][1]) + (acc[t][mt][2] + acc[t][mt][3]);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0) st[(16 * mt + m) * 4 + wave] = s;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float4 v = *reinterpret_cast<const float4*>(st + (16 * mt + m) * 4);
+        mean[mt] = ((v.x + v.y) + (v.z + v.w)) * (1.0f / RC_C);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < RC_NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[t][mt][r] - mean[mt];
+                s = fmaf(d, d, s);
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0) st[256 + (16 * mt + m) * 4 + wave] = s;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const float4 v = *reinterpret_cast<const float4*>(st + 256 + (16 * mt + m) * 4);
+        rstd[mt] = __builtin_amdgcn_rsqf(((v.x + v.y) + (v.z + v.w)) * (1.0f / RC_C) + eps);
+    }
+    lds_barrier();                                                  // statistics consumed: X may be overwritten
+#pragma unroll
+    for (int t = 0; t < RC_NT; ++t) {
+        const int c0 = 80 * wave + 16 * t + 4 * q;
+        const float4 g = *reinterpret_cast<const float4*>(gb + c0);
+        const float4 b = *reinterpret_cast<const float4*>(gb + RC_C + c0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float v[4] = {fmaf((acc[t][mt][0] - mean[mt]) * rstd[mt], g.x, b.x), fmaf((acc[t][mt][1] - mean[mt]) * rstd[mt], g.y, b.y),
+                                fmaf((acc[t][mt][2] - mean[mt]) * rstd[mt], g.z, b.z), fmaf((acc[t][mt][3] - mean[mt]) * rstd[mt], g.w, b.w)};
+            *reinterpret_cast<h16x4*>(X + x_off(c0 >> 5, 16 * mt + m, (c0 & 31) >> 3) + ((c0 >> 2) & 1) * 8) = pack4(v);
+        }
+    }
+}
+
+// per-channel (sum, sum of squares) of the fp16 rows in S over the 64 rows: the consumer's GroupNorm statistics
+__device__ __forceinline__ void gn_partials_from_S(const char* S, float* __restrict__ dst, int tid) {
+    if (tid < RC_C / 2) {
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        const int unit = tid >> 1, half = tid & 1;
+#pragma unroll 8
+        for (int row = 0; row < RC_BM; ++row) {
+            const h16x2 v = *reinterpret_cast<const h16x2*>(S + s_off8(row, unit) + half * 4);
+            const float a = (float)v[0], b = (float)v[1];
+            s0 += a; q0 = fmaf(a, a, q0);
+            s1 += b; q1 = fmaf(b, b, q1);
+        }
+        *reinterpret_cast<float4*>(dst + 4 * tid) = make_float4(s0, q0, s1, q1);
+    }
+}
+
+template <int KIND, bool BLOB>
+__global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* X = smem;
+    char* S = smem + RC_X_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int m0 = bc_xcd_remap(blockIdx.x, gridDim.x) * RC_BM;
+    const int b = m0 / a.rows_per_batch;
+    const int pix0 = m0 - b * a.rows_per_batch;
+    const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);        // this lane's fragment offset inside a (k-step, row-tile) KiB
+    const float* vec = a.vec;
+    const CopyMap cm = copy_map(tid);
+
+    WRing ring;
+    ring.p = a.wstream + (size_t)wave * a.wave_frags * 64 + lane;
+    ring_fill(ring);
+
+    f32x4v acc[RC_NT][4];
+    zero_acc(acc);
+
+    if (KIND == BC_CHAIN_IN) {
+        rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, a.affine ? a.affine + (size_t)b * RC_C * 2 : nullptr);
+        lds_barrier();
+        // proj_in -> h0
+        gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);
+        epi_bias_res<false>(acc, vec, S, wave, m, q);
+        layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        acc_to_S(acc, S, wave, m, q);
+        lds_barrier();                                                  // X = LN1(h0), S = h0
+        S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
+        // to_q | to_k: two passes of 320 columns
+        zero_acc(acc);
+        gemm_seg<RC_NT, RC_KS, (RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
+        lds_barrier();                                                  // S has been copied out by every thread
+        acc_to_S(acc, S, wave, m, q);
+        lds_barrier();
+        S_to_rows(a.out1 + (size_t)m0 * 2 * RC_C, 2 * RC_C, S, cm);
+        zero_acc(acc);
+        gemm_seg<RC_NT, RC_KS, (2 * RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
+        lds_barrier();
+        acc_to_S(acc, S, wave, m, q);
+        lds_barrier();
+        S_to_rows(a.out1 + (size_t)m0 * 2 * RC_C + RC_C, 2 * RC_C, S, cm);
+        // to_v, written transposed: D[row][channel] (lane: 4 consecutive rows of one channel) -> S^T [channel][64 rows]
+        zero_acc(acc);
+        gemm_seg<RC_NT, RC_KS, (3 * RC_NT * RC_KS) % RC_R, false>(acc, ring, X + xfo);
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < RC_NT; ++t) {
+            const int ch = 80 * wave + 16 * t + m;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+                *reinterpret_cast<h16x4*>(S + ch * 128 + (((4 * mt + q) ^ (ch & 15)) << 3)) = pack4(v);
+            }
+        }
+        lds_barrier();
+        {
+            const int ch0 = tid >> 3, part = tid & 7, sw = ch0 & 15;
+            h16* vt = a.out2 + ((size_t)b * RC_C + ch0) * a.ldvt + pix0 + part * 8;
+            const char* sp = S + ch0 * 128 + ((part ^ (sw >> 1)) << 4);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {                             // channels ch0 + 32 i: the swizzle (ch & 15) keeps its low 4 bits
+                uint4 d = *reinterpret_cast<const uint4*>(sp + i * 32 * 128);
+                if (sw & 1) d = swap_halves(d);
+                *reinterpret_cast<uint4*>(vt + (size_t)i * 32 * a.ldvt) = d;
+            }
+        }
+        return;
+    }
+
+    // MID / OUT: X = attention output rows, S = the residual stream
+    rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
+    rows_to_S(a.res + (size_t)m0 * RC_C, S, cm);
+    lds_barrier();
+    gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);               // attn.to_out
+    epi_bias_res<true>(acc, vec, S, wave, m, q);                        // + bias + residual (own columns only: no barrier needed)
+
+    if (KIND == BC_CHAIN_MID) {
+        layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        acc_to_S(acc, S, wave, m, q);
+        lds_barrier();
+        S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);           // h1
+        zero_acc(acc);
+        gemm_seg<RC_NT, RC_KS, (RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);   // attn2.to_q
+        lds_barrier();
+        acc_to_S(acc, S, wave, m, q);
+        lds_barrier();
+        S_to_rows(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        return;
+    }
+
+    // ---- OUT: LayerNorm3 -> GEGLU feed-forward accumulated ON TOP of h2 (acc keeps the residual in fp32) ----
+    layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+    lds_barrier();
+    {
+        const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][v0 v1 g0 g1][16]
+        constexpr int POS_FF = (RC_NT * RC_KS) % RC_R;
+        static_assert((4 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0, "a feed-forward chunk must consume a whole number of rings");
+        for (int c = 0; c < RC_NCH; ++c) {
+            char* P = S + (c & 1) * 16384;
+            f32x4v a1[4][4];
+            zero_acc(a1);
+            gemm_seg<4, RC_KS, POS_FF, true>(a1, ring, X + xfo);
+            const float* bb = b1 + (c * 4 + wave) * 64 + 4 * q;
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const float4 bv = *reinterpret_cast<const float4*>(bb + tp * 16);
+                const float4 bg = *reinterpret_cast<const float4*>(bb + (2 + tp) * 16);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float v[4] = {(a1[tp][mt][0] + bv.x) * bc_gelu_f(a1[2 + tp][mt][0] + bg.x), (a1[tp][mt][1] + bv.y) * bc_gelu_f(a1[2 + tp][mt][1] + bg.y),
+                                        (a1[tp][mt][2] + bv.z) * bc_gelu_f(a1[2 + tp][mt][2] + bg.z), (a1[tp][mt][3] + bv.w) * bc_gelu_f(a1[2 + tp][mt][3] + bg.w)};
+                    // hidden unit (inside the chunk) 32 wave + 16 tp + 4 q + r: k-step `wave`, chunk 2 tp + (q >> 1), half q & 1
+                    *reinterpret_cast<h16x4*>(P + x_off(wave, 16 * mt + m, 2 * tp + (q >> 1)) + (q & 1) * 8) = pack4(v);
+                }
+            }
+            lds_barrier();                                              // the chunk's 128 hidden columns are complete
+            gemm_seg<RC_NT, RC_HC / 32, (POS_FF + 4 * RC_KS) % RC_R, true>(acc, ring, P + xfo);
+        }
+    }
+    // (lane-derived values are laundered here: without it hipcc keeps the LDS addresses of the epilogues before and after the
+    //  feed-forward loop alive ACROSS it - common subexpressions - and spills two dozen registers around the loop)
+    int m_ = m, q_ = q, xfo_ = xfo;
+    CopyMap cm_ = cm;
+    asm volatile("" : "+v"(m_), "+v"(q_), "+v"(xfo_), "+v"(cm_.row), "+v"(cm_.v8), "+v"(cm_.sw), "+v"(cm_.s_base), "+v"(cm_.x_base));
+#define m m_
+#define q q_
+#define xfo xfo_
+#define cm cm_
+    epi_bias_res<false>(acc, vec + 3 * RC_C + 8 * RC_C, S, wave, m, q);  // + ff.net.2 bias -> h3
+    lds_barrier();                                                      // every wave is done with the last hidden chunk (S) and with X
+    acc_to_X(acc, X, wave, m, q);
+    rows_to_S(a.res2 + (size_t)m0 * RC_C, S, cm);
+    lds_barrier();
+    zero_acc(acc);
+    constexpr int POS_PO = (RC_NT * RC_KS) % RC_R;                      // (the feed-forward consumed whole rings)
+    gemm_seg<RC_NT, RC_KS, POS_PO, true>(acc, ring, X + xfo);          // proj_out
+    const float* bpo = vec + 3 * RC_C + 8 * RC_C + RC_C;
+    epi_bias_res<true>(acc, bpo, S, wave, m, q);                        // + bias + x
+    if (a.r2) {                                                          // + BlobNet residual on the right-hand part of the canvas
+        const bool any = ((pix0 % a.out_w) + RC_BM > a.r2_xmin) || (pix0 % a.out_w) + RC_BM > a.out_w;
+        if (any) {                                                       // (workgroup-uniform)
+            lds_barrier();
+            rows_to_S(a.r2 + ((size_t)(b % a.r2_bmod) * a.rows_per_batch + pix0) * RC_C, S, cm, true, pix0, a.out_w, a.r2_xmin);
+            lds_barrier();
+            epi_bias_res<true>(acc, nullptr, S, wave, m, q);
+        }
+    }
+    lds_barrier();
+    acc_to_S(acc, S, wave, m, q);
+    lds_barrier();
+    S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
+    if (a.gn_part)
+        gn_partials_from_S(S, a.gn_part + ((size_t)b * (a.rows_per_batch / RC_BM) + pix0 / RC_BM) * RC_C * 2, tid);
+    if (BLOB) {
+        // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
+        S_to_X(S, X, cm);
+        lds_barrier();
+        zero_acc(acc);
+        gemm_seg<RC_NT, RC_KS, (POS_PO + RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
+        epi_bias_res<false>(acc, bpo + RC_C, S, wave, m, q);
+        float alpha = a.alpha;
+        if (a.alpha_dev) alpha *= a.alpha_dev[(a.alpha_idx ? *a.alpha_idx : 0) * (a.alpha_bstride > 0 ? a.alpha_bstride : 1) + (a.alpha_bstride > 0 ? b : 0)];
+        lds_barrier();                                                  // S (block output) copied out and transposed into X by everyone
+        acc_to_S(acc, S, wave, m, q, alpha);
+        lds_barrier();
+        S_to_rows(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+    }
+#undef m
+#undef q
+#undef xfo
+#undef cm
+}
+
+template <int KIND, bool BLOB>
+int launch_chain(const RowChainArgs& a, hipStream_t stream) {
+    static std::atomic<unsigned long long> lds_set{0};
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<KIND, BLOB>), RC_LDS));
+    hipLaunchKernelGGL((rowchain_kernel<KIND, BLOB>), dim3(a.M / RC_BM), dim3(256), RC_LDS, stream, a);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bc_rowchain_supported(int channels, int M, int rows_per_batch) {
+    return channels == RC_C && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0 && rows_per_batch % RC_BM == 0;
+}
+
+extern "C" long long bc_rowchain_stream_frags(int kind, int blobnet) {
+    // fragments (1 KiB per wave-instruction) of ONE wave's weight stream, incl. the ring's worth of padding at the end
+    const long long g = RC_NT * RC_KS;
+    long long n = 0;
+    if (kind == BC_CHAIN_IN) n = 4 * g;
+    else if (kind == BC_CHAIN_MID) n = 2 * g;
+    else if (kind == BC_CHAIN_OUT) n = 2 * g + RC_NCH * (4 * RC_KS + RC_NT * (RC_HC / 32)) + (blobnet ? g : 0);
+    else return -1;
+    return n + RC_R;
+}
+
+extern "C" int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+                           const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
+                           const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
+                           float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream) {
+    BC_CHECK_ARG(bc_rowchain_supported(RC_C, M, rows_per_batch), "bc_rowchain: needs M %% rows_per_batch == 0 and rows_per_batch %% %d == 0 "
+                 "(M=%d rows_per_batch=%d)", RC_BM, M, rows_per_batch);
+    BC_CHECK_ARG(x && wstream && vec && out0, "bc_rowchain: null pointer");
+    const bool blob = kind == BC_CHAIN_OUT && out1 != nullptr;
+    RowChainArgs a;
+    a.kind = kind; a.M = M; a.rows_per_batch = rows_per_batch;
+    a.x = reinterpret_cast<const h16*>(x); a.affine = affine;
+    a.res = reinterpret_cast<const h16*>(res); a.res2 = reinterpret_cast<const h16*>(res2);
+    a.r2 = reinterpret_cast<const h16*>(r2); a.r2_xmin = r2_xmin; a.r2_bmod = r2_bmod > 0 ? r2_bmod : 1; a.out_w = out_w > 0 ? out_w : 1;
+    a.wstream = reinterpret_cast<const uint4*>(wstream);
+    a.wave_frags = bc_rowchain_stream_frags(kind, blob ? 1 : 0);
+    a.vec = vec;
+    a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1); a.out2 = reinterpret_cast<h16*>(out2);
+    a.ldvt = ldvt; a.gn_part = gn_part; a.ln_eps = ln_eps;
+    a.alpha = alpha; a.alpha_dev = alpha_dev; a.alpha_idx = alpha_idx; a.alpha_bstride = alpha_bstride;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (kind) {
+        case BC_CHAIN_IN:
+            BC_CHECK_ARG(out1 && out2 && ldvt >= rows_per_batch && ldvt % 8 == 0, "bc_rowchain(IN): needs out1 (q|k), out2 (V^T) and ldvt >= rows_per_batch, ldvt %% 8 == 0");
+            return launch_chain<BC_CHAIN_IN, false>(a, s);
+        case BC_CHAIN_MID:
+            BC_CHECK_ARG(res && out1, "bc_rowchain(MID): needs res and out1");
+            return launch_chain<BC_CHAIN_MID, false>(a, s);
+        case BC_CHAIN_OUT:
+            BC_CHECK_ARG(res && res2, "bc_rowchain(OUT): needs res and res2");
+            BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT): r2 needs out_w dividing rows_per_batch");
+            return blob ? launch_chain<BC_CHAIN_OUT, true>(a, s) : launch_chain<BC_CHAIN_OUT, false>(a, s);
+        default:
+            BC_CHECK_ARG(false, "bc_rowchain: unknown kind %d", kind);
+    }
+    return 1;
+}

@@ -156,11 +156,72 @@ class TrunkPlan:
             sc = x
         return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2)
 
-    def transformer(self, p, x: Act, r2=None):
-        """transformer_2d.py:479-527 + attention.py:421-541 (one BasicTransformerBlock)."""
+    def rowchain_ok(self, Cc, M, HW):
+        """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 channels, 64-row blocks inside one image."""
+        return not os.environ.get("BC_NO_ROWCHAIN") and bool(self.rec.lib.bc_rowchain_supported(Cc, M, HW))
+
+    def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
+        """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
+        LayerNorm -> q | k | V^T ; attention ; [to_out + residual -> LayerNorm -> attn2.to_q ; cross-attention ;] to_out + residual ->
+        LayerNorm -> GEGLU feed-forward -> proj_out + x (+ BlobNet residual) [-> zero-conv].  `zero` = (name, alpha, alpha_dev,
+        alpha_idx, alpha_bstride): BlobNet's zero-conv of the block output, returned as second value."""
+        from .weights import pack_rowchain
         rec, pw, B = self.rec, self.pw, self.B
         Cc, HW = x.C, x.H * x.W
         M = B * HW
+        d = Cc // self.heads
+        scale = d ** -0.5
+        bp = p + "transformer_blocks.0."
+        cache = pw.__dict__.setdefault("_rowchain", {})
+
+        def packed(kind, zname=None):
+            key = (p, kind, zname)
+            if key not in cache:
+                cache[key] = pack_rowchain(pw, p, kind, zname)
+            return cache[key]
+        ab = rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"])
+        h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
+        ldvt = (HW + 63) // 64 * 64
+        vt = rec.zeros(B, Cc, ldvt)
+        w, v = packed(_lib.CHAIN_IN)
+        rec.rowchain(_lib.CHAIN_IN, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, affine=ab)
+        a = rec.empty(M, Cc)
+        rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
+                      scale, q_off=0, k_off=Cc)
+        h = h0
+        if pw.has_cross:
+            h1, q2 = rec.empty(M, Cc), rec.empty(M, Cc)
+            w, v = packed(_lib.CHAIN_MID)
+            rec.rowchain(_lib.CHAIN_MID, M, HW, a, w, v, h1, out1=q2, res=h0)
+            ck, cvt, T, ldc_vt = self.ctx_kv[bp]
+            a = rec.empty(M, Cc)
+            rec.attention(q2, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
+            h = h1
+        out = rec.empty(M, Cc)
+        nslab = HW // 64
+        part = rec.empty(B, nslab, Cc, 2, dtype=torch.float32)
+        kw = {}
+        r2kw = self._r2(r2, x.H, x.W)                      # (records the wait for the BlobNet branch's residual)
+        if r2kw:
+            assert r2kw["ldr2"] == Cc
+            kw.update(r2=r2kw["R2"], r2_xmin=r2kw["r2_xmin"], r2_bmod=r2kw["r2_bmod"], out_w=r2kw["out_w"])
+        res_out = None
+        if zero is not None:
+            zname, alpha, alpha_dev, alpha_idx, alpha_bstride = zero
+            res_out = rec.empty(M, Cc)
+            kw.update(out1=res_out, alpha=alpha, alpha_dev=alpha_dev, alpha_idx=alpha_idx, alpha_bstride=alpha_bstride)
+        w, v = packed(_lib.CHAIN_OUT, zero[0] if zero is not None else None)
+        rec.rowchain(_lib.CHAIN_OUT, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
+        rec.parts[out.data_ptr()] = (part, nslab)
+        return Act(out, Cc, x.H, x.W), res_out
+
+    def transformer(self, p, x: Act, r2=None, zero=None):
+        """transformer_2d.py:479-527 + attention.py:421-541 (one BasicTransformerBlock).  Returns (output, zero-conv residual or None)."""
+        rec, pw, B = self.rec, self.pw, self.B
+        Cc, HW = x.C, x.H * x.W
+        M = B * HW
+        if self.rowchain_ok(Cc, M, HW):
+            return self.transformer_rowchain(p, x, r2, zero)
         d = Cc // self.heads
         scale = d ** -0.5
         bp = p + "transformer_blocks.0."
@@ -193,7 +254,7 @@ class TrunkPlan:
         # --- proj_out + residual (+ BlobNet residual)
         out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True,
                          **self._r2(r2, x.H, x.W))
-        return Act(out, Cc, x.H, x.W)
+        return Act(out, Cc, x.H, x.W), None
 
     # ------------------------------------------------------------------------------------------- prologue
     def record_context(self, ctx: torch.Tensor, T: int):
@@ -278,14 +339,23 @@ class TrunkPlan:
                 super().__init__()
                 s2.prefix, s2.res = prefix, []
 
-            def append(s2, f):
+            def next_zero(s2):
+                """(name, scale arguments) of the zero-conv that the NEXT appended feature goes through (BlobNet), else None."""
+                if not cfg.is_blobnet:
+                    return None
+                name = s2.prefix if s2.prefix.endswith("mid_block") else f"{s2.prefix}.{len(s2)}"
+                return (name, alpha, alpha_dev, alpha_idx, alpha_bstride)
+
+            def append(s2, f, pre=None):
+                """`pre`: the residual already produced by the fused row-chain (zero-conv inside the block's last launch)."""
                 super().append(f)
                 if cfg.is_blobnet:
                     name = s2.prefix if s2.prefix.endswith("mid_block") else f"{s2.prefix}.{len(s2) - 1}"
                     M = self.B * f.H * f.W
-                    r = self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
-                                   alpha_idx=alpha_idx, alpha_bstride=alpha_bstride,
-                                   rows_per_batch=f.H * f.W).view(self.B, f.H * f.W, f.C)
+                    r = pre if pre is not None else \
+                        self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
+                                   alpha_idx=alpha_idx, alpha_bstride=alpha_bstride, rows_per_batch=f.H * f.W)
+                    r = r.view(self.B, f.H * f.W, f.C)
                     if out_events is not None:
                         ev = self.rec.new_event()
                         self.rec.signal(ev)
@@ -313,10 +383,11 @@ class TrunkPlan:
             for j in range(cfg.layers_per_block):
                 r = pop(res_d)
                 h = self.resnet(f"down_blocks.{i}.resnets.{j}.", h, None, boc[i], r2=None if has_attn else r)
+                pre = None
                 if has_attn:
-                    h = self.transformer(f"down_blocks.{i}.attentions.{j}.", h, r2=r)
+                    h, pre = self.transformer(f"down_blocks.{i}.attentions.{j}.", h, r2=r, zero=feats_d.next_zero())
                 skips.append(h)
-                feats_d.append(h)
+                feats_d.append(h, pre)
             if i < nb - 1:
                 h = self.conv3x3(h, f"down_blocks.{i}.downsamplers.0.conv", boc[i], stride=2, r2=pop(res_d),
                                  kind="downsample")
@@ -324,7 +395,7 @@ class TrunkPlan:
                 feats_d.append(h)
         # mid (unet_2d_blocks.py:860-899) ; residual after the block (unet_2d_condition.py:1292-1296)
         h = self.resnet("mid_block.resnets.0.", h, None, boc[-1])
-        h = self.transformer("mid_block.attentions.0.", h)
+        h, _ = self.transformer("mid_block.attentions.0.", h)
         h = self.resnet("mid_block.resnets.1.", h, None, boc[-1], r2=residuals.mid if residuals is not None else None)
         feat_mid = h
         feats_m.append(h)
@@ -338,9 +409,10 @@ class TrunkPlan:
                 r = pop(res_u)
                 sk = res.pop()
                 h = self.resnet(f"up_blocks.{i}.resnets.{j}.", h, sk, rev[i], r2=None if has_attn else r)
+                pre = None
                 if has_attn:
-                    h = self.transformer(f"up_blocks.{i}.attentions.{j}.", h, r2=r)
-                feats_u.append(h)
+                    h, pre = self.transformer(f"up_blocks.{i}.attentions.{j}.", h, r2=r, zero=feats_u.next_zero())
+                feats_u.append(h, pre)
             if i < nb - 1:
                 size = (skips[-1].H, skips[-1].W)
                 h = self.conv3x3(h, f"up_blocks.{i}.upsamplers.0.conv", rev[i], up_to=size, r2=pop(res_u),

@@ -236,6 +236,31 @@ int bc_silu(const bc_half* x, bc_half* y, long long n, bc_stream stream);
 int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, int* step_idx, float* hist,
                           float guidance_scale, int B, int h, int w, float* eps_out, int advance, bc_stream stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row-chain: everything of a Transformer2D block that acts on token rows independently, as ONE launch per attention
+ * boundary (csrc/rowchain.hip).  Replaces, for 320-channel blocks (the 64 x 128 level of SD-1.5), the call sites
+ *   diffusers/src/diffusers/models/transformers/transformer_2d.py:479-527 (norm -> proj_in ... proj_out + residual),
+ *   attention.py:421-541 (norm1/2/3, attn to_q / to_k / to_v / to_out, residual adds), activations.py:113-123 and
+ *   attention.py:1161-1167 (GEGLU feed-forward), blobctrl/models/blobnet.py:860-864,921-924,936-938 (zero-conv x scale):
+ *   BC_CHAIN_IN   x [M][C] --(GroupNorm affine [B][C][2] or NULL)--> proj_in -> out0 = h0 [M][C]; LayerNorm ->
+ *                 out1 = q|k [M][2C] (row-major), out2 = V^T [B][C][ldvt]
+ *   BC_CHAIN_MID  x = attention output, res = h0: to_out + res -> out0 = h1; LayerNorm -> out1 = attn2.to_q [M][C]
+ *   BC_CHAIN_OUT  x = attention output, res = residual stream, res2 = the block's input: to_out + res -> LayerNorm ->
+ *                 GEGLU feed-forward + residual -> proj_out + res2 (+ r2: BlobNet residual [r2_bmod][rows_per_batch][C] where
+ *                 pixel x = (row % out_w) >= r2_xmin) -> out0 [M][C] and gn_part [B][rows_per_batch/64][C][2] (per-channel sum,
+ *                 sum of squares of the fp16 output per 64-row slab; NULL: none).  With out1 != NULL (BlobNet) the block
+ *                 output also goes through the zero-conv: out1 = (W out0 + b) * alpha * alpha_dev[*alpha_idx (* bstride + image)].
+ * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
+ * consumption order; bc_rowchain_stream_frags gives the length).  M % rows_per_batch == 0, rows_per_batch % 64 == 0.
+ * --------------------------------------------------------------------------------------------------------------- */
+enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2 };
+int bc_rowchain_supported(int channels, int M, int rows_per_batch);
+long long bc_rowchain_stream_frags(int kind, int blobnet);
+int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+                const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
+                const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
+                float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream);
+
 /* Layout helpers at the nn.Module boundary (NCHW <-> token-major NHWC, fp32/fp16). */
 int bc_nchw_to_nhwc_f16(const void* src, int src_is_f32, int B, int C, int HW, int Cpad, bc_half* dst, bc_stream stream);
 int bc_nhwc_to_nchw(const bc_half* src, int B, int C, int HW, int ldsrc, void* dst, int dst_is_f32, bc_stream stream);
@@ -285,7 +310,8 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_ATTENTION = 6, BC_OP_ATTENTION_CAUSAL = 7, BC_OP_ASSEMBLE_INPUT = 8, BC_OP_TIMESTEP_EMBEDDING = 9,
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
-       BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_COUNT = 22 };
+       BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22,
+       BC_OP_COUNT = 23 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

@@ -76,16 +76,23 @@ def test_resnet_block(z, name, split):
     _check(name + ("(hidden|skip)" if split else ""), _nchw(out, p["B"]), z[name])
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["tfm_320_cross", "tfm_320_self_only"])
-def test_transformer_block(z, name):
+def test_transformer_block(z, name, fused, monkeypatch):
+    """Both forms of the 320-channel block against the reference's Transformer2DModel: the fused row-chain launches
+    (csrc/rowchain.hip: 2 / 3 launches + attention) and the unfused GEMM / LayerNorm list (BC_NO_ROWCHAIN=1)."""
+    if not fused:
+        monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
     _, p = BLOCK_CASES[name]
     x, _, ctx = block_inputs(name)
     rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"], heads=p["heads"], cross=p["ctx"])
     if ctx is not None:
         plan.record_context(ctx.reshape(-1, p["ctx"]).half().cuda(), ctx.shape[1])
-    out = plan.transformer("blk.", _act(x))
+    out, _ = plan.transformer("blk.", _act(x))
+    kinds = rec.seg.kinds
+    assert ("rowchain" in kinds) == fused, kinds
     _run(seg)
-    _check(name, _nchw(out, p["B"]), z[name])
+    _check(name + (" (row-chain)" if fused else " (unfused)"), _nchw(out, p["B"]), z[name])
 
 
 @pytest.mark.parametrize("name", ["up_scale2", "up_explicit_size", "down"])
