@@ -23,6 +23,8 @@
 //     ahead of the MFMAs ACROSS GEMM boundaries;
 //   * row-major global inputs / outputs go through an LDS staging image S in full 16-byte accesses (640-byte rows coalesced);
 //   * LDS = X (40 KiB) + S (40 KiB; aliases the feed-forward's double-buffered hidden chunk) = 80 KiB: two workgroups per CU.
+#include <stdlib.h>
+#include <vector>
 #include "bc_common.h"
 
 namespace {
@@ -33,7 +35,10 @@ constexpr int RC_KS = RC_C / 32;       // k-steps of a K = C GEMM
 constexpr int RC_NT = RC_C / 64;       // 16-channel tiles per wave of an N = C GEMM (4 waves x 5 tiles x 16)
 constexpr int RC_HC = 128;             // feed-forward hidden chunk
 constexpr int RC_NCH = 4 * RC_C / RC_HC;
-constexpr int RC_R = 12;               // weight ring: fragments (1 KiB per wave) in flight ahead of the MFMAs
+constexpr int RC_RPAD = 20;            // padding fragments at the end of every wave's stream (>= the deepest ring)
+// weight ring depth R (template parameter): 16 for IN / MID, 15 for OUT (a feed-forward chunk must consume a whole number of rings):
+constexpr int RC_R_UNUSED = 20;        // weight ring: fragments (1 KiB per wave) in flight ahead of the MFMAs (80 KiB per CU:
+                                       // at ~1 us of L2 / HBM latency that is what the per-CU fetch rate of ~70 GB/s needs in flight)
 constexpr int RC_X_BYTES = RC_KS * 4096;
 constexpr int RC_S_BYTES = RC_BM * RC_C * 2;
 constexpr int RC_LDS = RC_X_BYTES + RC_S_BYTES;
@@ -59,6 +64,7 @@ struct RowChainArgs {
     const float* alpha_dev;
     const int* alpha_idx;
     int alpha_bstride;
+    unsigned long long* stamps;   // BC_RC_STAMPS diagnostics: [workgroup][16] s_memtime stamps (null in production)
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -73,39 +79,56 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ---- weight ring: R fragments ahead of the consumer, static indices only ------------------------------------------------------
+template <int R>
 struct WRing {
-    uint4 f[RC_R];
+    uint4 f[R];
     const uint4* p;          // this lane's next fragment to LOAD
 };
 
-__device__ __forceinline__ void ring_fill(WRing& r) {
+template <int R>
+__device__ __forceinline__ void ring_fill(WRing<R>& r) {
 #pragma unroll
-    for (int i = 0; i < RC_R; ++i) r.f[i] = r.p[i * 64];
-    r.p += RC_R * 64;
+    for (int i = 0; i < R; ++i) r.f[i] = r.p[i * 64];
+    r.p += R * 64;
 }
 
 // One GEMM segment: acc[t][mt] += W-tile t (16 channels) x rows-tile mt (16 rows) over KS k-steps of 32.
-// POS = ring index of the segment's first fragment (compile time); returns through the template chain: (POS + NT*KS) % R.
+// POS = ring index of the segment's first fragment (compile time).
 // SWAP: D^T[channel][row] (lane: 4 consecutive channels of one row); !SWAP: D[row][channel] (lane: 4 consecutive rows of one channel).
-template <int NT, int KS, int POS, bool SWAP>
-__device__ __forceinline__ void gemm_seg(f32x4v (&acc)[NT][4], WRing& r, const char* xb) {
+// Issue order per k-step, pinned with sched_barrier (left alone, hipcc sinks the ring refills by two k-steps - the prefetch distance
+// collapses to vmcnt(0..1) - and reads the operand fragments right in front of the MFMAs that need them): refill the slots the
+// PREVIOUS step consumed, read the NEXT step's operand fragments, then this step's MFMAs run under both.
+template <int NT, int KS, int POS, bool SWAP, int RC_R>
+__device__ __forceinline__ void gemm_seg(f32x4v (&acc)[NT][4], WRing<RC_R>& r, const char* xb) {
+    h16x8 xq[2][4];                                  // operand fragments of the current / the next k-step (static ping-pong)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xq[0][mt] = *reinterpret_cast<const h16x8*>(xb + mt * 1024);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        h16x8 xf[4];
+        if (s > 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const h16x8*>(xb + s * 4096 + mt * 1024);
+            for (int t = 0; t < NT; ++t) r.f[(POS + (s - 1) * NT + t) % RC_R] = r.p[t * 64];
+            r.p += NT * 64;
+        }
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xq[(s + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(xb + (s + 1) * 4096 + mt * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const h16x8 w = as_h8(r.f[(POS + s * NT + t) % RC_R]);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                acc[t][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[mt], acc[t][mt], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[mt], w, acc[t][mt], 0, 0, 0);
+                acc[t][mt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xq[s & 1][mt], acc[t][mt], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(xq[s & 1][mt], w, acc[t][mt], 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r.f[(POS + s * NT + t) % RC_R] = r.p[t * 64];
-        r.p += NT * 64;
+        __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r.f[(POS + (KS - 1) * NT + t) % RC_R] = r.p[t * 64];
+    r.p += NT * 64;
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int NT>
@@ -344,8 +367,16 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);        // this lane's fragment offset inside a (k-step, row-tile) KiB
     const float* vec = a.vec;
     const CopyMap cm = copy_map(tid);
+    unsigned long long* const stamps = a.stamps;
+    unsigned long long acc_t[3] = {0, 0, 0};         // (OUT, diagnostics) ticks inside ff1 GEMMs / GEGLU epilogues / ff2 GEMMs
+    auto stamp = [&](int i) {
+        if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
-    WRing ring;
+    constexpr int RC_R = KIND == BC_CHAIN_OUT ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16);
+    static_assert(RC_R <= RC_RPAD, "stream padding");
+    WRing<RC_R> ring;
     ring.p = a.wstream + (size_t)wave * a.wave_frags * 64 + lane;
     ring_fill(ring);
 
@@ -355,10 +386,13 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     if (KIND == BC_CHAIN_IN) {
         rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, a.affine ? a.affine + (size_t)b * RC_C * 2 : nullptr);
         lds_barrier();
+        stamp(1);
         // proj_in -> h0
         gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);
+        stamp(2);
         epi_bias_res<false>(acc, vec, S, wave, m, q);
         layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        stamp(3);
         acc_to_S(acc, S, wave, m, q);
         lds_barrier();                                                  // X = LN1(h0), S = h0
         S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
@@ -400,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
                 *reinterpret_cast<uint4*>(vt + (size_t)i * 32 * a.ldvt) = d;
             }
         }
+        stamp(4);
         return;
     }
 
@@ -407,7 +442,9 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
     rows_to_S(a.res + (size_t)m0 * RC_C, S, cm);
     lds_barrier();
+    stamp(1);
     gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);               // attn.to_out
+    stamp(2);
     epi_bias_res<true>(acc, vec, S, wave, m, q);                        // + bias + residual (own columns only: no barrier needed)
 
     if (KIND == BC_CHAIN_MID) {
@@ -421,37 +458,54 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
         acc_to_S(acc, S, wave, m, q);
         lds_barrier();
         S_to_rows(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        stamp(4);
         return;
     }
 
     // ---- OUT: LayerNorm3 -> GEGLU feed-forward accumulated ON TOP of h2 (acc keeps the residual in fp32) ----
     layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
     lds_barrier();
+    stamp(3);
     {
-        const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][v0 v1 g0 g1][16]
+        const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][v0 g0 v1 g1][16]
         constexpr int POS_FF = (RC_NT * RC_KS) % RC_R;
-        static_assert((4 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0, "a feed-forward chunk must consume a whole number of rings");
+        static_assert(KIND != BC_CHAIN_OUT || (4 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0, "a feed-forward chunk must consume a whole number of rings");
         for (int c = 0; c < RC_NCH; ++c) {
             char* P = S + (c & 1) * 16384;
-            f32x4v a1[4][4];
-            zero_acc(a1);
-            gemm_seg<4, RC_KS, POS_FF, true>(a1, ring, X + xfo);
             const float* bb = b1 + (c * 4 + wave) * 64 + 4 * q;
+            // ff.net.0.proj for this wave's 32 hidden units of the chunk, as two (value tile, gate tile) pairs: 32 accumulator
+            // registers instead of 64 (the block's 80 stay resident underneath)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
-                const float4 bv = *reinterpret_cast<const float4*>(bb + tp * 16);
-                const float4 bg = *reinterpret_cast<const float4*>(bb + (2 + tp) * 16);
+                f32x4v a1[2][4];
+                zero_acc(a1);
+                const unsigned long long ta = stamps ? __builtin_amdgcn_s_memtime() : 0;
+                if (tp == 0) gemm_seg<2, RC_KS, POS_FF, true>(a1, ring, X + xfo);
+                else gemm_seg<2, RC_KS, (POS_FF + 2 * RC_KS) % RC_R, true>(a1, ring, X + xfo);
+                const unsigned long long tb = stamps ? __builtin_amdgcn_s_memtime() : 0;
+                acc_t[0] += tb - ta;
+                const float4 bv = *reinterpret_cast<const float4*>(bb + tp * 32);
+                const float4 bg = *reinterpret_cast<const float4*>(bb + tp * 32 + 16);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const float v[4] = {(a1[tp][mt][0] + bv.x) * bc_gelu_f(a1[2 + tp][mt][0] + bg.x), (a1[tp][mt][1] + bv.y) * bc_gelu_f(a1[2 + tp][mt][1] + bg.y),
-                                        (a1[tp][mt][2] + bv.z) * bc_gelu_f(a1[2 + tp][mt][2] + bg.z), (a1[tp][mt][3] + bv.w) * bc_gelu_f(a1[2 + tp][mt][3] + bg.w)};
+                    const float v[4] = {(a1[0][mt][0] + bv.x) * bc_gelu_f(a1[1][mt][0] + bg.x), (a1[0][mt][1] + bv.y) * bc_gelu_f(a1[1][mt][1] + bg.y),
+                                        (a1[0][mt][2] + bv.z) * bc_gelu_f(a1[1][mt][2] + bg.z), (a1[0][mt][3] + bv.w) * bc_gelu_f(a1[1][mt][3] + bg.w)};
                     // hidden unit (inside the chunk) 32 wave + 16 tp + 4 q + r: k-step `wave`, chunk 2 tp + (q >> 1), half q & 1
                     *reinterpret_cast<h16x4*>(P + x_off(wave, 16 * mt + m, 2 * tp + (q >> 1)) + (q & 1) * 8) = pack4(v);
                 }
+                if (stamps) acc_t[1] += __builtin_amdgcn_s_memtime() - tb;
             }
             lds_barrier();                                              // the chunk's 128 hidden columns are complete
+            const unsigned long long tc = stamps ? __builtin_amdgcn_s_memtime() : 0;
             gemm_seg<RC_NT, RC_HC / 32, (POS_FF + 4 * RC_KS) % RC_R, true>(acc, ring, P + xfo);
+            if (stamps) acc_t[2] += __builtin_amdgcn_s_memtime() - tc;
         }
+    }
+    stamp(4);
+    if (stamps && tid == 0) {
+        stamps[(size_t)blockIdx.x * 16 + 8] = acc_t[0];
+        stamps[(size_t)blockIdx.x * 16 + 9] = acc_t[1];
+        stamps[(size_t)blockIdx.x * 16 + 10] = acc_t[2];
     }
     // (lane-derived values are laundered here: without it hipcc keeps the LDS addresses of the epilogues before and after the
     //  feed-forward loop alive ACROSS it - common subexpressions - and spills two dozen registers around the loop)
@@ -469,7 +523,9 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     lds_barrier();
     zero_acc(acc);
     constexpr int POS_PO = (RC_NT * RC_KS) % RC_R;                      // (the feed-forward consumed whole rings)
+    stamp(5);
     gemm_seg<RC_NT, RC_KS, POS_PO, true>(acc, ring, X + xfo);          // proj_out
+    stamp(6);
     const float* bpo = vec + 3 * RC_C + 8 * RC_C + RC_C;
     epi_bias_res<true>(acc, bpo, S, wave, m, q);                        // + bias + x
     if (a.r2) {                                                          // + BlobNet residual on the right-hand part of the canvas
@@ -487,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
     if (a.gn_part)
         gn_partials_from_S(S, a.gn_part + ((size_t)b * (a.rows_per_batch / RC_BM) + pix0 / RC_BM) * RC_C * 2, tid);
+    stamp(7);
     if (BLOB) {
         // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
         S_to_X(S, X, cm);
@@ -507,8 +564,46 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
 #undef cm
 }
 
+// BC_RC_STAMPS=1 (diagnostics; synchronises the stream after every launch): where a workgroup's cycles go
+struct RcStampReport {
+    hipStream_t stream; size_t n; unsigned long long* buf; int kind;
+    ~RcStampReport() {
+        if (!buf) return;
+        if (hipStreamSynchronize(stream) != hipSuccess) return;
+        std::vector<unsigned long long> h(n * 16);
+        if (hipMemcpy(h.data(), buf, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+        double d[8] = {0}, ff[3] = {0};
+        unsigned long long t0 = ~0ull, t1 = 0;
+        const int last = kind == BC_CHAIN_OUT ? 7 : 4;
+        for (size_t i = 0; i < n; ++i) {
+            for (int k = 0; k < last; ++k) d[k] += (double)(h[i * 16 + k + 1] - h[i * 16 + k]);
+            for (int k = 0; k < 3; ++k) ff[k] += (double)h[i * 16 + 8 + k];
+            t0 = std::min(t0, h[i * 16]);
+            t1 = std::max(t1, h[i * 16 + last]);
+        }
+        if (kind == BC_CHAIN_OUT)
+            fprintf(stderr, "[rowchain stamps out] wgs=%zu | avg ticks: prologue %.0f, to_out gemm %.0f, epilogue+LN %.0f, ff loop %.0f (ff1 gemms %.0f, "
+                    "geglu %.0f, ff2 gemms %.0f), h3 + x staging %.0f, proj_out gemm %.0f, epilogue+stores %.0f | first entry -> last exit %llu ticks\n",
+                    n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, ff[0] / n, ff[1] / n, ff[2] / n, d[4] / n, d[5] / n, d[6] / n, t1 - t0);
+        else
+            fprintf(stderr, "[rowchain stamps %s] wgs=%zu | avg ticks: prologue %.0f, first gemm %.0f, epilogue+LN %.0f, rest %.0f | first entry -> last "
+                    "exit %llu ticks\n", kind == BC_CHAIN_IN ? "in" : "mid", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, t1 - t0);
+    }
+};
+
 template <int KIND, bool BLOB>
-int launch_chain(const RowChainArgs& a, hipStream_t stream) {
+int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
+    RowChainArgs a = a_in;
+    static const bool want_stamps = getenv("BC_RC_STAMPS") != nullptr;
+    static unsigned long long* stamp_buf = nullptr;
+    const size_t nwg = (size_t)a.M / RC_BM;
+    a.stamps = nullptr;
+    if (want_stamps && nwg <= 8192) {
+        if (!stamp_buf) BC_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&stamp_buf), 8192 * 16 * sizeof(unsigned long long)));
+        BC_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, nwg * 16 * sizeof(unsigned long long), stream));
+        a.stamps = stamp_buf;
+    }
+    RcStampReport report{stream, nwg, a.stamps, KIND};
     static std::atomic<unsigned long long> lds_set{0};
     BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<KIND, BLOB>), RC_LDS));
     hipLaunchKernelGGL((rowchain_kernel<KIND, BLOB>), dim3(a.M / RC_BM), dim3(256), RC_LDS, stream, a);
@@ -530,7 +625,7 @@ extern "C" long long bc_rowchain_stream_frags(int kind, int blobnet) {
     else if (kind == BC_CHAIN_MID) n = 2 * g;
     else if (kind == BC_CHAIN_OUT) n = 2 * g + RC_NCH * (4 * RC_KS + RC_NT * (RC_HC / 32)) + (blobnet ? g : 0);
     else return -1;
-    return n + RC_R;
+    return n + RC_RPAD;
 }
 
 extern "C" int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
@@ -552,6 +647,7 @@ extern "C" int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x
     a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1); a.out2 = reinterpret_cast<h16*>(out2);
     a.ldvt = ldvt; a.gn_part = gn_part; a.ln_eps = ln_eps;
     a.alpha = alpha; a.alpha_dev = alpha_dev; a.alpha_idx = alpha_idx; a.alpha_bstride = alpha_bstride;
+    a.stamps = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (kind) {
         case BC_CHAIN_IN:

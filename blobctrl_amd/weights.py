@@ -179,7 +179,7 @@ class PackedTrunk:
 
 
 # ---------------------------------------------------------------------------------------------------------------- row-chain streams
-RC_C, RC_HC, RC_RING = 320, 128, 12          # mirrors csrc/rowchain.hip (RC_C, RC_HC, RC_R)
+RC_C, RC_HC, RC_RING = 320, 128, 20          # mirrors csrc/rowchain.hip (RC_C, RC_HC, RC_R)
 
 
 def _frag_stream(w: torch.Tensor, row_starts, k0: int = 0, k1: int = None) -> torch.Tensor:
@@ -228,12 +228,12 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
         segs = [_frag_stream(h[bp + att + ".to_out.0.weight"], n320)]
         ffb = []
         for c in range(hid // RC_HC):
-            starts = [[RC_HC * c + 32 * w, RC_HC * c + 32 * w + 16, hid + RC_HC * c + 32 * w, hid + RC_HC * c + 32 * w + 16] for w in range(4)]
-            segs.append(_frag_stream(w1o, starts))
+            for tp in range(2):                   # two (value tile, gate tile) passes over K per chunk
+                segs.append(_frag_stream(w1o, [[RC_HC * c + 32 * w + 16 * tp, hid + RC_HC * c + 32 * w + 16 * tp] for w in range(4)]))
             segs.append(_frag_stream(w2, n320, RC_HC * c, RC_HC * (c + 1)))
             for w in range(4):
                 j0 = RC_HC * c + 32 * w
-                ffb += [bv[j0:j0 + 16], bv[j0 + 16:j0 + 32], bg[j0:j0 + 16], bg[j0 + 16:j0 + 32]]
+                ffb += [bv[j0:j0 + 16], bg[j0:j0 + 16], bv[j0 + 16:j0 + 32], bg[j0 + 16:j0 + 32]]
         segs.append(_frag_stream(h[p + "proj_out.weight"], n320))
         vec = [f[bp + att + ".to_out.0.bias"], f[bp + "norm3.weight"], f[bp + "norm3.bias"], torch.cat(ffb), f[bp + "ff.net.2.bias"],
                f[p + "proj_out.bias"]]

@@ -81,4 +81,4 @@ def test_rowchain_rejects_unsupported_shapes():
     lib = _lib.load()
     assert lib.bc_rowchain_supported(320, 2 * 8192, 8192) == 1
     assert lib.bc_rowchain_supported(640, 4096, 2048) == 0 and lib.bc_rowchain_supported(320, 96, 96) == 0
-    assert lib.bc_rowchain_stream_frags(0, 0) == 212 and lib.bc_rowchain_stream_frags(2, 1) == 762
+    assert lib.bc_rowchain_stream_frags(0, 0) == 220 and lib.bc_rowchain_stream_frags(2, 1) == 770
