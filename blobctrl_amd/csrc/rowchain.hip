@@ -473,6 +473,10 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
         for (int c = 0; c < RC_NCH; ++c) {
             char* P = S + (c & 1) * 16384;
             const float* bb = b1 + (c * 4 + wave) * 64 + 4 * q;
+            // (the chunk's GEGLU biases are fetched here, a GEMM pass ahead of their use: behind the pass's sched_barriers they cost
+            //  an exposed L2 round trip per pass)
+            const float4 bvg[4] = {*reinterpret_cast<const float4*>(bb), *reinterpret_cast<const float4*>(bb + 16),
+                                   *reinterpret_cast<const float4*>(bb + 32), *reinterpret_cast<const float4*>(bb + 48)};
             // ff.net.0.proj for this wave's 32 hidden units of the chunk, as two (value tile, gate tile) pairs: 32 accumulator
             // registers instead of 64 (the block's 80 stay resident underneath)
 #pragma unroll
@@ -484,8 +488,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
                 else gemm_seg<2, RC_KS, (POS_FF + 2 * RC_KS) % RC_R, true>(a1, ring, X + xfo);
                 const unsigned long long tb = stamps ? __builtin_amdgcn_s_memtime() : 0;
                 acc_t[0] += tb - ta;
-                const float4 bv = *reinterpret_cast<const float4*>(bb + tp * 32);
-                const float4 bg = *reinterpret_cast<const float4*>(bb + tp * 32 + 16);
+                const float4 bv = bvg[2 * tp], bg = bvg[2 * tp + 1];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const float v[4] = {(a1[0][mt][0] + bv.x) * bc_gelu_f(a1[1][mt][0] + bg.x), (a1[0][mt][1] + bv.y) * bc_gelu_f(a1[1][mt][1] + bg.y),

@@ -195,6 +195,8 @@ def test_free_running_fifty_step_edit_matches_the_reference_final_latents(full, 
     again = eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], trace=trace, **kw).float().cpu().numpy()
     assert np.array_equal(again, final)
     for k in (1, 10, 25, 40):
+        if f"{tag}_x{k}" not in z.files:                 # (checkpoints are stored for the benchmark's own weights only)
+            continue
         xr, xg = z[f"{tag}_x{k}"], trace[k - 1][1].float().cpu().numpy()
         r = np.abs(xg - xr).max() / np.abs(xr).max()
         print(f"   after step {k:2d}: max-abs/scale {r:.3e}, PSNR {psnr(xg, xr):.1f} dB")

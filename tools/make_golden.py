@@ -299,7 +299,7 @@ def golden_fullsize_loop(variants=None):
             nu, nt = npred.chunk(2)
             npred = nu + 7.5 * (nt - nu)
             latents = sch.step(npred, t, latents, return_dict=False)[0]
-            if i + 1 in (1, 10, 25, 40):
+            if i + 1 in (1, 10, 25, 40) and scale == 1.0:          # (checkpoints only for the benchmark's own weights: 64 KB each)
                 out[f"{tag}_x{i + 1}"] = latents.numpy().copy()
             print(f"{tag} step {i + 1}/{steps} |x| max {latents.abs().max():.2f} ({time.time() - t0:.0f} s)", flush=True)
         out[f"{tag}_final"] = latents.numpy().copy()
