@@ -395,7 +395,10 @@ int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int he
         // queries) 659 / 804; 8 x 2 660 / 737.  Halving the LDS traffic buys nothing - the kernel is VALU-issue-bound - so the
         // 8-wave form is taken where the grid still gives every SIMD four waves, and the two-block forms are not instantiated.
         const long long wgs8 = (long long)bc_ceil_div(Nq, QW * 8) * heads * B;
-        if (wgs8 >= 2 * 256 && Nkv >= 1024 && !causal && !getenv("BC_ATTN_NO8"))
+        // Round 3: from ONE 8-wave workgroup per CU (was two): BlobNet's batch-1 self-attention at the 64 x 128 level (256 such
+        // workgroups) then stages every K / V^T tile once per 256 queries too - step 10.59 -> 10.49 ms (same box, two rounds).
+        static const long long min8 = getenv("BC_ATTN_MIN8") ? atoll(getenv("BC_ATTN_MIN8")) : 256;
+        if (wgs8 >= min8 && Nkv >= 1024 && !causal && !getenv("BC_ATTN_NO8"))
             return launch_attn_nw<D, 8, 1, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
     }
     if constexpr (D <= 40) {

@@ -352,10 +352,11 @@ class Recorder:
             if splitk is None:
                 target = int(os.environ.get("BC_HALO_CTAS", "256"))
                 min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "2"))               # fewest 64-channel chunks per workgroup
-                # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the step gains
-                # 0.5 % because the other trunk's kernels fill the idle CUs, but this kernel's own efficiency drops from 0.22 to 0.19 of
-                # peak: DESIGN 3.5.)
-                full = int(os.environ.get("BC_HALO_FULL", str(target * 2 // 3)))
+                # workgroups from which one pass is taken unsplit: HALF of the target (round 3; was 2/3).  The 64 x 128 BlobNet and the
+                # 32 x 64 UNet convolutions (128 workgroups) then run as ONE pass instead of two K halves + a reducer: 13 reducer launches
+                # and 0.7 GB of fp32 slab traffic less per step, step -0.4 % (10.59 -> 10.55 ms, same box, two rounds) - the other
+                # trunk's kernels fill the idle CUs - although this kernel's own average efficiency drops.
+                full = int(os.environ.get("BC_HALO_FULL", str(target // 2)))
                 splitk = 1 if base >= full else max(1, min(nch // min_cps, -(-target // base)))
             splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))
