@@ -73,6 +73,8 @@ _SIGNATURES = {
     "bc_splat_scores": (C.c_int, [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_assemble_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_assemble_input_im2col": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p]),
     "bc_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_timestep_embedding_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
@@ -127,7 +129,7 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_attention": 6, "bc_attention_causal": 7, "bc_assemble_input": 8, "bc_timestep_embedding": 9,
        "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
-       "bc_gaussian_sample": 19, "bc_rowchain": 22}
+       "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23}
 OP_SIGNAL, OP_WAIT = 20, 21
 CHAIN_IN, CHAIN_MID, CHAIN_OUT = 0, 1, 2
 _KIND = {C.c_void_p: "p", C.c_int: "i", C.c_float: "f", C.c_longlong: "l", C.c_char_p: "p"}

@@ -77,6 +77,41 @@ __global__ void assemble_kernel(const float* __restrict__ latents, int Blat, con
     }
 }
 
+// The same input (8 channels: 4 latents, score, [score], 0, 0) written as the 3x3 im2col operand of conv_in: row = canvas pixel,
+// k = tap * 8 + channel for the nine taps (zero outside the h x 2w canvas = the convolution's padding), zero-filled up to 128, so that
+// conv_in (K = 72: outside the LDS-DMA GEMM's K % 64 == 0 fast path, 41 us per launch on the register-staged kernel) runs as a dense
+// K = 128 GEMM.  One thread per (pixel, 16-byte chunk).
+__global__ void assemble_im2col_kernel(const float* __restrict__ latents, int Blat, const float* __restrict__ img_lat,
+                                       const float* __restrict__ score, int Bimg, int Bout, int h, int w, int dup_score,
+                                       h16* __restrict__ X) {
+    const long long total = (long long)Bout * h * 2 * w * 16;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int chunk = (int)(idx & 15);
+        const long long pix = idx >> 4;
+        const int x = (int)(pix % (2 * w));
+        const int y = (int)((pix / (2 * w)) % h);
+        const int b = (int)(pix / ((long long)2 * w * h));
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (chunk < 9) {
+            const int yy = y + chunk / 3 - 1, xx = x + chunk % 3 - 1;
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)(2 * w)) {
+                const bool right = xx >= w;
+                const int xs = right ? xx - w : xx;
+                const int bi = b % Bimg;
+                const float sc = score[((size_t)bi * h + yy) * w + xs];
+                h16* o = reinterpret_cast<h16*>(&raw);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    o[c] = (h16)(right ? latents[(((size_t)(b % Blat) * 4 + c) * h + yy) * w + xs]
+                                       : img_lat[(((size_t)bi * 4 + c) * h + yy) * w + xs]);
+                o[4] = (h16)sc;
+                o[5] = dup_score ? (h16)sc : (h16)0.f;
+            }
+        }
+        bc_st16(X + (size_t)pix * 128 + chunk * 8, raw);
+    }
+}
+
 // embeddings.py:27-78: [cos(t*f_k) | sin(t*f_k)], f_k = exp(-ln(10000) * k / half)
 // rows_per_step > 0: row r belongs to step r / rows_per_step of the table (all steps of an edit at once)
 __global__ void temb_kernel(const float* __restrict__ t_table, const int* __restrict__ t_idx, float t_value, int rows,
@@ -262,6 +297,17 @@ extern "C" int bc_assemble_input(const float* latents, int Blat, const float* im
     long long total = (long long)Bout * h * 2 * w * (Cpad / 8);
     hipLaunchKernelGGL(assemble_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, latents, Blat, img_lat, score, feat,
                        Bimg, F, Bout, h, w, Cpad, dup_score, reinterpret_cast<h16*>(X));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_assemble_input_im2col(const float* latents, int Blat, const float* img_lat, const float* score, int Bimg, int Bout,
+                                        int h, int w, int dup_score, bc_half* X, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(latents && img_lat && score && X && Blat > 0 && Bout > 0 && Bimg > 0, "bc_assemble_input_im2col: bad args");
+    long long total = (long long)Bout * h * 2 * w * 16;
+    hipLaunchKernelGGL(assemble_im2col_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, latents, Blat, img_lat, score, Bimg, Bout,
+                       h, w, dup_score, reinterpret_cast<h16*>(X));
     BC_CHECK_LAUNCH();
     return 0;
 }

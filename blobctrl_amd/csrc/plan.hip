@@ -50,6 +50,7 @@ const char* op_signature(int op) {
         case BC_OP_SIGNAL:
         case BC_OP_WAIT: return "i";
         case BC_OP_ROWCHAIN: return "iiipppppiiipppppipffppi";
+        case BC_OP_ASSEMBLE_IM2COL: return "pippiiiiip";
         default: return nullptr;
     }
 }
@@ -159,6 +160,8 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
         case BC_OP_NCHW_TO_NHWC_F16: return bc_nchw_to_nhwc_f16(P(0), I(1), I(2), I(3), I(4), I(5), MP(bc_half, 6), s);
         case BC_OP_NHWC_TO_NCHW: return bc_nhwc_to_nchw(CP(bc_half, 0), I(1), I(2), I(3), I(4), P(5), I(6), s);
         case BC_OP_GAUSSIAN_SAMPLE: return bc_gaussian_sample(CP(bc_half, 0), CP(float, 1), I(2), I(3), I(4), F(5), MP(float, 6), s);
+        case BC_OP_ASSEMBLE_IM2COL:
+            return bc_assemble_input_im2col(CP(float, 0), I(1), CP(float, 2), CP(float, 3), I(4), I(5), I(6), I(7), I(8), MP(bc_half, 9), s);
         case BC_OP_ROWCHAIN:
             return bc_rowchain(I(0), I(1), I(2), CP(bc_half, 3), CP(float, 4), CP(bc_half, 5), CP(bc_half, 6), CP(bc_half, 7), I(8), I(9), I(10),
                                CP(bc_half, 11), CP(float, 12), MP(bc_half, 13), MP(bc_half, 14), MP(bc_half, 15), I(16), MP(float, 17), F(18),

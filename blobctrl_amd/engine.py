@@ -77,7 +77,7 @@ class TrunkPlan:
         return not os.environ.get("BC_NO_HALO") and bool(self.rec.lib.bc_conv_halo_eligible(Cin, C1, Cout, H, W, H, W, 1))
 
     def conv3x3(self, x: Act, wname, Cout, stride=1, up_to=None, rowvec=None, R=None, r2=None, out_f32=False,
-                kind="conv3x3", out=None, x2: Optional[Act] = None, affine=None, halo=False):
+                kind="conv3x3", out=None, x2: Optional[Act] = None, affine=None, halo=False, tile_cfg=0):
         """`halo=True`: conv_halo.hip on the channel-concat (x | x2) with `affine` = (ab tensor, activation) applied while staging."""
         rec, pw = self.rec, self.pw
         Hv, Wv = up_to if up_to is not None else (x.H, x.W)
@@ -102,6 +102,8 @@ class TrunkPlan:
                 kw.update(a_act=affine[1], **({"a_gn": affine[0]} if isinstance(affine[0], dict) else {"a_affine": affine[0]}))
         else:
             assert x2 is None and affine is None
+            if tile_cfg:
+                kw.update(tile_cfg=tile_cfg)
         rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * Cin, out=out,
                  out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,
                  conv=dict(Cin=Cin, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
@@ -278,12 +280,11 @@ class TrunkPlan:
     def record_collapse(self, feat16: torch.Tensor):
         """BlobNet conv_in over the F feature channels, which are score x f (rank 1, pipe:706-721, SURVEY 8a note iii):
         g[o, tap] = sum_c W[o, 5+c, tap] * f_c is computed once per edit (one GEMV on the MFMA path) and written into input
-        channel 5 of an 8-channel conv_in weight; the step then convolves [latents(4), score, score, 0, 0]."""
+        channel 5 of an 8-channel conv_in weight; the step then convolves [latents(4), score, score, 0, 0] - as a dense K = 128
+        GEMM over the im2col operand that bc_assemble_input_im2col writes (weight [co][128], k = tap * 8 + channel)."""
         pw = self.pw
         w8 = pw.h["conv_in.weight8"]
         fm = pw.h["conv_in.featmat"]
-        pw.h["conv_in8.weight"] = w8
-        pw.f["conv_in8.bias"] = pw.f["conv_in.bias"]
         self.rec.gemm(A=fm, W=feat16, M=fm.shape[0], N=1, K=fm.shape[1], out=w8, ldc=8, out_offset=5, kind="collapse")
 
     # ------------------------------------------------------------------------------------------- time embedding
@@ -315,9 +316,20 @@ class TrunkPlan:
         self.tproj_table = (t_idx, B * pw.temb_total)
 
     # ------------------------------------------------------------------------------------------- forward
+    def conv_in_dense(self, x_in: torch.Tensor, wkey, r2=None):
+        """conv_in on the im2col operand [B][H*W][128] (round 3): K = 72 is outside the LDS-DMA GEMM's fast path (the register-staged
+        kernel took 41 us per launch for 2.4 GFLOP); as a dense K = 128 GEMM it is one of the ordinary 1x1-convolution launches."""
+        pw, H, W = self.pw, self.H, self.W
+        Cout = self.cfg.block_out_channels[0]
+        M = self.B * H * W
+        out = self.rec.empty(self.B, H * W, Cout)
+        self.rec.gemm(A=x_in, W=pw.h[wkey], M=M, N=Cout, K=128, out=out, bias=pw.f["conv_in.bias"], rows_per_batch=H * W, kind="conv_in",
+                      want_gn=True, **self._r2(r2, H, W))
+        return Act(out, Cout, H, W)
+
     def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,
-                       signal_residuals: bool = False, eps_out: Optional[torch.Tensor] = None):
-        """x_in: [B, H*W, pad8(in_channels)] fp16.  UNet: returns eps fp32 [B, H*W, out_channels].
+                       signal_residuals: bool = False, eps_out: Optional[torch.Tensor] = None, im2col: bool = False):
+        """x_in: [B, H*W, pad8(in_channels)] fp16, or with `im2col` the [B, H*W, 128] operand of bc_assemble_input_im2col.  UNet: returns eps fp32 [B, H*W, out_channels].
         BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx[, alpha_bstride]);
         alpha_bstride = B selects per-image scales alpha_dev[step * B + image] for a batch of independent requests)."""
         cfg, pw = self.cfg, self.pw
@@ -366,15 +378,20 @@ class TrunkPlan:
 
         x = Act(x_in, x_in.shape[-1], H, W)
         conv_in_name = "conv_in"
-        if x_in.shape[-1] == 8 and pad8(cfg.in_channels) > 8:
-            conv_in_name = "conv_in8"        # rank-1-collapsed BlobNet input (see record_collapse)
+        if not im2col and x_in.shape[-1] == 8 and pad8(cfg.in_channels) > 8:
+            raise ValueError("the rank-1-collapsed BlobNet input is consumed in its im2col form (bc_assemble_input_im2col, im2col=True)")
+        if im2col:
+            wkey = "conv_in.weight8" if pad8(cfg.in_channels) > 8 else "conv_in.weight_k128"
+            conv_in = lambda r2=None: self.conv_in_dense(x_in, wkey, r2)
+        else:
+            conv_in = lambda r2=None: self.conv3x3(x, conv_in_name, boc[0], r2=r2, kind="conv_in")
         if residuals is not None and W == H:
             # square canvas: `sample = sample + r` rebinds, skip #0 stays WITHOUT the residual (unet_2d_condition.py:1213-1217)
-            skip0 = self.conv3x3(x, conv_in_name, boc[0], kind="conv_in")
-            h = self.conv3x3(x, conv_in_name, boc[0], r2=pop(res_d), kind="conv_in")
+            skip0 = conv_in()
+            h = conv_in(pop(res_d))
         else:
             # wide canvas: in-place slice add aliases the tuple element => skip #0 carries the residual (:1219)
-            h = self.conv3x3(x, conv_in_name, boc[0], r2=pop(res_d), kind="conv_in")
+            h = conv_in(pop(res_d))
             skip0 = h
         skips = [skip0]
         feats_d.append(h)
@@ -420,7 +437,10 @@ class TrunkPlan:
                 feats_u.append(h)
         if not cfg.is_blobnet:
             n = self.groupnorm(h, None, "conv_norm_out", 1e-5, True)
-            eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out", out=eps_out)
+            # conv_out has 4 output channels: one column tile.  The planner's 256-row tiles left 64 workgroups, each gathering 1.5 MB
+            # through one CU (23 us); 64-row tiles spread the same gather over 256 CUs.
+            small = 7 if (self.B * H * W) >= 64 * 128 and not os.environ.get("BC_CONV_OUT_AUTO") else 0
+            eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out", out=eps_out, tile_cfg=small)
             return eps.t
         self.feat_shapes = ([(f.C, f.H, f.W) for f in feats_d], (feat_mid.C, feat_mid.H, feat_mid.W),
                             [(f.C, f.H, f.W) for f in feats_u])

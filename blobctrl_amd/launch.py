@@ -352,11 +352,12 @@ class Recorder:
             if splitk is None:
                 target = int(os.environ.get("BC_HALO_CTAS", "256"))
                 min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "2"))               # fewest 64-channel chunks per workgroup
-                # workgroups from which one pass is taken unsplit: HALF of the target (round 3; was 2/3).  The 64 x 128 BlobNet and the
-                # 32 x 64 UNet convolutions (128 workgroups) then run as ONE pass instead of two K halves + a reducer: 13 reducer launches
-                # and 0.7 GB of fp32 slab traffic less per step, step -0.4 % (10.59 -> 10.55 ms, same box, two rounds) - the other
-                # trunk's kernels fill the idle CUs - although this kernel's own average efficiency drops.
-                full = int(os.environ.get("BC_HALO_FULL", str(target // 2)))
+                # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the 64 x 128
+                # BlobNet and 32 x 64 UNet convolutions run as one pass instead of two K halves + a reducer: 13 reducer launches and
+                # 0.7 GB of slab traffic less, and the step gains 0.4 % (10.59 -> 10.55 ms, round 3, same box) because the other trunk's
+                # kernels fill the idle CUs - but this kernel's own average goes from 37.5 to 45.8 us (0.24 -> 0.19 of peak) and the
+                # serialised kernel time of a step rises by 0.76 ms: not the default.)
+                full = int(os.environ.get("BC_HALO_FULL", str(target * 2 // 3)))
                 splitk = 1 if base >= full else max(1, min(nch // min_cps, -(-target // base)))
             splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))

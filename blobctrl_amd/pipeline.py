@@ -111,12 +111,17 @@ class BlobCtrlEngine:
         P.guidance = [7.5]
 
         # rank-1 collapse of the BlobNet feature channels (per-edit weight): not for per-request batches (one weight per launch)
-        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request
+        no_im2col = bool(os.environ.get("BC_NO_IM2COL"))      # diagnostics: conv_in as a 3x3 convolution (K = 72 / 9288: generic kernel)
+        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request and not no_im2col
         unet_cin = pad8(self.unet_cfg.in_channels)
         blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
+        # 8-channel inputs (the UNet's 4 latents + score; BlobNet's rank-1-collapsed 4 latents + 2 x score) are assembled directly as
+        # the 3x3 im2col operand [rows][128] of conv_in, which then runs as a dense GEMM on the LDS-DMA fast path (K = 72 does not)
+        P.unet_im2col = unet_cin == 8 and not no_im2col
+        P.blob_im2col = P.collapse
         P.feat16 = rec.zeros(1, pad8(max(F, 1)), name="feat16")
-        P.blob_in = rec.zeros(B, H * W, blob_cin)
-        P.unet_in = rec.zeros(2 * B, H * W, unet_cin)
+        P.blob_in = rec.zeros(B, H * W, 128 if P.blob_im2col else blob_cin)
+        P.unet_in = rec.zeros(2 * B, H * W, 128 if P.unet_im2col else unet_cin)
 
         # ---- prologue: prompt K/V
         P.prologue = rec.begin("prologue")
@@ -151,8 +156,12 @@ class BlobCtrlEngine:
             return hp
 
         def record_unet(plan, residuals):
-            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, Bi, 0,
-                     2 * B, h, w, unet_cin, 0, P.unet_in.data_ptr(), kind="assemble")
+            if P.unet_im2col:
+                rec.call("bc_assemble_input_im2col", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), Bi, 2 * B, h, w,
+                         0, P.unet_in.data_ptr(), kind="assemble")
+            else:
+                rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.bg_lat.data_ptr(), P.bg_score.data_ptr(), None, Bi, 0,
+                         2 * B, h, w, unet_cin, 0, P.unet_in.data_ptr(), kind="assemble")
             if temb_per_step:
                 plan.record_time(P.t_table, P.step_idx)
             if split_cfg:
@@ -160,14 +169,14 @@ class BlobCtrlEngine:
                 rec.signal(ready)                                   # unet_in assembled (stream 0)
                 rec.sid = 2
                 rec.wait(ready)
-                half_plan(B).record_forward(P.unet_in[B:], residuals, eps_out=P.eps_all[B:])        # cond half
+                half_plan(B).record_forward(P.unet_in[B:], residuals, eps_out=P.eps_all[B:], im2col=P.unet_im2col)   # cond half
                 rec.signal(joined)
                 rec.sid = 0
-                half_plan(0).record_forward(P.unet_in[:B], residuals, eps_out=P.eps_all[:B])        # uncond half
+                half_plan(0).record_forward(P.unet_in[:B], residuals, eps_out=P.eps_all[:B], im2col=P.unet_im2col)   # uncond half
                 rec.wait(joined)
                 eps = P.eps_all
             else:
-                eps = plan.record_forward(P.unet_in, residuals)
+                eps = plan.record_forward(P.unet_in, residuals, im2col=P.unet_im2col)
             P.eps = eps
             rec.call("bc_cfg_scheduler_step", eps, P.latents, P.coef, P.step_idx, P.hist, -1.0, B, h, w, P.eps_guided, 1,
                      kind="cfg_step")
@@ -180,16 +189,16 @@ class BlobCtrlEngine:
         rec.signal(fork)
         rec.sid = 1
         rec.wait(fork)
-        if P.collapse:
-            rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(), None, 1, 0,
-                     B, h, w, blob_cin, 1, P.blob_in.data_ptr(), kind="assemble")
+        if P.blob_im2col:
+            rec.call("bc_assemble_input_im2col", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(), 1, B, h, w, 1,
+                     P.blob_in.data_ptr(), kind="assemble")
         else:
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
                      P.feat.data_ptr() if F > 0 else None, Bi, F, B, h, w, blob_cin, 0, P.blob_in.data_ptr(), kind="assemble")
         if temb_per_step:
             blob.record_time(P.t_table, P.step_idx)
         residuals = blob.record_forward(P.blob_in, None, zero_scale=(1.0, P.scale_table, P.step_idx, B if per_request else 0),
-                                        signal_residuals=True)
+                                        signal_residuals=True, im2col=P.blob_im2col)
         rec.sid = 0
         P.residuals = residuals
         record_unet(unet_a, residuals)

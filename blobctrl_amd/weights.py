@@ -108,14 +108,29 @@ class PackedTrunk:
                 self.h[k] = pack_matrix(v).half().to(device)
         self.temb_total = off
         w_in = sd["conv_in.weight"]
+        co = w_in.shape[0]
+
+        def k128(w8ch):
+            """[co][3][3][8] -> [co][128]: the dense-GEMM form of an 8-channel conv_in (k = tap * 8 + channel, zero from k = 72),
+            multiplied with the im2col operand bc_assemble_input_im2col writes."""
+            out = torch.zeros(co, 128)
+            out[:, :72] = w8ch.reshape(co, 72)
+            return out
+        if w_in.shape[1] <= 8:
+            base = torch.zeros(co, 3, 3, 8)
+            base[..., : w_in.shape[1]] = w_in.permute(0, 2, 3, 1)
+            self.h["conv_in.weight_k128"] = k128(base).half().to(device)
         if w_in.shape[1] > 8:
             # BlobNet: conditioning = 1 score channel + F feature channels that are (score x per-edit vector) (pipe:706-721).
-            # Keep the F-channel block as a [Co*9, F] matrix: a per-edit GEMV collapses it into ONE extra input channel.
-            co = w_in.shape[0]
+            # Keep the F-channel block as a matrix whose per-edit GEMV (engine.record_collapse) collapses it into ONE extra input
+            # channel (channel 5) of an 8-channel conv_in.  Row co * 16 + tap of the matrix (taps 9..15: zero rows), so that the
+            # GEMV's output row m lands at element m * 8 + 5 of the [co][128] dense-GEMM weight.
             base = torch.zeros(co, 3, 3, 8)
             base[..., :5] = w_in[:, :5].permute(0, 2, 3, 1)
-            self.h["conv_in.weight8"] = base.reshape(co, 72).half().to(device)
-            self.h["conv_in.featmat"] = pack_matrix(w_in[:, 5:].permute(0, 2, 3, 1).reshape(co * 9, -1)).half().to(device)
+            self.h["conv_in.weight8"] = k128(base).half().to(device)
+            fm = torch.zeros(co, 16, w_in.shape[1] - 5)
+            fm[:, :9] = w_in[:, 5:].permute(0, 2, 3, 1).reshape(co, 9, -1)
+            self.h["conv_in.featmat"] = pack_matrix(fm.reshape(co * 16, -1)).half().to(device)
         self.h["temb_all.weight"] = torch.cat(temb_w, 0).half().to(device)
         self.f["temb_all.bias"] = torch.cat(temb_b, 0).to(device)
         self._to_arenas()

@@ -211,6 +211,11 @@ int bc_splat_scores(const double* params_host, int n, int h, int w, double* out,
  * the score with the per-edit kernel sum_c W[:, 5+c] * f_c). */
 int bc_assemble_input(const float* latents, int Blat, const float* img_lat, const float* score, const float* feat,
                       int Bimg, int F, int Bout, int h, int w, int Cpad, int dup_score, bc_half* X, bc_stream stream);
+/* The 8-channel form of the same input (4 latents, score, [second copy of the score], 0, 0) as the 3x3 im2col operand of conv_in:
+ * X [Bout][h * 2w][128] fp16, k = tap * 8 + channel for the nine taps (zero outside the canvas), zero-filled from k = 72, so that
+ * conv_in (pipe:724-739 -> unet_2d_condition.py:1166 / blobnet.py:812) is a dense K = 128 GEMM on the LDS-DMA fast path. */
+int bc_assemble_input_im2col(const float* latents, int Blat, const float* img_lat, const float* score, int Bimg, int Bout,
+                             int h, int w, int dup_score, bc_half* X, bc_stream stream);
 
 /* Sinusoidal timestep embedding (embeddings.py:27-78, flip_sin_to_cos=True, shift 0) for `rows` identical rows.
  * t = t_table[*t_idx] when t_table != NULL else t_value.  out [rows][dim] fp16. */
@@ -310,8 +315,8 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_ATTENTION = 6, BC_OP_ATTENTION_CAUSAL = 7, BC_OP_ASSEMBLE_INPUT = 8, BC_OP_TIMESTEP_EMBEDDING = 9,
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
-       BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22,
-       BC_OP_COUNT = 23 };
+       BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
+       BC_OP_COUNT = 24 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

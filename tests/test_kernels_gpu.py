@@ -480,6 +480,26 @@ def test_layout_roundtrip(rec):
     assert float(t[..., Cc:].abs().max()) == 0.0
 
 
+def test_assemble_im2col_is_the_unfolded_eight_channel_input(rec):
+    """bc_assemble_input_im2col = F.unfold(3x3, pad 1) of what bc_assemble_input writes for 8 channels (4 latents, score, [score]),
+    k = tap * 8 + channel, zero-filled from k = 72: the operand of conv_in as a dense K = 128 GEMM."""
+    B, Bi, hh, ww = 2, 1, 6, 5
+    lat, img, sc = g(1, B, 4, hh, ww), g(2, Bi, 4, hh, ww), torch.rand(Bi, hh, ww, generator=torch.Generator().manual_seed(3))
+    dl, di, ds = lat.cuda(), img.cuda(), sc.cuda()
+    for dup in (0, 1):
+        x8 = rec.zeros(2 * B, hh * 2 * ww, 8)
+        xi = rec.zeros(2 * B, hh * 2 * ww, 128)
+        run(rec, lambda: (rec.call("bc_assemble_input", dl.data_ptr(), B, di.data_ptr(), ds.data_ptr(), None, Bi, 0, 2 * B, hh, ww, 8, dup,
+                                   x8.data_ptr(), kind="assemble"),
+                          rec.call("bc_assemble_input_im2col", dl.data_ptr(), B, di.data_ptr(), ds.data_ptr(), Bi, 2 * B, hh, ww, dup,
+                                   xi.data_ptr(), kind="assemble")))
+        nchw = x8.float().cpu().view(2 * B, hh, 2 * ww, 8).permute(0, 3, 1, 2)
+        unf = F.unfold(nchw, 3, padding=1).view(2 * B, 8, 9, hh * 2 * ww).permute(0, 3, 2, 1).reshape(2 * B, hh * 2 * ww, 72)
+        got = xi.float().cpu()
+        assert torch.equal(got[..., :72], unf) and float(got[..., 72:].abs().max()) == 0.0
+        assert float(got[..., 5].abs().max()) == (0.0 if not dup else float(got[..., 5].abs().max())) and (dup or float(nchw[:, 5].abs().max()) == 0.0)
+
+
 def test_bad_arguments_fail_loudly(rec):
     from blobctrl_amd import _lib
     with pytest.raises(_lib.BlobCtrlHipError):
