@@ -134,8 +134,23 @@ def test_c3_batch8_mixed_operations_per_request_full_size(full):
                      latents=lat[b:b + 1], blobnet_conditioning_scale=strengths[b], **kw).cpu().numpy()
         rel = np.abs(out[b:b + 1] - single).max() / np.abs(single).max()
         print(f"C3 request {b} (strength {strengths[b]}): rel {rel:.3e}, PSNR {psnr(out[b:b + 1], single):.1f} dB")
-        assert rel < 3e-2 and psnr(out[b:b + 1], single) > 40.0, (b, rel)
+        assert rel < 1e-2 and psnr(out[b:b + 1], single) > 40.0, (b, rel)
     assert np.abs(out[0] - out[2]).max() > 1e-2 * np.abs(out[0]).max()            # the requests really are different edits
+    # an ORACLE number at batch 8: the first denoise step of request 3 (strength 1.2) INSIDE the per-request batch against
+    # the CPU oracle on that request's own inputs (the reference runs one edit per call)
+    trace = []
+    eng(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=strengths, trace=trace,
+        num_inference_steps=1, guidance_scale=7.5)
+    b = 3
+    from blobctrl_amd.schedulers import UniPCTable
+    tab = UniPCTable()
+    tab.set_timesteps(1)
+    inp_b = dict(prompt=torch.cat([neg[b:b + 1], pos[b:b + 1]]), fg=fg[b:b + 1], bg=bg[b:b + 1], dino=dino[b:b + 1])
+    ref = _oracle_eps(full, lat[b:b + 1], tab.timesteps[0], inp_b, score[b:b + 1], 7.5, strengths[b]).numpy()
+    got = trace[0][0][b:b + 1].cpu().numpy()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"C3 request {b} inside the batch of 8 vs the CPU oracle: guided eps max-abs/scale {rel:.3e}, PSNR {psnr(got, ref):.1f} dB")
+    assert rel < 1e-2 and psnr(got, ref) > 40.0
 
 
 def test_c5_768_single_step_vs_oracle(full):
@@ -158,6 +173,28 @@ def test_c5_768_single_step_vs_oracle(full):
     rel = np.abs(got - ref).max() / np.abs(ref).max()
     print(f"768^2 step: eps max-abs/scale {rel:.3e}, PSNR {psnr(got, ref):.1f} dB")
     assert rel < 1e-2 and psnr(got, ref) > 40.0
+    # configs[4] at its batch size: four variations (four noise tensors) of the edit in one launch; sample 2 of the batch-4 step
+    # against the same oracle evaluated on that sample's latents
+    inp4 = bench.synth_inputs(h, w, batch=4)
+    trace = []
+    eng(inp4["prompt"], inp4["fg"], inp4["bg"], score, inp4["dino"], num_inference_steps=1, guidance_scale=7.5, latents=inp4["latents"],
+        trace=trace)
+    k = 2
+    inp_k = dict(inp4, prompt=torch.cat([inp4["prompt"][k:k + 1], inp4["prompt"][4 + k:5 + k]]))
+    ref = _oracle_eps(full, inp4["latents"][k:k + 1], tab.timesteps[0], inp_k, score, 7.5).numpy()
+    got = trace[0][0][k:k + 1].cpu().numpy()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    # as in the 50-step teacher-forced test: the guided eps (CFG multiplies a difference of two fp16 branch outputs by 7.5) is held to
+    # 2e-2 / 40 dB, the LATENT after the step - the quantity the north star bounds - to 1e-2 / 40 dB
+    c = tab.table()[0].double()
+    x = inp4["latents"][k:k + 1].double()
+    step = lambda e: (c[7] * x + c[8] * (x * c[0] - e * c[1]) + c[10] * e).numpy()
+    xg, xr = step(torch.from_numpy(got).double()), step(torch.from_numpy(ref).double())
+    rel_x = np.abs(xg - xr).max() / np.abs(xr).max()
+    print(f"768^2 batch 4, sample {k}: eps max-abs/scale {rel:.3e}, PSNR {psnr(got, ref):.1f} dB | latents after the step {rel_x:.3e}, "
+          f"PSNR {psnr(xg, xr):.1f} dB")
+    assert rel < 2e-2 and psnr(got, ref) > 40.0
+    assert rel_x < 1e-2 and psnr(xg, xr) > 40.0
 
 
 GOLD_LOOP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loop_fullsize.npz")
