@@ -85,8 +85,8 @@ _SIGNATURES = {
     "bc_add_cls_pos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_rowchain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "bc_rowchain_stream_frags": (C.c_longlong, [C.c_int, C.c_int]),
-    "bc_rowchain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "bc_rowchain_stream_frags": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "bc_rowchain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                               C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     # ---- plan runtime (plan.hip)

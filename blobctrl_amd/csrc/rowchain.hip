@@ -29,19 +29,30 @@
 
 namespace {
 
-constexpr int RC_C = 320;              // channels
 constexpr int RC_BM = 64;              // rows per workgroup
-constexpr int RC_KS = RC_C / 32;       // k-steps of a K = C GEMM
-constexpr int RC_NT = RC_C / 64;       // 16-channel tiles per wave of an N = C GEMM (4 waves x 5 tiles x 16)
+constexpr int RC_NT = 5;               // 16-channel tiles per wave of an N = C GEMM: a wave owns 80 output channels
 constexpr int RC_HC = 128;             // feed-forward hidden chunk
-constexpr int RC_NCH = 4 * RC_C / RC_HC;
 constexpr int RC_RPAD = 20;            // padding fragments at the end of every wave's stream (>= the deepest ring)
-// weight ring depth R (template parameter): 16 for IN / MID, 15 for OUT (a feed-forward chunk must consume a whole number of rings):
-constexpr int RC_R_UNUSED = 20;        // weight ring: fragments (1 KiB per wave) in flight ahead of the MFMAs (80 KiB per CU:
-                                       // at ~1 us of L2 / HBM latency that is what the per-CU fetch rate of ~70 GB/s needs in flight)
-constexpr int RC_X_BYTES = RC_KS * 4096;
-constexpr int RC_S_BYTES = RC_BM * RC_C * 2;
-constexpr int RC_LDS = RC_X_BYTES + RC_S_BYTES;
+// Ring depth R (fragments of 1 KiB per wave in flight ahead of the MFMAs): 14 for IN, 16 for MID, 15 for OUT (a feed-forward chunk
+// must consume a whole number of rings): 56-64 KiB per 4 waves in flight, what ~70 GB/s per CU needs at ~1 us of L2 / HBM latency.
+
+// Channel count C in {320, 640}: C / 80 waves (4 / 8), 64 rows per workgroup either way.
+template <int C>
+struct RCfg {
+    static constexpr int NW = C / 80;                  // waves
+    static constexpr int NTH = 64 * NW;                // threads
+    static constexpr int KS = C / 32;                  // k-steps of a K = C GEMM
+    static constexpr int NCH = 4 * C / RC_HC;          // feed-forward hidden chunks
+    static constexpr int HW_ = RC_HC / NW;             // hidden units of a chunk per wave (32 / 16)
+    static constexpr int TP = HW_ / 16;                // (value tile, gate tile) passes per chunk and wave (2 / 1)
+    static constexpr int X_BYTES = KS * 4096;
+    static constexpr int S_BYTES = RC_BM * C * 2;
+    static constexpr int LDS = X_BYTES + S_BYTES;
+    static constexpr int ROWS_PASS = NTH / 8;          // rows one pass of the copy threads covers (32 / 64)
+    static constexpr int NPASS = RC_BM / ROWS_PASS;    // 2 / 1
+    static constexpr int NKC = C / 64;                 // 16-byte chunks per row and thread (5 / 10)
+    static constexpr int G = RC_NT * KS;               // weight fragments of one N = C GEMM per wave
+};
 
 struct RowChainArgs {
     int kind, M, rows_per_batch;
@@ -142,13 +153,14 @@ __device__ __forceinline__ void zero_acc(f32x4v (&acc)[NT][4]) {
 // ---- LDS images -----------------------------------------------------------------------------------------------------------------
 // X / P operand image: [k-step][row][32 k]: byte offset of the 16-byte chunk kc (0..3) of `row` in k-step s
 __device__ __forceinline__ int x_off(int s, int row, int kc) { return s * 4096 + row * 64 + ((kc ^ ((0 - ((row & 15) >> 2)) & 3)) << 4); }
-// S staging image: [row][320] fp16, 8-byte units XOR-swizzled by ((row >> 1) & 7)
+// S staging image: [row][C] fp16, 8-byte units XOR-swizzled by ((row >> 1) & 7)
+template <int RC_C>
 __device__ __forceinline__ int s_off8(int row, int unit) { return row * (RC_C * 2) + ((unit ^ ((row >> 1) & 7)) << 3); }
 
 __device__ __forceinline__ uint4 swap_halves(uint4 d) { return make_uint4(d.z, d.w, d.x, d.y); }
 
 // ---- coalesced 16-byte copies between global rows and the LDS images ------------------------------------------------------------------
-// Thread (v8 = tid & 7, r5 = tid >> 3) moves the chunks v = v8 + 8 k (k < 5) of the rows r5 + 32 j (j < 2): the swizzles depend on row
+// Thread (v8 = tid & 7, r = tid >> 3) moves the chunks v = v8 + 8 k (k < C / 64) of the rows r + ROWS_PASS j: the swizzles depend on row
 // bits 1..3 only, so every address is a per-thread base plus a compile-time offset (an idx / 40 mapping made the compiler keep twenty
 // 64-bit addresses alive across the whole kernel - spills).
 struct CopyMap {
@@ -156,6 +168,7 @@ struct CopyMap {
     int s_base, x_base;
 };
 
+template <int RC_C>
 __device__ __forceinline__ CopyMap copy_map(int tid) {
     CopyMap c;
     c.row = tid >> 3;
@@ -167,48 +180,51 @@ __device__ __forceinline__ CopyMap copy_map(int tid) {
 }
 
 // global rows [64][C] (ld = C) -> S; rows whose pixel x < xmin are staged as zeros when `masked`
+template <int RC_C>
 __device__ __forceinline__ void rows_to_S(const h16* __restrict__ src, char* S, const CopyMap& c, bool masked = false, int pix0 = 0,
                                           int out_w = 1, int xmin = 0) {
     const h16* g = src + (size_t)c.row * RC_C + c.v8 * 8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool zero = masked && ((pix0 + c.row + 32 * j) % out_w) < xmin;
+    for (int j = 0; j < RCfg<RC_C>::NPASS; ++j) {
+        const bool zero = masked && ((pix0 + c.row + RCfg<RC_C>::ROWS_PASS * j) % out_w) < xmin;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            uint4 d = *reinterpret_cast<const uint4*>(g + j * 32 * RC_C + k * 64);
+        for (int k = 0; k < RCfg<RC_C>::NKC; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(g + j * RCfg<RC_C>::ROWS_PASS * RC_C + k * 64);
             if (zero) d = make_uint4(0u, 0u, 0u, 0u);
             if (c.sw & 1) d = swap_halves(d);
-            *reinterpret_cast<uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128) = d;
+            *reinterpret_cast<uint4*>(S + c.s_base + j * RCfg<RC_C>::ROWS_PASS * RC_C * 2 + k * 128) = d;
         }
     }
 }
 
 // S -> global rows (row stride ld elements)
+template <int RC_C>
 __device__ __forceinline__ void S_to_rows(h16* __restrict__ dst, int ld, const char* S, const CopyMap& c) {
     h16* g = dst + (size_t)c.row * ld + c.v8 * 8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RCfg<RC_C>::NPASS; ++j)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128);
+        for (int k = 0; k < RCfg<RC_C>::NKC; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * RCfg<RC_C>::ROWS_PASS * RC_C * 2 + k * 128);
             if (c.sw & 1) d = swap_halves(d);
-            *reinterpret_cast<uint4*>(g + (size_t)j * 32 * ld + k * 64) = d;
+            *reinterpret_cast<uint4*>(g + (size_t)j * RCfg<RC_C>::ROWS_PASS * ld + k * 64) = d;
         }
 }
 
 // global rows -> X operand image, optionally through the per-(image, channel) GroupNorm affine y = a x + b
+template <int RC_C>
 __device__ __forceinline__ void rows_to_X(const h16* __restrict__ src, char* X, const CopyMap& c, const float* __restrict__ ab) {
     const h16* g = src + (size_t)c.row * RC_C + c.v8 * 8;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < RCfg<RC_C>::NKC; ++k) {
         float4 a4[4];
         if (ab) {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) a4[j4] = reinterpret_cast<const float4*>(ab + (c.v8 + 8 * k) * 16)[j4];   // (a, b) of 8 channels
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint4 d = *reinterpret_cast<const uint4*>(g + j * 32 * RC_C + k * 64);
+        for (int j = 0; j < RCfg<RC_C>::NPASS; ++j) {
+            uint4 d = *reinterpret_cast<const uint4*>(g + j * RCfg<RC_C>::ROWS_PASS * RC_C + k * 64);
             if (ab) {
                 h16* e = reinterpret_cast<h16*>(&d);
 #pragma unroll
@@ -217,20 +233,21 @@ __device__ __forceinline__ void rows_to_X(const h16* __restrict__ src, char* X, 
                     e[2 * j4 + 1] = (h16)fmaf((float)e[2 * j4 + 1], a4[j4].z, a4[j4].w);
                 }
             }
-            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * 32 * 64) = d;
+            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * RCfg<RC_C>::ROWS_PASS * 64) = d;
         }
     }
 }
 
 // S -> X (the block output as the zero-conv's operand)
+template <int RC_C>
 __device__ __forceinline__ void S_to_X(const char* S, char* X, const CopyMap& c) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RCfg<RC_C>::NPASS; ++j)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * 32 * RC_C * 2 + k * 128);
+        for (int k = 0; k < RCfg<RC_C>::NKC; ++k) {
+            uint4 d = *reinterpret_cast<const uint4*>(S + c.s_base + j * RCfg<RC_C>::ROWS_PASS * RC_C * 2 + k * 128);
             if (c.sw & 1) d = swap_halves(d);
-            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * 32 * 64) = d;
+            *reinterpret_cast<uint4*>(X + c.x_base + k * 2 * 4096 + j * RCfg<RC_C>::ROWS_PASS * 64) = d;
         }
 }
 
@@ -238,7 +255,7 @@ __device__ __forceinline__ h16x4 pack4(const float (&v)[4]) { return (h16x4){(h1
 
 // ---- epilogues on the swapped accumulator layout: acc[t][mt][r] = (channel 80w + 16t + 4q + r, row 16mt + m) ----------------------
 // acc += bias (+ the fp16 rows staged in S when RES)
-template <bool RES>
+template <int RC_C, bool RES>
 __device__ __forceinline__ void epi_bias_res(f32x4v (&acc)[RC_NT][4], const float* __restrict__ bias, const char* S, int wave, int m, int q) {
 #pragma unroll
     for (int t = 0; t < RC_NT; ++t) {
@@ -248,7 +265,7 @@ __device__ __forceinline__ void epi_bias_res(f32x4v (&acc)[RC_NT][4], const floa
         for (int mt = 0; mt < 4; ++mt) {
             acc[t][mt][0] += b.x; acc[t][mt][1] += b.y; acc[t][mt][2] += b.z; acc[t][mt][3] += b.w;
             if (RES) {
-                const h16x4 rr = *reinterpret_cast<const h16x4*>(S + s_off8(16 * mt + m, c0 >> 2));
+                const h16x4 rr = *reinterpret_cast<const h16x4*>(S + s_off8<RC_C>(16 * mt + m, c0 >> 2));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][mt][r] += (float)rr[r];
             }
@@ -257,6 +274,7 @@ __device__ __forceinline__ void epi_bias_res(f32x4v (&acc)[RC_NT][4], const floa
 }
 
 // acc (scaled) -> fp16 -> S
+template <int RC_C>
 __device__ __forceinline__ void acc_to_S(const f32x4v (&acc)[RC_NT][4], char* S, int wave, int m, int q, float scale = 1.0f) {
 #pragma unroll
     for (int t = 0; t < RC_NT; ++t) {
@@ -264,7 +282,7 @@ __device__ __forceinline__ void acc_to_S(const f32x4v (&acc)[RC_NT][4], char* S,
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float v[4] = {acc[t][mt][0] * scale, acc[t][mt][1] * scale, acc[t][mt][2] * scale, acc[t][mt][3] * scale};
-            *reinterpret_cast<h16x4*>(S + s_off8(16 * mt + m, c0 >> 2)) = pack4(v);
+            *reinterpret_cast<h16x4*>(S + s_off8<RC_C>(16 * mt + m, c0 >> 2)) = pack4(v);
         }
     }
 }
@@ -284,10 +302,21 @@ __device__ __forceinline__ void acc_to_X(const f32x4v (&acc)[RC_NT][4], char* X,
 
 // LayerNorm over the 320 channels of every row (two passes, fp32), written as the next GEMM's operand image.  `gb` = gamma | beta.
 // Statistics cross the four waves through the head of X, which is free between the barriers below.
+template <int RC_C>
 __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], const float* __restrict__ gb, float eps, char* X, int wave,
                                                int m, int q) {
-    float* st = reinterpret_cast<float*>(X);                       // [2][64 rows][4 waves]
+    constexpr int NW = RCfg<RC_C>::NW;
+    float* st = reinterpret_cast<float*>(X);                       // [2][64 rows][NW waves]
     float mean[4], rstd[4];
+    auto row_total = [&](const float* p) {                          // sum of the NW per-wave partials of a row
+        float4 v = *reinterpret_cast<const float4*>(p);
+        float t = (v.x + v.y) + (v.z + v.w);
+        if (NW == 8) {
+            v = *reinterpret_cast<const float4*>(p + 4);
+            t += (v.x + v.y) + (v.z + v.w);
+        }
+        return t;
+    };
     lds_barrier();                                                  // every wave has left the k-loop that read X
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -296,13 +325,12 @@ __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], co
         for (int t = 0; t < RC_NT; ++t) s += (acc[t][mt][0] + acc[t][mt][1]) + (acc[t][mt][2] + acc[t][mt][3]);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (q == 0) st[(16 * mt + m) * 4 + wave] = s;
+        if (q == 0) st[(16 * mt + m) * NW + wave] = s;
     }
     lds_barrier();
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const float4 v = *reinterpret_cast<const float4*>(st + (16 * mt + m) * 4);
-        mean[mt] = ((v.x + v.y) + (v.z + v.w)) * (1.0f / RC_C);
+        mean[mt] = row_total(st + (16 * mt + m) * NW) * (1.0f / RC_C);
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < RC_NT; ++t)
@@ -313,14 +341,11 @@ __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], co
             }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (q == 0) st[256 + (16 * mt + m) * 4 + wave] = s;
+        if (q == 0) st[64 * NW + (16 * mt + m) * NW + wave] = s;
     }
     lds_barrier();
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const float4 v = *reinterpret_cast<const float4*>(st + 256 + (16 * mt + m) * 4);
-        rstd[mt] = __builtin_amdgcn_rsqf(((v.x + v.y) + (v.z + v.w)) * (1.0f / RC_C) + eps);
-    }
+    for (int mt = 0; mt < 4; ++mt) rstd[mt] = __builtin_amdgcn_rsqf(row_total(st + 64 * NW + (16 * mt + m) * NW) * (1.0f / RC_C) + eps);
     lds_barrier();                                                  // statistics consumed: X may be overwritten
 #pragma unroll
     for (int t = 0; t < RC_NT; ++t) {
@@ -337,13 +362,14 @@ __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], co
 }
 
 // per-channel (sum, sum of squares) of the fp16 rows in S over the 64 rows: the consumer's GroupNorm statistics
+template <int RC_C>
 __device__ __forceinline__ void gn_partials_from_S(const char* S, float* __restrict__ dst, int tid) {
     if (tid < RC_C / 2) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
         const int unit = tid >> 1, half = tid & 1;
 #pragma unroll 8
         for (int row = 0; row < RC_BM; ++row) {
-            const h16x2 v = *reinterpret_cast<const h16x2*>(S + s_off8(row, unit) + half * 4);
+            const h16x2 v = *reinterpret_cast<const h16x2*>(S + s_off8<RC_C>(row, unit) + half * 4);
             const float a = (float)v[0], b = (float)v[1];
             s0 += a; q0 = fmaf(a, a, q0);
             s1 += b; q1 = fmaf(b, b, q1);
@@ -352,11 +378,13 @@ __device__ __forceinline__ void gn_partials_from_S(const char* S, float* __restr
     }
 }
 
-template <int KIND, bool BLOB>
-__global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) {
+template <int RC_C, int KIND, bool BLOB>
+__global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowChainArgs a) {
+    using CF = RCfg<RC_C>;
+    constexpr int RC_KS = CF::KS, RC_NCH = CF::NCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* X = smem;
-    char* S = smem + RC_X_BYTES;
+    char* S = smem + CF::X_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     const int pix0 = m0 - b * a.rows_per_batch;
     const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);        // this lane's fragment offset inside a (k-step, row-tile) KiB
     const float* vec = a.vec;
-    const CopyMap cm = copy_map(tid);
+    const CopyMap cm = copy_map<RC_C>(tid);
     unsigned long long* const stamps = a.stamps;
     unsigned long long acc_t[3] = {0, 0, 0};         // (OUT, diagnostics) ticks inside ff1 GEMMs / GEGLU epilogues / ff2 GEMMs
     auto stamp = [&](int i) {
@@ -374,7 +402,8 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     };
     stamp(0);
 
-    constexpr int RC_R = KIND == BC_CHAIN_OUT ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16);
+    constexpr int RC_R = RC_C == 320 ? (KIND == BC_CHAIN_OUT ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16))
+                                     : (KIND == BC_CHAIN_OUT ? 10 : (KIND == BC_CHAIN_IN ? 14 : 12));   // (8 waves: two per SIMD hide more latency)
     static_assert(RC_R <= RC_RPAD, "stream padding");
     WRing<RC_R> ring;
     ring.p = a.wstream + (size_t)wave * a.wave_frags * 64 + lane;
@@ -384,31 +413,31 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     zero_acc(acc);
 
     if (KIND == BC_CHAIN_IN) {
-        rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, a.affine ? a.affine + (size_t)b * RC_C * 2 : nullptr);
+        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, a.affine ? a.affine + (size_t)b * RC_C * 2 : nullptr);
         lds_barrier();
         stamp(1);
         // proj_in -> h0
         gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);
         stamp(2);
-        epi_bias_res<false>(acc, vec, S, wave, m, q);
-        layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        epi_bias_res<RC_C, false>(acc, vec, S, wave, m, q);
+        layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
         stamp(3);
-        acc_to_S(acc, S, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();                                                  // X = LN1(h0), S = h0
-        S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
+        S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
         // to_q | to_k: two passes of 320 columns
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
         lds_barrier();                                                  // S has been copied out by every thread
-        acc_to_S(acc, S, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();
-        S_to_rows(a.out1 + (size_t)m0 * 2 * RC_C, 2 * RC_C, S, cm);
+        S_to_rows<RC_C>(a.out1 + (size_t)m0 * 2 * RC_C, 2 * RC_C, S, cm);
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (2 * RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
         lds_barrier();
-        acc_to_S(acc, S, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();
-        S_to_rows(a.out1 + (size_t)m0 * 2 * RC_C + RC_C, 2 * RC_C, S, cm);
+        S_to_rows<RC_C>(a.out1 + (size_t)m0 * 2 * RC_C + RC_C, 2 * RC_C, S, cm);
         // to_v, written transposed: D[row][channel] (lane: 4 consecutive rows of one channel) -> S^T [channel][64 rows]
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (3 * RC_NT * RC_KS) % RC_R, false>(acc, ring, X + xfo);
@@ -428,10 +457,10 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
             h16* vt = a.out2 + ((size_t)b * RC_C + ch0) * a.ldvt + pix0 + part * 8;
             const char* sp = S + ch0 * 128 + ((part ^ (sw >> 1)) << 4);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {                             // channels ch0 + 32 i: the swizzle (ch & 15) keeps its low 4 bits
-                uint4 d = *reinterpret_cast<const uint4*>(sp + i * 32 * 128);
+            for (int i = 0; i < RC_C / CF::ROWS_PASS; ++i) {            // channels ch0 + ROWS_PASS i: the swizzle (ch & 15) keeps its low 4 bits
+                uint4 d = *reinterpret_cast<const uint4*>(sp + i * CF::ROWS_PASS * 128);
                 if (sw & 1) d = swap_halves(d);
-                *reinterpret_cast<uint4*>(vt + (size_t)i * 32 * a.ldvt) = d;
+                *reinterpret_cast<uint4*>(vt + (size_t)i * CF::ROWS_PASS * a.ldvt) = d;
             }
         }
         stamp(4);
@@ -439,48 +468,51 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     }
 
     // MID / OUT: X = attention output rows, S = the residual stream
-    rows_to_X(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
-    rows_to_S(a.res + (size_t)m0 * RC_C, S, cm);
+    rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
+    rows_to_S<RC_C>(a.res + (size_t)m0 * RC_C, S, cm);
     lds_barrier();
     stamp(1);
     gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);               // attn.to_out
     stamp(2);
-    epi_bias_res<true>(acc, vec, S, wave, m, q);                        // + bias + residual (own columns only: no barrier needed)
+    epi_bias_res<RC_C, true>(acc, vec, S, wave, m, q);                        // + bias + residual (own columns only: no barrier needed)
 
     if (KIND == BC_CHAIN_MID) {
-        layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
-        acc_to_S(acc, S, wave, m, q);
+        layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();
-        S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);           // h1
+        S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);           // h1
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);   // attn2.to_q
         lds_barrier();
-        acc_to_S(acc, S, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();
-        S_to_rows(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        S_to_rows<RC_C>(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
         stamp(4);
         return;
     }
 
     // ---- OUT: LayerNorm3 -> GEGLU feed-forward accumulated ON TOP of h2 (acc keeps the residual in fp32) ----
-    layernorm_to_X(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+    layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
     lds_barrier();
     stamp(3);
     {
-        const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][v0 g0 v1 g1][16]
+        const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][pass][value 16 | gate 16]
         constexpr int POS_FF = (RC_NT * RC_KS) % RC_R;
-        static_assert(KIND != BC_CHAIN_OUT || (4 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0, "a feed-forward chunk must consume a whole number of rings");
+        constexpr int TP = CF::TP, HPW = CF::HW_;                        // (value, gate) tile passes per chunk, hidden units per wave
+        static_assert(KIND != BC_CHAIN_OUT || (TP * 2 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0,
+                      "a feed-forward chunk must consume a whole number of rings");
         for (int c = 0; c < RC_NCH; ++c) {
             char* P = S + (c & 1) * 16384;
-            const float* bb = b1 + (c * 4 + wave) * 64 + 4 * q;
+            const float* bb = b1 + (c * CF::NW + wave) * (2 * HPW) + 4 * q;
             // (the chunk's GEGLU biases are fetched here, a GEMM pass ahead of their use: behind the pass's sched_barriers they cost
             //  an exposed L2 round trip per pass)
-            const float4 bvg[4] = {*reinterpret_cast<const float4*>(bb), *reinterpret_cast<const float4*>(bb + 16),
-                                   *reinterpret_cast<const float4*>(bb + 32), *reinterpret_cast<const float4*>(bb + 48)};
-            // ff.net.0.proj for this wave's 32 hidden units of the chunk, as two (value tile, gate tile) pairs: 32 accumulator
-            // registers instead of 64 (the block's 80 stay resident underneath)
+            float4 bvg[2 * TP];
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
+            for (int i = 0; i < 2 * TP; ++i) bvg[i] = *reinterpret_cast<const float4*>(bb + 16 * i);
+            // ff.net.0.proj for this wave's hidden units of the chunk in (value tile, gate tile) pairs: 32 accumulator registers per
+            // pass (the block's 80 stay resident underneath)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) {
                 f32x4v a1[2][4];
                 zero_acc(a1);
                 const unsigned long long ta = stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -489,18 +521,18 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
                 const unsigned long long tb = stamps ? __builtin_amdgcn_s_memtime() : 0;
                 acc_t[0] += tb - ta;
                 const float4 bv = bvg[2 * tp], bg = bvg[2 * tp + 1];
+                const int hc0 = HPW * wave + 16 * tp + 4 * q;           // hidden unit (inside the chunk) of this lane's first value
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const float v[4] = {(a1[0][mt][0] + bv.x) * bc_gelu_f(a1[1][mt][0] + bg.x), (a1[0][mt][1] + bv.y) * bc_gelu_f(a1[1][mt][1] + bg.y),
                                         (a1[0][mt][2] + bv.z) * bc_gelu_f(a1[1][mt][2] + bg.z), (a1[0][mt][3] + bv.w) * bc_gelu_f(a1[1][mt][3] + bg.w)};
-                    // hidden unit (inside the chunk) 32 wave + 16 tp + 4 q + r: k-step `wave`, chunk 2 tp + (q >> 1), half q & 1
-                    *reinterpret_cast<h16x4*>(P + x_off(wave, 16 * mt + m, 2 * tp + (q >> 1)) + (q & 1) * 8) = pack4(v);
+                    *reinterpret_cast<h16x4*>(P + x_off(hc0 >> 5, 16 * mt + m, (hc0 & 31) >> 3) + ((hc0 >> 2) & 1) * 8) = pack4(v);
                 }
                 if (stamps) acc_t[1] += __builtin_amdgcn_s_memtime() - tb;
             }
             lds_barrier();                                              // the chunk's 128 hidden columns are complete
             const unsigned long long tc = stamps ? __builtin_amdgcn_s_memtime() : 0;
-            gemm_seg<RC_NT, RC_HC / 32, (POS_FF + 4 * RC_KS) % RC_R, true>(acc, ring, P + xfo);
+            gemm_seg<RC_NT, RC_HC / 32, (POS_FF + TP * 2 * RC_KS) % RC_R, true>(acc, ring, P + xfo);
             if (stamps) acc_t[2] += __builtin_amdgcn_s_memtime() - tc;
         }
     }
@@ -519,10 +551,10 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
 #define q q_
 #define xfo xfo_
 #define cm cm_
-    epi_bias_res<false>(acc, vec + 3 * RC_C + 8 * RC_C, S, wave, m, q);  // + ff.net.2 bias -> h3
+    epi_bias_res<RC_C, false>(acc, vec + 3 * RC_C + 8 * RC_C, S, wave, m, q);  // + ff.net.2 bias -> h3
     lds_barrier();                                                      // every wave is done with the last hidden chunk (S) and with X
     acc_to_X(acc, X, wave, m, q);
-    rows_to_S(a.res2 + (size_t)m0 * RC_C, S, cm);
+    rows_to_S<RC_C>(a.res2 + (size_t)m0 * RC_C, S, cm);
     lds_barrier();
     zero_acc(acc);
     constexpr int POS_PO = (RC_NT * RC_KS) % RC_R;                      // (the feed-forward consumed whole rings)
@@ -530,36 +562,36 @@ __global__ __launch_bounds__(256, 2) void rowchain_kernel(const RowChainArgs a) 
     gemm_seg<RC_NT, RC_KS, POS_PO, true>(acc, ring, X + xfo);          // proj_out
     stamp(6);
     const float* bpo = vec + 3 * RC_C + 8 * RC_C + RC_C;
-    epi_bias_res<true>(acc, bpo, S, wave, m, q);                        // + bias + x
+    epi_bias_res<RC_C, true>(acc, bpo, S, wave, m, q);                        // + bias + x
     if (a.r2) {                                                          // + BlobNet residual on the right-hand part of the canvas
         const bool any = ((pix0 % a.out_w) + RC_BM > a.r2_xmin) || (pix0 % a.out_w) + RC_BM > a.out_w;
         if (any) {                                                       // (workgroup-uniform)
             lds_barrier();
-            rows_to_S(a.r2 + ((size_t)(b % a.r2_bmod) * a.rows_per_batch + pix0) * RC_C, S, cm, true, pix0, a.out_w, a.r2_xmin);
+            rows_to_S<RC_C>(a.r2 + ((size_t)(b % a.r2_bmod) * a.rows_per_batch + pix0) * RC_C, S, cm, true, pix0, a.out_w, a.r2_xmin);
             lds_barrier();
-            epi_bias_res<true>(acc, nullptr, S, wave, m, q);
+            epi_bias_res<RC_C, true>(acc, nullptr, S, wave, m, q);
         }
     }
     lds_barrier();
-    acc_to_S(acc, S, wave, m, q);
+    acc_to_S<RC_C>(acc, S, wave, m, q);
     lds_barrier();
-    S_to_rows(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
+    S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
     if (a.gn_part)
-        gn_partials_from_S(S, a.gn_part + ((size_t)b * (a.rows_per_batch / RC_BM) + pix0 / RC_BM) * RC_C * 2, tid);
+        gn_partials_from_S<RC_C>(S, a.gn_part + ((size_t)b * (a.rows_per_batch / RC_BM) + pix0 / RC_BM) * RC_C * 2, tid);
     stamp(7);
     if (BLOB) {
         // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
-        S_to_X(S, X, cm);
+        S_to_X<RC_C>(S, X, cm);
         lds_barrier();
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (POS_PO + RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
-        epi_bias_res<false>(acc, bpo + RC_C, S, wave, m, q);
+        epi_bias_res<RC_C, false>(acc, bpo + RC_C, S, wave, m, q);
         float alpha = a.alpha;
         if (a.alpha_dev) alpha *= a.alpha_dev[(a.alpha_idx ? *a.alpha_idx : 0) * (a.alpha_bstride > 0 ? a.alpha_bstride : 1) + (a.alpha_bstride > 0 ? b : 0)];
         lds_barrier();                                                  // S (block output) copied out and transposed into X by everyone
-        acc_to_S(acc, S, wave, m, q, alpha);
+        acc_to_S<RC_C>(acc, S, wave, m, q, alpha);
         lds_barrier();
-        S_to_rows(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        S_to_rows<RC_C>(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
     }
 #undef m
 #undef q
@@ -594,8 +626,9 @@ struct RcStampReport {
     }
 };
 
-template <int KIND, bool BLOB>
+template <int RC_C, int KIND, bool BLOB>
 int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
+    using CF = RCfg<RC_C>;
     RowChainArgs a = a_in;
     static const bool want_stamps = getenv("BC_RC_STAMPS") != nullptr;
     static unsigned long long* stamp_buf = nullptr;
@@ -608,36 +641,54 @@ int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
     }
     RcStampReport report{stream, nwg, a.stamps, KIND};
     static std::atomic<unsigned long long> lds_set{0};
-    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<KIND, BLOB>), RC_LDS));
-    hipLaunchKernelGGL((rowchain_kernel<KIND, BLOB>), dim3(a.M / RC_BM), dim3(256), RC_LDS, stream, a);
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<RC_C, KIND, BLOB>), CF::LDS));
+    hipLaunchKernelGGL((rowchain_kernel<RC_C, KIND, BLOB>), dim3(a.M / RC_BM), dim3(CF::NTH), CF::LDS, stream, a);
     BC_CHECK_LAUNCH();
     return 0;
+}
+
+template <int RC_C>
+long long stream_frags(int kind, int blobnet) {
+    using CF = RCfg<RC_C>;
+    const long long g = CF::G;
+    long long n = 0;
+    if (kind == BC_CHAIN_IN) n = 4 * g;
+    else if (kind == BC_CHAIN_MID) n = 2 * g;
+    else if (kind == BC_CHAIN_OUT) n = 2 * g + CF::NCH * (CF::TP * 2 * CF::KS + RC_NT * (RC_HC / 32)) + (blobnet ? g : 0);
+    else return -1;
+    return n + RC_RPAD;
+}
+
+template <int RC_C>
+int dispatch_chain(int kind, bool blob, const RowChainArgs& a, hipStream_t s) {
+    switch (kind) {
+        case BC_CHAIN_IN: return launch_chain<RC_C, BC_CHAIN_IN, false>(a, s);
+        case BC_CHAIN_MID: return launch_chain<RC_C, BC_CHAIN_MID, false>(a, s);
+        default: return blob ? launch_chain<RC_C, BC_CHAIN_OUT, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT, false>(a, s);
+    }
 }
 
 }  // namespace
 
 extern "C" int bc_rowchain_supported(int channels, int M, int rows_per_batch) {
-    return channels == RC_C && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0 && rows_per_batch % RC_BM == 0;
+    return (channels == 320 || channels == 640) && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0 && rows_per_batch % RC_BM == 0;
 }
 
-extern "C" long long bc_rowchain_stream_frags(int kind, int blobnet) {
-    // fragments (1 KiB per wave-instruction) of ONE wave's weight stream, incl. the ring's worth of padding at the end
-    const long long g = RC_NT * RC_KS;
-    long long n = 0;
-    if (kind == BC_CHAIN_IN) n = 4 * g;
-    else if (kind == BC_CHAIN_MID) n = 2 * g;
-    else if (kind == BC_CHAIN_OUT) n = 2 * g + RC_NCH * (4 * RC_KS + RC_NT * (RC_HC / 32)) + (blobnet ? g : 0);
-    else return -1;
-    return n + RC_RPAD;
+extern "C" long long bc_rowchain_stream_frags(int channels, int kind, int blobnet) {
+    // fragments (1 KiB per wave-instruction) of ONE wave's weight stream, incl. the padding at the end; -1: unsupported
+    if (channels == 320) return stream_frags<320>(kind, blobnet);
+    if (channels == 640) return stream_frags<640>(kind, blobnet);
+    return -1;
 }
 
-extern "C" int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
                            const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                            const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
                            float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream) {
-    BC_CHECK_ARG(bc_rowchain_supported(RC_C, M, rows_per_batch), "bc_rowchain: needs M %% rows_per_batch == 0 and rows_per_batch %% %d == 0 "
-                 "(M=%d rows_per_batch=%d)", RC_BM, M, rows_per_batch);
+    BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
+                 "rows_per_batch %% %d == 0 (channels=%d M=%d rows_per_batch=%d)", RC_BM, channels, M, rows_per_batch);
     BC_CHECK_ARG(x && wstream && vec && out0, "bc_rowchain: null pointer");
+    BC_CHECK_ARG(kind == BC_CHAIN_IN || kind == BC_CHAIN_MID || kind == BC_CHAIN_OUT, "bc_rowchain: unknown kind %d", kind);
     const bool blob = kind == BC_CHAIN_OUT && out1 != nullptr;
     RowChainArgs a;
     a.kind = kind; a.M = M; a.rows_per_batch = rows_per_batch;
@@ -645,26 +696,19 @@ extern "C" int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x
     a.res = reinterpret_cast<const h16*>(res); a.res2 = reinterpret_cast<const h16*>(res2);
     a.r2 = reinterpret_cast<const h16*>(r2); a.r2_xmin = r2_xmin; a.r2_bmod = r2_bmod > 0 ? r2_bmod : 1; a.out_w = out_w > 0 ? out_w : 1;
     a.wstream = reinterpret_cast<const uint4*>(wstream);
-    a.wave_frags = bc_rowchain_stream_frags(kind, blob ? 1 : 0);
+    a.wave_frags = bc_rowchain_stream_frags(channels, kind, blob ? 1 : 0);
     a.vec = vec;
     a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1); a.out2 = reinterpret_cast<h16*>(out2);
     a.ldvt = ldvt; a.gn_part = gn_part; a.ln_eps = ln_eps;
     a.alpha = alpha; a.alpha_dev = alpha_dev; a.alpha_idx = alpha_idx; a.alpha_bstride = alpha_bstride;
     a.stamps = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (kind) {
-        case BC_CHAIN_IN:
-            BC_CHECK_ARG(out1 && out2 && ldvt >= rows_per_batch && ldvt % 8 == 0, "bc_rowchain(IN): needs out1 (q|k), out2 (V^T) and ldvt >= rows_per_batch, ldvt %% 8 == 0");
-            return launch_chain<BC_CHAIN_IN, false>(a, s);
-        case BC_CHAIN_MID:
-            BC_CHECK_ARG(res && out1, "bc_rowchain(MID): needs res and out1");
-            return launch_chain<BC_CHAIN_MID, false>(a, s);
-        case BC_CHAIN_OUT:
-            BC_CHECK_ARG(res && res2, "bc_rowchain(OUT): needs res and res2");
-            BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT): r2 needs out_w dividing rows_per_batch");
-            return blob ? launch_chain<BC_CHAIN_OUT, true>(a, s) : launch_chain<BC_CHAIN_OUT, false>(a, s);
-        default:
-            BC_CHECK_ARG(false, "bc_rowchain: unknown kind %d", kind);
+    if (kind == BC_CHAIN_IN)
+        BC_CHECK_ARG(out1 && out2 && ldvt >= rows_per_batch && ldvt % 8 == 0, "bc_rowchain(IN): needs out1 (q|k), out2 (V^T) and ldvt >= rows_per_batch, ldvt %% 8 == 0");
+    if (kind == BC_CHAIN_MID) BC_CHECK_ARG(res && out1, "bc_rowchain(MID): needs res and out1");
+    if (kind == BC_CHAIN_OUT) {
+        BC_CHECK_ARG(res && res2, "bc_rowchain(OUT): needs res and res2");
+        BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT): r2 needs out_w dividing rows_per_batch");
     }
-    return 1;
+    return channels == 320 ? dispatch_chain<320>(kind, blob, a, s) : dispatch_chain<640>(kind, blob, a, s);
 }

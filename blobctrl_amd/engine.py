@@ -159,8 +159,14 @@ class TrunkPlan:
         return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2)
 
     def rowchain_ok(self, Cc, M, HW):
-        """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 channels, 64-row blocks inside one image."""
-        return not os.environ.get("BC_NO_ROWCHAIN") and bool(self.rec.lib.bc_rowchain_supported(Cc, M, HW))
+        """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 or 640 channels, 64-row blocks inside one image, and
+        enough row blocks for the price of the structure - every 64-row workgroup streams the block's WHOLE weight set (4.1 MB at 320
+        channels, 16.4 MB at 640) at the per-CU fetch rate: at 320 channels that pays from the first row block (the unfused list is
+        a dozen launches), at 640 only once the row blocks fill the device (256: batch 4 at 512^2, batch 2 at 768^2)."""
+        if os.environ.get("BC_NO_ROWCHAIN") or not self.rec.lib.bc_rowchain_supported(Cc, M, HW):
+            return False
+        min_blocks = {320: 1, 640: int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640", "256"))}[Cc]
+        return M // 64 >= min_blocks
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
         """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
@@ -186,7 +192,7 @@ class TrunkPlan:
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
         w, v = packed(_lib.CHAIN_IN)
-        rec.rowchain(_lib.CHAIN_IN, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, affine=ab)
+        rec.rowchain(_lib.CHAIN_IN, Cc, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, affine=ab)
         a = rec.empty(M, Cc)
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
                       scale, q_off=0, k_off=Cc)
@@ -194,7 +200,7 @@ class TrunkPlan:
         if pw.has_cross:
             h1, q2 = rec.empty(M, Cc), rec.empty(M, Cc)
             w, v = packed(_lib.CHAIN_MID)
-            rec.rowchain(_lib.CHAIN_MID, M, HW, a, w, v, h1, out1=q2, res=h0)
+            rec.rowchain(_lib.CHAIN_MID, Cc, M, HW, a, w, v, h1, out1=q2, res=h0)
             ck, cvt, T, ldc_vt = self.ctx_kv[bp]
             a = rec.empty(M, Cc)
             rec.attention(q2, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
@@ -213,7 +219,7 @@ class TrunkPlan:
             res_out = rec.empty(M, Cc)
             kw.update(out1=res_out, alpha=alpha, alpha_dev=alpha_dev, alpha_idx=alpha_idx, alpha_bstride=alpha_bstride)
         w, v = packed(_lib.CHAIN_OUT, zero[0] if zero is not None else None)
-        rec.rowchain(_lib.CHAIN_OUT, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
+        rec.rowchain(_lib.CHAIN_OUT, Cc, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
         rec.parts[out.data_ptr()] = (part, nslab)
         return Act(out, Cc, x.H, x.W), res_out
 

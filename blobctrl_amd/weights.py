@@ -194,41 +194,45 @@ class PackedTrunk:
 
 
 # ---------------------------------------------------------------------------------------------------------------- row-chain streams
-RC_C, RC_HC, RC_RING = 320, 128, 20          # mirrors csrc/rowchain.hip (RC_C, RC_HC, RC_R)
+RC_HC, RC_RPAD = 128, 20                     # mirrors csrc/rowchain.hip (RC_HC, RC_RPAD)
+RC_CHANNELS = (320, 640)                     # block widths rowchain.hip is instantiated for (C / 80 waves per 64-row workgroup)
 
 
 def _frag_stream(w: torch.Tensor, row_starts, k0: int = 0, k1: int = None) -> torch.Tensor:
-    """[N][K] fp16 matrix -> per-wave MFMA fragment stream [4 waves][KS * NT][64 lanes][8] for one GEMM segment of rowchain.hip.
+    """[N][K] fp16 matrix -> per-wave MFMA fragment stream [waves][KS * NT][64 lanes][8] for one GEMM segment of rowchain.hip.
     `row_starts[wave][tile]` = first of the 16 output rows of that wave's tile; lane l of a fragment holds
     W[row_start + (l & 15)][k0 + 32 s + 8 (l >> 4) : + 8] (the v_mfma_f32_16x16x32_f16 operand layout), k-step s outermost."""
     k1 = w.shape[1] if k1 is None else k1
-    rs = torch.as_tensor(row_starts, device=w.device)                       # [4][NT]
-    nt = rs.shape[1]
-    rows = rs[:, :, None] + torch.arange(16, device=w.device)               # [4][NT][16]
-    x = w[rows.reshape(-1), k0:k1].reshape(4, nt, 16, (k1 - k0) // 32, 4, 8)   # [wave][tile][m][s][q][8]
-    return x.permute(0, 3, 1, 4, 2, 5).reshape(4, -1, 64, 8).contiguous()   # [wave][s][tile][q][m][8] -> lane = 16 q + m
+    rs = torch.as_tensor(row_starts, device=w.device)                       # [waves][NT]
+    nw, nt = rs.shape
+    rows = rs[:, :, None] + torch.arange(16, device=w.device)               # [waves][NT][16]
+    x = w[rows.reshape(-1), k0:k1].reshape(nw, nt, 16, (k1 - k0) // 32, 4, 8)  # [wave][tile][m][s][q][8]
+    return x.permute(0, 3, 1, 4, 2, 5).reshape(nw, -1, 64, 8).contiguous()  # [wave][s][tile][q][m][8] -> lane = 16 q + m
 
 
 def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str] = None):
-    """Weights of one 320-channel Transformer2D block `p` (e.g. "down_blocks.0.attentions.0.") as rowchain.hip consumes them:
-    (wstream [4 waves][fragments][64][8] fp16 in exact consumption order + RC_RING fragments of padding, vec fp32).
+    """Weights of one 320- or 640-channel Transformer2D block `p` (e.g. "down_blocks.0.attentions.0.") as rowchain.hip consumes them:
+    (wstream [C / 80 waves][fragments][64][8] fp16 in exact consumption order + RC_RPAD fragments of padding, vec fp32).
     kind 0 IN: proj_in, to_q, to_k, to_v | vec = proj_in bias, norm1 gamma, norm1 beta
     kind 1 MID: attn1.to_out, attn2.to_q | vec = to_out bias, norm2 gamma, beta
-    kind 2 OUT: attnX.to_out, per 128-wide hidden chunk (ff.net.0.proj value / gate tiles, ff.net.2 K-slice), proj_out[, zero-conv]
-                | vec = to_out bias, norm3 gamma, beta, GEGLU bias per (chunk, wave, tile), ff.net.2 bias, proj_out bias[, zero-conv bias]
+    kind 2 OUT: attnX.to_out, per 128-wide hidden chunk (ff.net.0.proj (value, gate) tile pairs, ff.net.2 K-slice), proj_out[, zero-conv]
+                | vec = to_out bias, norm3 gamma, beta, GEGLU bias per (chunk, wave, pass: value 16 | gate 16), ff.net.2 bias, proj_out bias
+                [, zero-conv bias]
     Built on the device from the trunk's packed matrices (every rank builds its own: nothing to broadcast)."""
     h, f = pw.h, pw.f
     bp = p + "transformer_blocks.0."
-    C = RC_C
-    n320 = [[80 * w + 16 * t for t in range(5)] for w in range(4)]
+    C = h[p + "proj_in.weight"].shape[0]
+    assert C in RC_CHANNELS, C
+    nw = C // 80
+    nC = [[80 * w + 16 * t for t in range(5)] for w in range(nw)]
     segs, vec = [], []
     if kind == 0:
         qk = h[bp + "attn1.to_qk.weight"]
-        segs = [_frag_stream(h[p + "proj_in.weight"], n320), _frag_stream(qk[:C], n320), _frag_stream(qk[C:], n320),
-                _frag_stream(h[bp + "attn1.to_v.weight"], n320)]
+        segs = [_frag_stream(h[p + "proj_in.weight"], nC), _frag_stream(qk[:C], nC), _frag_stream(qk[C:], nC),
+                _frag_stream(h[bp + "attn1.to_v.weight"], nC)]
         vec = [f[p + "proj_in.bias"], f[bp + "norm1.weight"], f[bp + "norm1.bias"]]
     elif kind == 1:
-        segs = [_frag_stream(h[bp + "attn1.to_out.0.weight"], n320), _frag_stream(h[bp + "attn2.to_q.weight"], n320)]
+        segs = [_frag_stream(h[bp + "attn1.to_out.0.weight"], nC), _frag_stream(h[bp + "attn2.to_q.weight"], nC)]
         vec = [f[bp + "attn1.to_out.0.bias"], f[bp + "norm2.weight"], f[bp + "norm2.bias"]]
     else:
         att = "attn2" if pw.has_cross else "attn1"
@@ -240,20 +244,22 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
         bv, bg = b1[:, 0].reshape(hid), b1[:, 1].reshape(hid)
         w1o = torch.cat([wv, wg], 0)
         w2 = h[bp + "ff.net.2.weight"]
-        segs = [_frag_stream(h[bp + att + ".to_out.0.weight"], n320)]
+        segs = [_frag_stream(h[bp + att + ".to_out.0.weight"], nC)]
         ffb = []
+        hpw = RC_HC // nw                         # hidden units of a chunk per wave (32 / 16)
         for c in range(hid // RC_HC):
-            for tp in range(2):                   # two (value tile, gate tile) passes over K per chunk
-                segs.append(_frag_stream(w1o, [[RC_HC * c + 32 * w + 16 * tp, hid + RC_HC * c + 32 * w + 16 * tp] for w in range(4)]))
-            segs.append(_frag_stream(w2, n320, RC_HC * c, RC_HC * (c + 1)))
-            for w in range(4):
-                j0 = RC_HC * c + 32 * w
-                ffb += [bv[j0:j0 + 16], bg[j0:j0 + 16], bv[j0 + 16:j0 + 32], bg[j0 + 16:j0 + 32]]
-        segs.append(_frag_stream(h[p + "proj_out.weight"], n320))
+            for tp in range(hpw // 16):           # (value tile, gate tile) passes over K per chunk
+                segs.append(_frag_stream(w1o, [[RC_HC * c + hpw * w + 16 * tp, hid + RC_HC * c + hpw * w + 16 * tp] for w in range(nw)]))
+            segs.append(_frag_stream(w2, nC, RC_HC * c, RC_HC * (c + 1)))
+            for w in range(nw):
+                for tp in range(hpw // 16):
+                    j0 = RC_HC * c + hpw * w + 16 * tp
+                    ffb += [bv[j0:j0 + 16], bg[j0:j0 + 16]]
+        segs.append(_frag_stream(h[p + "proj_out.weight"], nC))
         vec = [f[bp + att + ".to_out.0.bias"], f[bp + "norm3.weight"], f[bp + "norm3.bias"], torch.cat(ffb), f[bp + "ff.net.2.bias"],
                f[p + "proj_out.bias"]]
         if zero_name is not None:
-            segs.append(_frag_stream(h[zero_name + ".weight"], n320))
+            segs.append(_frag_stream(h[zero_name + ".weight"], nC))
             vec.append(f[zero_name + ".bias"])
-    pad = torch.zeros(4, RC_RING, 64, 8, dtype=torch.float16, device=segs[0].device)
+    pad = torch.zeros(nw, RC_RPAD, 64, 8, dtype=torch.float16, device=segs[0].device)
     return torch.cat(segs + [pad], 1).contiguous(), torch.cat([v.reshape(-1).float() for v in vec]).contiguous()

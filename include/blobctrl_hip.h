@@ -243,7 +243,8 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Row-chain: everything of a Transformer2D block that acts on token rows independently, as ONE launch per attention
- * boundary (csrc/rowchain.hip).  Replaces, for 320-channel blocks (the 64 x 128 level of SD-1.5), the call sites
+ * boundary (csrc/rowchain.hip).  Replaces, for 320- and 640-channel blocks (the 64 x 128 and 32 x 64 levels of SD-1.5; C / 80 waves
+ * per 64-row workgroup), the call sites
  *   diffusers/src/diffusers/models/transformers/transformer_2d.py:479-527 (norm -> proj_in ... proj_out + residual),
  *   attention.py:421-541 (norm1/2/3, attn to_q / to_k / to_v / to_out, residual adds), activations.py:113-123 and
  *   attention.py:1161-1167 (GEGLU feed-forward), blobctrl/models/blobnet.py:860-864,921-924,936-938 (zero-conv x scale):
@@ -256,12 +257,14 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  *                 sum of squares of the fp16 output per 64-row slab; NULL: none).  With out1 != NULL (BlobNet) the block
  *                 output also goes through the zero-conv: out1 = (W out0 + b) * alpha * alpha_dev[*alpha_idx (* bstride + image)].
  * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
- * consumption order; bc_rowchain_stream_frags gives the length).  M % rows_per_batch == 0, rows_per_batch % 64 == 0.
+ * consumption order; bc_rowchain_stream_frags(channels, kind, blobnet) gives the length).  M % rows_per_batch == 0,
+ * rows_per_batch % 64 == 0.  Every workgroup streams the block's whole weight set (4.1 MB at 320 channels, 16.4 MB at 640): worth it
+ * when M / 64 workgroups fill the device (the engine takes the 640-channel form from 256 row blocks upwards).
  * --------------------------------------------------------------------------------------------------------------- */
 enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
-long long bc_rowchain_stream_frags(int kind, int blobnet);
-int bc_rowchain(int kind, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+long long bc_rowchain_stream_frags(int channels, int kind, int blobnet);
+int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
                 const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                 const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
                 float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream);

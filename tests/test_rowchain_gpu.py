@@ -12,29 +12,30 @@ from tests.common import g, psnr  # noqa: E402
 from tests.test_blocks_gpu import _act, _plan, _run  # noqa: E402
 
 
-def _block_sd(cross, seed, zero=False):
+def _block_sd(cross, seed, zero=False, C=320):
     from blobctrl_amd import synth
     from tests.common import block_param_shapes
-    sh = block_param_shapes("transformer", dict(C=320, ctx=768 if cross else None))
+    sh = block_param_shapes("transformer", dict(C=C, ctx=768 if cross else None))
     sd = synth.synth_state_dict(sh, seed)
     if zero:
-        sd["zero.weight"], sd["zero.bias"] = g(seed + 1, 320, 320, 1, 1) * 0.05, g(seed + 2, 320) * 0.1
+        sd["zero.weight"], sd["zero.bias"] = g(seed + 1, C, C, 1, 1) * 0.05, g(seed + 2, C) * 0.1
     return sd
 
 
-def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero):
+def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320):
+    monkeypatch.setenv("BC_ROWCHAIN_MIN_BLOCKS_640", "1")      # (the engine takes the 640-channel form only from 256 row blocks upwards)
     if fused:
         monkeypatch.delenv("BC_NO_ROWCHAIN", raising=False)
     else:
         monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
-    sd = _block_sd(cross, 77, zero)
+    sd = _block_sd(cross, 77, zero, C)
     rec, seg, plan = _plan("rc", sd, B, H, W, heads=8, cross=768 if cross else None)
-    x = g(5, B, 320, H, W) * 1.3 + 0.2
+    x = g(5, B, C, H, W) * 1.3 + 0.2
     if cross:
         plan.record_context(g(6, B, 7, 768).reshape(-1, 768).half().cuda(), 7)
     r2 = None
     if with_r2:
-        r2 = (g(7, 1, H * W, 320) * 0.7).half().cuda()
+        r2 = (g(7, 1, H * W, C) * 0.7).half().cuda()
         plan.res_bmod = 1
     zspec = None
     if zero:
@@ -45,19 +46,20 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero):
     if zero and pre is None:            # the unfused path leaves the zero-conv to the caller (engine._Feats.append)
         from blobctrl_amd import _lib
         M = B * H * W
-        pre = plan.dense(out.t, M, 320, "blk.zero", 320, kind="zero_conv", alpha=1.0, alpha_dev=zspec[2], alpha_idx=zspec[3],
+        pre = plan.dense(out.t, M, C, "blk.zero", C, kind="zero_conv", alpha=1.0, alpha_dev=zspec[2], alpha_idx=zspec[3],
                          alpha_bstride=0, rows_per_batch=H * W)
     part = rec.parts.get(out.t.data_ptr())
     _run(seg)
     return rec, out, pre, part
 
 
-@pytest.mark.parametrize("cross,B,H,W,with_r2,zero", [(True, 2, 16, 32, True, False), (True, 1, 8, 24, True, False),
-                                                      (False, 1, 16, 32, False, True), (False, 2, 8, 8, False, True),
-                                                      (True, 2, 8, 8, True, False)])
-def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero):
-    _, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero)
-    _, out_u, pre_u, _ = _record(monkeypatch, False, cross, B, H, W, with_r2, zero)
+@pytest.mark.parametrize("cross,B,H,W,with_r2,zero,C", [(True, 2, 16, 32, True, False, 320), (True, 1, 8, 24, True, False, 320),
+                                                        (False, 1, 16, 32, False, True, 320), (False, 2, 8, 8, False, True, 320),
+                                                        (True, 2, 8, 8, True, False, 320), (True, 2, 16, 32, True, False, 640),
+                                                        (False, 1, 8, 24, False, True, 640), (True, 1, 8, 8, True, False, 640)])
+def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C):
+    _, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C)
+    _, out_u, pre_u, _ = _record(monkeypatch, False, cross, B, H, W, with_r2, zero, C)
     a, b = out_f.t.float().cpu().numpy(), out_u.t.float().cpu().numpy()
     rel = np.abs(a - b).max() / np.abs(b).max()
     print(f"row-chain vs unfused block output: max-abs/scale {rel:.3e}, PSNR {psnr(a, b):.1f} dB")
@@ -71,7 +73,7 @@ def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2
     part, nslab = part_f
     assert nslab == H * W // 64
     s = part.float().cpu().sum(1)
-    o = out_f.t.float().cpu().view(B, H * W, 320)
+    o = out_f.t.float().cpu().view(B, H * W, C)
     assert torch.allclose(s[..., 0], o.sum(1), rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
     assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
 
@@ -79,6 +81,7 @@ def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2
 def test_rowchain_rejects_unsupported_shapes():
     from blobctrl_amd import _lib
     lib = _lib.load()
-    assert lib.bc_rowchain_supported(320, 2 * 8192, 8192) == 1
-    assert lib.bc_rowchain_supported(640, 4096, 2048) == 0 and lib.bc_rowchain_supported(320, 96, 96) == 0
-    assert lib.bc_rowchain_stream_frags(0, 0) == 220 and lib.bc_rowchain_stream_frags(2, 1) == 770
+    assert lib.bc_rowchain_supported(320, 2 * 8192, 8192) == 1 and lib.bc_rowchain_supported(640, 4096, 2048) == 1
+    assert lib.bc_rowchain_supported(1280, 1024, 512) == 0 and lib.bc_rowchain_supported(320, 96, 96) == 0
+    assert lib.bc_rowchain_stream_frags(320, 0, 0) == 220 and lib.bc_rowchain_stream_frags(320, 2, 1) == 770
+    assert lib.bc_rowchain_stream_frags(640, 1, 0) == 220 and lib.bc_rowchain_stream_frags(640, 2, 0) == 1420
