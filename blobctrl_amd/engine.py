@@ -161,11 +161,13 @@ class TrunkPlan:
     def rowchain_ok(self, Cc, M, HW):
         """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 or 640 channels, 64-row blocks inside one image, and
         enough row blocks for the price of the structure - every 64-row workgroup streams the block's WHOLE weight set (4.1 MB at 320
-        channels, 16.4 MB at 640) at the per-CU fetch rate: at 320 channels that pays from the first row block (the unfused list is
-        a dozen launches), at 640 only once the row blocks fill the device (256: batch 4 at 512^2, batch 2 at 768^2)."""
+        channels, 16.4 MB at 640) at the per-CU fetch rate.  At 320 channels that pays from the first row block.  At 640 channels a
+        workgroup needs ~234 us whatever the batch; measured in the step at batch 1 (same box, two rounds): the UNet's 32 x 64 level
+        (64 row blocks on 64 CUs, the other 192 left to the BlobNet branch) 10.485 -> 10.29 ms, BlobNet's too (32 row blocks) 10.40
+        - hence from 64 row blocks upwards."""
         if os.environ.get("BC_NO_ROWCHAIN") or not self.rec.lib.bc_rowchain_supported(Cc, M, HW):
             return False
-        min_blocks = {320: 1, 640: int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640", "256"))}[Cc]
+        min_blocks = {320: 1, 640: int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640", "64"))}[Cc]
         return M // 64 >= min_blocks
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):

@@ -259,7 +259,7 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
  * consumption order; bc_rowchain_stream_frags(channels, kind, blobnet) gives the length).  M % rows_per_batch == 0,
  * rows_per_batch % 64 == 0.  Every workgroup streams the block's whole weight set (4.1 MB at 320 channels, 16.4 MB at 640): worth it
- * when M / 64 workgroups fill the device (the engine takes the 640-channel form from 256 row blocks upwards).
+ * from a few dozen row blocks upwards (the engine takes the 640-channel form from 64 row blocks).
  * --------------------------------------------------------------------------------------------------------------- */
 enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
