@@ -298,3 +298,55 @@ def test_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
     assert out["kernels_in_step"] == 6 and set(out["queues"]) == {"1", "2"}
     assert out["queues"]["1"]["kernels"] == 4 and abs(out["queues"]["1"]["busy_us"] - 32.0) < 1e-6
     assert out["queues"]["2"]["busy_us"] == 16.0 and out["two_or_more_running_us"] > 0
+
+
+@pytest.mark.parametrize("C", [320, 640])
+def test_rowchain_weight_streams_follow_the_kernels_consumption_order(C):
+    """weights.pack_rowchain (host side of csrc/rowchain.hip): per wave ONE linear stream of 1-KiB MFMA fragments in the order the
+    kernel consumes them; lane l of fragment (k-step s, tile t) holds W[row0(wave, t) + (l & 15)][32 s + 8 (l >> 4) : + 8]; the
+    feed-forward section interleaves, per 128-wide hidden chunk, the (value tile, gate tile) passes of ff.net.0.proj with the K-slice
+    of ff.net.2; lengths match bc_rowchain_stream_frags (checked against the library in tests/test_rowchain_gpu.py)."""
+    import torch
+    from blobctrl_amd import synth, weights
+    boc = (C, 2 * C)
+    sd = synth.synth_state_dict(synth.trunk_param_shapes(4 + 1 + 3, boc, 1, None, None, blobnet=True), 3)
+    pw = weights.PackedTrunk(sd, "cpu", boc, 1)
+    p, bp = "down_blocks.0.attentions.0.", "down_blocks.0.attentions.0.transformer_blocks.0."
+    nw, ks = C // 80, C // 32
+    g = 5 * ks
+    w_in, v_in = weights.pack_rowchain(pw, p, 0)
+    assert tuple(w_in.shape) == (nw, 4 * g + weights.RC_RPAD, 64, 8) and v_in.numel() == 3 * C
+    qk = pw.h[bp + "attn1.to_qk.weight"]
+    mats = [pw.h[p + "proj_in.weight"], qk[:C], qk[C:], pw.h[bp + "attn1.to_v.weight"]]
+    rng = np.random.Generator(np.random.PCG64(1))
+    for _ in range(200):
+        seg, wave, s, t, lane = rng.integers(4), rng.integers(nw), rng.integers(ks), rng.integers(5), rng.integers(64)
+        frag = w_in[wave, seg * g + s * 5 + t, lane]
+        ref = mats[seg][80 * wave + 16 * t + (lane & 15), 32 * s + 8 * (lane >> 4): 32 * s + 8 * (lane >> 4) + 8]
+        assert torch.equal(frag, ref)
+    assert float(w_in[:, 4 * g:].abs().max()) == 0.0                      # ring padding
+    assert torch.equal(v_in[:C], pw.f[p + "proj_in.bias"]) and torch.equal(v_in[C:2 * C], pw.f[bp + "norm1.weight"])
+    # OUT chain of a BlobNet block (no cross-attention: attn1.to_out) with its zero-conv
+    w_o, v_o = weights.pack_rowchain(pw, p, 2, "blobnet_down_blocks.1")
+    hpw, tp, nch = 128 // nw, (128 // nw) // 16, 4 * C // 128
+    per_chunk = tp * 2 * ks + 5 * 4
+    assert per_chunk == 60 and w_o.shape[1] == 2 * g + nch * per_chunk + g + weights.RC_RPAD
+    sdw1, sdw2 = sd[bp + "ff.net.0.proj.weight"].half(), sd[bp + "ff.net.2.weight"].half()
+    for _ in range(200):
+        c, wave, lane = rng.integers(nch), rng.integers(nw), rng.integers(64)
+        base = g + c * per_chunk
+        ps, s, vg = rng.integers(tp), rng.integers(ks), rng.integers(2)      # ff.net.0.proj pass `ps`: tile 0 = value rows, tile 1 = gate rows
+        j = 128 * c + hpw * wave + 16 * ps + (lane & 15)
+        ref = sdw1[(4 * C if vg else 0) + j, 32 * s + 8 * (lane >> 4): 32 * s + 8 * (lane >> 4) + 8]
+        assert torch.equal(w_o[wave, base + ps * 2 * ks + s * 2 + vg, lane], ref)
+        s2, t = rng.integers(4), rng.integers(5)                             # ff.net.2: K-slice of the chunk
+        k0 = 128 * c + 32 * s2 + 8 * (lane >> 4)
+        assert torch.equal(w_o[wave, base + tp * 2 * ks + s2 * 5 + t, lane], sdw2[80 * wave + 16 * t + (lane & 15), k0:k0 + 8])
+    # fp32 vector: to_out bias, norm3 gamma / beta, GEGLU bias per (chunk, wave, pass: value 16 | gate 16), ff.net.2 bias, proj_out bias, zero-conv bias
+    assert v_o.numel() == 3 * C + 8 * C + 3 * C
+    b1 = sd[bp + "ff.net.0.proj.bias"]
+    c, wave, ps = 3, nw - 1, tp - 1
+    off = 3 * C + ((c * nw + wave) * tp + ps) * 32
+    j0 = 128 * c + hpw * wave + 16 * ps
+    assert torch.equal(v_o[off:off + 16], b1[j0:j0 + 16]) and torch.equal(v_o[off + 16:off + 32], b1[4 * C + j0:4 * C + j0 + 16])
+    assert torch.equal(v_o[-C:], sd["blobnet_down_blocks.1.bias"])
