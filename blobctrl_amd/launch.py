@@ -209,10 +209,12 @@ class Recorder:
     def signal(self, ev):
         """Record `ev` on the stream currently being recorded for."""
         self._add_op(_lib.OP_SIGNAL, "i", (ev,), "event_record")
+        self.seg.meta[-1]["ev"] = ev
 
     def wait(self, ev):
         """Make the stream currently being recorded for wait on `ev`."""
         self._add_op(_lib.OP_WAIT, "i", (ev,), "event_wait")
+        self.seg.meta[-1]["ev"] = ev
 
     def _add_op(self, op, sig, args, kind, flops=0, variant="", shape=None, bytes_=0):
         assert len(sig) == len(args), (op, sig, args)

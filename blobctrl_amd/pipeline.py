@@ -58,10 +58,11 @@ class BlobCtrlEngine:
             PackedTrunk(blobnet_state_dict, self.device, blobnet_config.block_out_channels)
         self.scheduler_kind = scheduler
         self.scheduler_params = (1000, 0.00085, 0.012)               # (num_train_timesteps, beta_start, beta_end): SD-1.5 values
-        self.use_graphs = use_graphs
+        self.use_graphs = use_graphs and not os.environ.get("BC_NO_GRAPHS")    # diagnostics: eager launches from the host loop
         if self.device.type == "cuda":
-            self.stream = torch.cuda.Stream(device=self.device)
-            self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
+            prio = int(os.environ.get("BC_STREAM_PRIO", "0"))            # diagnostics: 1 = UNet stream high priority, 2 = BlobNet stream high
+            self.stream = torch.cuda.Stream(device=self.device, priority=-1 if prio == 1 else 0)
+            self.side_stream = torch.cuda.Stream(device=self.device, priority=-1 if prio == 2 else 0)   # BlobNet branch runs here, concurrently with the UNet
             self.side_stream2 = torch.cuda.Stream(device=self.device)    # (BC_SPLIT_CFG: the cond half of the UNet batch)
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
         self.loop_graph = os.environ.get("BC_LOOP_GRAPH", "1") != "0"     # whole-edit graph (one launch per edit) vs one graph per step

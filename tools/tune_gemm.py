@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--gn-penalty-us", type=float, default=0.0,
                     help="extra cost charged to split-K on convolutions (0: the split-K reducer emits the GroupNorm partials too)")
     ap.add_argument("--dump", default=None, help="also write EVERY candidate's time (us, cfg, splitk, workgroups) per shape to this JSON")
+    ap.add_argument("--only", default=None, help="regular expression on 'mode|M|N|K': measure these shapes only and MERGE them into --out")
     ap.add_argument("--cold", action="store_true", help="flush the caches before every timed launch (weights cold, activations warm)")
     args = ap.parse_args()
     os.environ["BC_NO_TUNING"] = "1"
@@ -113,6 +114,12 @@ def main():
     table, report, dump = {}, [], {}
     t0 = time.time()
     thrash = torch.zeros(160 * 1024 * 1024, dtype=torch.float32, device=dev) if args.cold else None      # 640 MB
+    if args.only:
+        import re
+        shapes = {k: v for k, v in shapes.items() if re.search(args.only, "|".join(str(x) for x in k))}
+        if os.path.exists(args.out):
+            with open(args.out) as f:
+                table.update(json.load(f).get("shapes", {}))
     for (mode, M, N, K), conv in sorted(shapes.items()):
         nk = K // 64
         if K % 64 or (conv and conv["Cin"] % 64):
