@@ -158,16 +158,20 @@ class TrunkPlan:
             sc = x
         return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2)
 
-    def rowchain_ok(self, Cc, M, HW):
+    def rowchain_ok(self, Cc, M, HW, p=""):
         """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 or 640 channels, 64-row blocks inside one image, and
         enough row blocks for the price of the structure - every 64-row workgroup streams the block's WHOLE weight set (4.1 MB at 320
         channels, 16.4 MB at 640) at the per-CU fetch rate.  At 320 channels that pays from the first row block.  At 640 channels a
         workgroup needs ~234 us whatever the batch; measured in the step at batch 1 (same box, two rounds): the UNet's 32 x 64 level
         (64 row blocks on 64 CUs, the other 192 left to the BlobNet branch) 10.485 -> 10.29 ms, BlobNet's too (32 row blocks) 10.40
-        - hence from 64 row blocks upwards."""
+        - hence from 64 row blocks upwards.  Exception: BlobNet's UP blocks.  The UNet queue is the step's critical path and BlobNet
+        runs 1.1 - 1.6 ms ahead of it by the time it reaches its 640-channel up blocks (tools/critical_path.py), so there the
+        32-workgroup form is the better neighbour even though it is the slower kernel: 10.43 -> 10.385 ms (same box, two rounds)."""
         if os.environ.get("BC_NO_ROWCHAIN") or not self.rec.lib.bc_rowchain_supported(Cc, M, HW):
             return False
         min_blocks = {320: 1, 640: int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640", "64"))}[Cc]
+        if Cc == 640 and self.cfg.is_blobnet and p.startswith("up_blocks"):
+            min_blocks = int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640_BLOB_UP", "32"))
         return M // 64 >= min_blocks
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
@@ -230,7 +234,7 @@ class TrunkPlan:
         rec, pw, B = self.rec, self.pw, self.B
         Cc, HW = x.C, x.H * x.W
         M = B * HW
-        if self.rowchain_ok(Cc, M, HW):
+        if self.rowchain_ok(Cc, M, HW, p):
             return self.transformer_rowchain(p, x, r2, zero)
         d = Cc // self.heads
         scale = d ** -0.5
