@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("BLOBCTRL_HIP_LIB") or os.path.join(_HERE, "libblobctr
 A_DENSE, A_CONV3X3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
-TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160"]
+TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160", "wreg128x160"]
 TILE_HALO = 8
+TILE_WREG = 9
 
 
 class BcGemm(C.Structure):
@@ -50,6 +51,7 @@ _SIGNATURES = {
                                C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bc_conv_halo_eligible": (C.c_int, [C.c_int] * 8),
     "bc_conv_halo_max_chunks": (C.c_int, []),
+    "bc_conv_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,574 @@
+// 3x3 / stride-1 / pad-1 convolution, LDS-resident input halo, WEIGHTS STREAMED STRAIGHT INTO VGPRs (gfx950, v_mfma_f32_16x16x32_f16).
+//
+// Same contract, tile (8 x 16 output pixels x 160 output channels per workgroup), halo staging (raw rows by LDS-DMA into their final
+// swizzled slots, in-place GroupNorm + SiLU pass, zero padding after the activation), split-K over 64-channel chunks and epilogue as
+// conv_halo.hip, which it replaces for the ResBlock convolutions (D/models/resnet.py:327-341, :351-366).  What changed is the main loop.
+// conv_halo.hip brings the weights of every tap in by LDS-DMA (20 KiB per tap and workgroup, one barrier per tap) and measures ~1500
+// cycles per tap against 640 cycles of MFMA: the LDS-DMA path of a CU delivers ~22 B/clk here (tools/wreg_probe.hip), the
+// ordinary global-load path more than twice that.  So:
+//   * the B operand never touches LDS: weights are pre-packed (bc_conv_wreg_pack / weights.pack_conv_wreg) into one CONTIGUOUS stream
+//     of 1-KiB MFMA fragments per wave - lane l of a fragment holds W[n0 + (l & 15)][k0 + 8 (l >> 4) .. + 8] - read with one
+//     global_load_dwordx4 per fragment into a register ring that runs a whole chunk (9 taps) ahead: 144-216 KiB in flight per CU;
+//   * 8 waves = 4 column groups of 3 | 2 | 2 | 3 MFMA column tiles x 2 K halves of each 64-channel chunk; wave w runs on SIMD w % 4, the
+//     groups are assigned so that every SIMD owns 5 tile columns (waves 0, 1, 6, 7 three tiles; 2 - 5 two): no weight byte is fetched
+//     twice and the matrix pipes are evenly loaded;
+//   * every wave covers all 8 pixel rows of the tile, so an A fragment (16 pixels of halo row r at x shift kx) serves the three taps
+//     (ky = 0..2) that read row r: 10 ds_read_b128 per kx group instead of 24, 0.4 LDS reads per MFMA;
+//   * one barrier per CHUNK: the halo images are triple-buffered; the four two-tile waves (which have matrix-pipe time to spare) issue
+//     the LDS-DMA of chunk c + 2 and run the in-place pass over chunk c + 1 while everybody multiplies chunk c.
+// LDS accesses of the loop are inline asm with counted lgkmcnt waits (hipcc would order plain LDS reads behind every LDS-DMA in
+// flight); the weight ring is plain C++ (the compiler counts vmcnt for it, the LDS-DMA of a wave is always older than the ring loads
+// that follow it, so "ring data arrived" implies "halo rows arrived").
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+#include "gemm_common.h"
+
+using namespace bcg;
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_line_w[4] = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+constexpr int TW = 16, TH = 8;
+constexpr int HBM = TW * TH;                    // 128 output pixels per workgroup
+constexpr int HBN = 160;                        // output channels per workgroup
+constexpr int HSTR = TW + 2;                    // halo row stride (pixels)
+constexpr int HPIX = (TH + 2) * HSTR;           // 180 halo pixels
+constexpr int HALO_BYTES = 24 * 1024;           // one 64-channel chunk of the halo: 192 pixel slots x 128 B (the last 12 are padding)
+constexpr int NBUF = 3;                         // halo images: multiplied | being transformed | landing
+constexpr int OFF_AB = NBUF * HALO_BYTES;
+constexpr int MAX_CH = 40;                      // channel chunks per workgroup (affine table: 512 B per chunk)
+constexpr int TS = HBN + 4;                     // epilogue tile row stride (floats)
+constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
+constexpr int LDS_LOOP = OFF_AB + MAX_CH * 512;
+constexpr int LDS_EPI = OFF_SCR + 24 * HBN * 2 * 4;
+constexpr int LDS_TOTAL = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES, "LDS budget");
+constexpr int FIN_MAX_CH = 720;                 // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
+
+template <int N>
+__device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+// AFFINE: 0 = plain convolution, 1 = affine table from global memory (bc_gn_finalize ran), 2 = GroupNorm finalize in the prologue
+template <int AFFINE>
+__global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BcGemm& p = g.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave & 1;                                      // K half of every chunk
+    const int grp = ((wave >> 1) & 1) | ((wave >> 2) << 1);       // column group <- waves {0,1} {2,3} {4,5} {6,7}
+    const bool three = grp == 0 || grp == 3;                      // 3 | 2 | 2 | 3 column tiles
+    const int tile0 = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 5 : 7;
+
+    const int plane = gridDim.x * gridDim.y;
+    const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
+    const int lin = lin3 % plane;
+    const int split = lin3 / plane;
+    const int tile = g.nband ? lin % (int)gridDim.y : lin / (int)gridDim.x;
+    const int ntile = g.nband ? lin / (int)gridDim.y : lin % (int)gridDim.x;
+    const int n0 = ntile * HBN;
+    const int b = tile / g.halo_tpi;
+    const int tin = tile - b * g.halo_tpi;
+    const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
+    const int H = p.Hin, W = p.Win;
+    const int c_begin = split * g.halo_cps;
+    const int nch = min(g.halo_nch, c_begin + g.halo_cps) - c_begin;
+
+    unsigned long long* const stamps = g.halo_stamps;        // BC_WREG_STAMPS diagnostics (null in production): waves 0 (three tiles) and 2 (staging)
+    auto stamp = [&](int i) {
+        if (stamps && lane == 0 && (wave == 0 || wave == 2))
+            stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + (wave >> 1)) * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    const h16* __restrict__ A1 = reinterpret_cast<const h16*>(p.A);
+    const h16* __restrict__ A2 = reinterpret_cast<const h16*>(p.A2);
+    const h16* zero = reinterpret_cast<const h16*>(g_zero_line_w);
+
+    // ---- staging duty (waves 2-5, 256 lanes): lane owns six 16-byte slots of every halo image: bytes [sidx * 16 + 4096 q, + 16) =
+    // halo pixel hp = (sidx >> 3) + 32 q, 16-byte slot sidx & 7.  The swizzle (chunk c lives in slot c ^ swz(hx)) is applied to the
+    // SOURCE address; the lane that brings a slot in by LDS-DMA is the lane that later normalises it in place.
+    const int sidx = ((wave >= 2 ? wave - 2 : 0) << 6) | lane;
+    int pixv[6], csubv[6];
+    unsigned in_halo = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int hp = (sidx >> 3) + 32 * q;
+        const int hy = hp / HSTR, hx = hp - hy * HSTR;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inh = hp < HPIX;
+        in_halo |= inh ? 1u << q : 0u;
+        const bool in_img = inh && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        pixv[q] = in_img ? (b * H + gy) * W + gx : -1;
+        csubv[q] = (sidx & 7) ^ (((hx >> 1) & 3) << 1);
+    }
+    // raw rows of chunk c_begin + cl -> halo image `buf` (staging waves only).  `valid` false: six reads of the zero line instead (the
+    // tail of the loop keeps the SAME number of memory operations per chunk: hipcc's vmcnt bookkeeping takes the minimum over the
+    // paths that join, so a conditional load anywhere in the loop makes every wait behind it stricter by its count)
+    auto issue_a = [&](int cl, int buf, bool valid) {
+        const int k0 = (c_begin + cl) * 64;
+        const bool second = A2 != nullptr && k0 >= p.C1;      // wave-uniform (C1 % 64 == 0)
+        const h16* src = second ? A2 : A1;
+        const int stride = second ? p.lda2 : p.lda;           // (element offsets fit 32 bits: checked by the launcher)
+        const int kin = second ? k0 - p.C1 : k0;
+        char* dst = smem + buf * HALO_BYTES + (wave - 2) * 1024;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int off = pixv[q] * stride + kin + csubv[q] * 8;
+            const h16* s = (valid && pixv[q] >= 0) ? src + off : zero;
+            glds16(s, dst + q * 4096);
+        }
+    };
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)(smem);
+    const unsigned slot_addr = lds0 + sidx * 16;
+    const unsigned ab_base = lds0 + OFF_AB;
+    struct Pending { u32x4v raw; f32x4v t0, t1, t2, t3; };
+    auto tr_issue = [&](auto qc, int cl, int buf, Pending& pd) {
+        constexpr int q = decltype(qc)::value;
+        const unsigned sa = slot_addr + buf * HALO_BYTES;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pd.raw) : "v"(sa), "n"(4096 * q) : "memory");
+        const unsigned ab_addr = ab_base + cl * 512 + csubv[q] * 64;     // (64 channels x (a, b) x 4 bytes per chunk)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                     "ds_read_b128 %3, %4 offset:48"
+                     : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
+    };
+    auto tr_finish = [&](auto qc, int buf, Pending& pd, auto waitc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int WAITN = decltype(waitc)::value;            // LDS operations issued after this slot's five reads
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3) : "n"(WAITN) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const float aa[8] = {pd.t0[0], pd.t0[2], pd.t1[0], pd.t1[2], pd.t2[0], pd.t2[2], pd.t3[0], pd.t3[2]};
+        const float bb[8] = {pd.t0[1], pd.t0[3], pd.t1[1], pd.t1[3], pd.t2[1], pd.t2[3], pd.t3[1], pd.t3[3]};
+        const u32x4v rawv = pd.raw;
+        const h16* xin = reinterpret_cast<const h16*>(&rawv);
+        u32x4v outraw;
+        h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = fmaf((float)xin[j], aa[j], bb[j]);
+            if (p.a_act == BC_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+            o[j] = (h16)v;
+        }
+        if (pixv[q] < 0) outraw = (u32x4v){0u, 0u, 0u, 0u};       // zero padding is applied AFTER norm + activation
+        const unsigned sa = slot_addr + buf * HALO_BYTES;
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(sa), "v"(outraw), "n"(4096 * q) : "memory");
+    };
+    // the in-place pass over three of this lane's six slots of chunk `cl` in image `buf`: all reads first, then the arithmetic
+    auto transform3 = [&](auto q0c, int cl, int buf) {
+        constexpr int q0 = decltype(q0c)::value;
+        Pending pa, pb, pc;
+        if (in_halo >> q0 & 1) tr_issue(IC<q0>{}, cl, buf, pa);
+        if (in_halo >> (q0 + 1) & 1) tr_issue(IC<q0 + 1>{}, cl, buf, pb);
+        if (in_halo >> (q0 + 2) & 1) tr_issue(IC<q0 + 2>{}, cl, buf, pc);
+        // (in_halo is not wave-uniform: the waits below are conservative - zero - whenever a later slot may have been skipped)
+        if (in_halo >> q0 & 1) tr_finish(IC<q0>{}, buf, pa, IC<0>{});
+        if (in_halo >> (q0 + 1) & 1) tr_finish(IC<q0 + 1>{}, buf, pb, IC<0>{});
+        if (in_halo >> (q0 + 2) & 1) tr_finish(IC<q0 + 2>{}, buf, pc, IC<0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    // ---- prologue: affine table of this chunk range -> LDS ----
+    if (AFFINE == 2) {
+        // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the producers' per-channel
+        // partials (fixed summation order: bit-reproducible).  Scratch = the halo images (before any LDS-DMA is issued).
+        const int cpg = p.Cin / p.a_groups;
+        const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
+        const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
+        const int c_lo = g_lo * cpg, nc = g_hi * cpg - c_lo;
+        float* scr = reinterpret_cast<float*>(smem);                     // [8 waves][nc][2]
+        for (int cc = lane; cc < nc; cc += 64) {
+            const int c = c_lo + cc;
+            const bool second = p.A2 != nullptr && c >= p.C1;
+            const int ns = second ? p.a_ns2 : p.a_ns1;
+            const int Cs = second ? p.Cin - p.C1 : (p.A2 ? p.C1 : p.Cin);
+            const float* base = (second ? p.a_part2 : p.a_part1) + ((size_t)b * ns * Cs + (second ? c - p.C1 : c)) * 2;
+            double s = 0.0, q = 0.0;
+            for (int sl = wave; sl < ns; sl += 8) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)sl * Cs * 2);
+                s += v.x;
+                q += v.y;
+            }
+            scr[(wave * nc + cc) * 2] = (float)s;
+            scr[(wave * nc + cc) * 2 + 1] = (float)q;
+        }
+        __syncthreads();
+        float* stat = scr + 8 * nc * 2;                                   // [groups][2] = (mean, rstd)
+        for (int gi = g_lo + wave; gi < g_hi; gi += 8) {
+            double s = 0.0, q = 0.0;
+            for (int it = lane; it < cpg * 8; it += 64) {
+                const int w8 = it / cpg, cj = it - w8 * cpg;
+                s += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2];
+                q += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o);
+                q += __shfl_xor(q, o);
+            }
+            const double n = (double)g.div_rpb.d * cpg;
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (lane == 0) {
+                stat[(gi - g_lo) * 2] = (float)mean;
+                stat[(gi - g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+            }
+        }
+        __syncthreads();
+        float* abt = reinterpret_cast<float*>(smem + OFF_AB);
+        for (int i = tid; i < nch * 64; i += 512) {
+            const int c = k_lo + i;
+            const int gi = c / cpg - g_lo;
+            const float a = stat[gi * 2 + 1] * p.a_gamma[c];
+            abt[i * 2] = a;
+            abt[i * 2 + 1] = p.a_beta[c] - stat[gi * 2] * a;
+        }
+        __syncthreads();                                                  // scratch is free again before the first halo is written
+    }
+
+    // ---- main loop + the K-half sum of the epilogue, per wave kind (NT = column tiles of this wave; STG = staging duty) ----
+    float* tilef = reinterpret_cast<float*>(smem);
+    auto body = [&](auto ntc, auto stgc) {
+        constexpr int NT = decltype(ntc)::value;
+        constexpr bool STG = decltype(stgc)::value != 0;
+        constexpr int G = 3 * NT;                                 // fragments per kx group (3 ky x NT tiles)
+        // this wave's fragment stream: [column tile block ntile][group, K half][chunk][kx][ky][tile][64 lanes x 8 halves]
+        const long long per_chunk = 9 * 512;                      // halves per chunk and tile column
+        // The ring is loaded and waited for by hand (inline asm): with the LDS-DMA of the staging waves in the same loop hipcc
+        // treats the memory counter as out of order and drains it (vmcnt(0)) at every first use of a ring register.  Loads return in
+        // order; at the top of a kx group the wave may have in flight: the two younger groups (2 G loads) and, in a staging wave, the
+        // six LDS-DMA pieces of the chunk's halo prefetch - in whatever position, so they are always allowed for.
+        u32x4v ring[3 * G];
+        const unsigned lane16 = lane * 16;
+        // fragments [GX * G, GX * G + G) of the chunk at BASE (wave-uniform); 13-bit immediate: one scalar base per four fragments
+#define BC_WREG_LOAD_GROUP(GX, BASE)                                                                                                  \
+    _Pragma("unroll") for (int f = 0; f < G; ++f) {                                                                                   \
+        const h16* b4 = (BASE) + (((GX) * G + f) & ~3) * 512;                                                                          \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ring[(GX) * G + f]) : "v"(lane16), "s"(b4), "n"((((GX) * G + f) & 3) * 1024) : "memory"); \
+    }
+        const h16* wb = reinterpret_cast<const h16*>(p.W) + ((long long)ntile * 20 + 2 * tile0 + kg * NT) * g.halo_nch * per_chunk +
+                        (long long)c_begin * NT * per_chunk;     // wave-uniform stream pointer (chunk cl)
+        BC_WREG_LOAD_GROUP(0, wb)
+        BC_WREG_LOAD_GROUP(1, wb)
+        BC_WREG_LOAD_GROUP(2, wb)                                 // chunk 0 (flies during the staging below)
+        if (STG) issue_a(0, 0, true);
+        if (AFFINE == 1) {                                        // (its global loads fly together with the ring and the first halo rows)
+            const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
+            float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
+            for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
+        }
+        stamp(1);
+        if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first halo rows (and the ring: chunk 0 of the weights is needed right after anyway)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // affine table visible (AFFINE: written above by everybody)
+        asm volatile("" ::: "memory");
+        if (STG) {
+            if (AFFINE) {
+                transform3(IC<0>{}, 0, 0);
+                transform3(IC<3>{}, 0, 0);
+            }
+            issue_a(1, 1, nch > 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // halo image 0 complete
+        asm volatile("" ::: "memory");
+        stamp(2);
+
+        int a_off[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hx = (lane & 15) + kx;
+            const int ch = 4 * kg + (lane >> 4);
+            a_off[kx] = hx * 128 + ((ch ^ (((hx >> 1) & 3) << 1)) << 4);
+        }
+        f32x4v acc[8][NT];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+        // The staging waves carry 2/3 of a three-tile wave's MFMAs plus the in-place pass; their SIMD partner has nothing else to do.
+        // Raised priority lets their MFMAs through first, the partner fills the matrix pipe while they normalise.
+        if (STG) __builtin_amdgcn_s_setprio(3);
+        int buf = 0;                                              // image of chunk cl
+        for (int cl = 0; cl < nch; ++cl) {
+            const int buf1 = buf + 1 == NBUF ? 0 : buf + 1;       // image of chunk cl + 1
+            const int buf2 = buf1 + 1 == NBUF ? 0 : buf1 + 1;     // image of chunk cl + 2 (last read during chunk cl - 1)
+            const bool more = cl + 1 < nch;
+            if (STG) issue_a(cl + 2, buf2, cl + 2 < nch);
+            if (more) wb += 3 * G * 512;                          // -> chunk cl + 1 (the last chunk re-reads itself: see issue_a)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                // this group's fragments have landed (see the ring comment for what may still fly)
+                if (NT == 3) asm volatile("s_waitcnt vmcnt(%9)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),
+                                          "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + 5]), "+v"(ring[kx * G + 6]), "+v"(ring[kx * G + 7]),
+                                          "+v"(ring[kx * G + G - 1]) : "n"(2 * G + (STG ? 6 : 0)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),
+                                  "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + G - 1]) : "n"(2 * G + (STG ? 6 : 0)) : "memory");
+                const unsigned abase = lds0 + buf * HALO_BYTES + a_off[kx];
+                u32x4v a[3];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(abase) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[1]) : "v"(abase), "n"(HSTR * 128) : "memory");
+#pragma unroll
+                for (int r = 0; r < 10; ++r) {
+                    if (r + 2 < 10) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[(r + 2) % 3]) : "v"(abase), "n"((r + 2) * HSTR * 128) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[r % 3])::"memory");
+                    } else if (r + 1 < 10) {
+                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[r % 3])::"memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[r % 3])::"memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const h16x8 af = __builtin_bit_cast(h16x8, a[r % 3]);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int i = r - ky;
+                        if (i < 0 || i >= 8) continue;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(h16x8, ring[(kx * 3 + ky) * NT + t]), acc[i][t], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (STG && AFFINE && more && kx >= 1) {
+                    // in-place pass over chunk cl + 1 (three slots after kx = 1, three after kx = 2).  Its LDS-DMA is older than the
+                    // ring loads of chunk cl - 1 this wave has already consumed (cl >= 1); for cl = 0 it was issued after the ring
+                    // prefill, with at most the DMA of chunk 2 and this chunk's first refill behind it.
+                    if (kx == 1) {
+                        wait_vm_c<6 + G>();
+                        transform3(IC<0>{}, cl + 1, buf1);
+                    } else {
+                        transform3(IC<3>{}, cl + 1, buf1);
+                    }
+                }
+                // this group's slots are free: the same group of the next chunk
+                BC_WREG_LOAD_GROUP(kx, wb)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (STG && !AFFINE) wait_vm_c<6 + 3 * G>();           // (plain convolution: the rows of chunk cl + 1 have landed)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // image of chunk cl is free; image of chunk cl + 1 is complete
+            asm volatile("" ::: "memory");
+            buf = buf1;
+        }
+
+        if (STG) __builtin_amdgcn_s_setprio(0);
+        stamp(3);
+        // ---- the two K halves are summed through LDS (the halo images are dead: every wave passed the last barrier) ----
+        const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + t * 16] = acc[i][t][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + t * 16] += acc[i][t][r];
+        }
+        __syncthreads();
+    };
+    if (three) body(IC<3>{}, IC<0>{});
+    else body(IC<2>{}, IC<1>{});
+    stamp(4);
+
+    // ------------------------------------------------------------------------------------------------ epilogue (as conv_halo.hip)
+    // row-major pass: 24 rows x 20 eight-column chunks per sweep (480 of the 512 threads)
+    const int col8 = tid % 20, row0 = tid / 20;
+    const bool act = tid < 480;
+    const int rpb = (int)g.div_rpb.d;
+    if (p.splitk > 1) {
+        if (act) {
+            float* slab = p.slab + (size_t)split * p.M * p.N;
+            for (int row = row0; row < HBM; row += 24) {
+                const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
+                const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
+                float* dst = slab + (size_t)m * p.N + n0 + col8 * 8;
+                *reinterpret_cast<float4*>(dst) = lo;
+                *reinterpret_cast<float4*>(dst + 4) = hi;
+            }
+        }
+        stamp(5);
+        return;
+    }
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    if (act) {
+        const float alpha = scalar_alpha(p);
+        Cols8 cols;
+        cols8_init(g, cols, n0 + col8 * 8, n0 + col8 * 8, false, alpha);
+        const float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int row = row0; row < HBM; row += 24) {
+            const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
+            const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            epi8_store(g, cols, v, gt, m, gs, gq);
+        }
+    }
+    if (p.gn_part) {
+        float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                scr[(row0 * HBN + col8 * 8 + j) * 2] = gs[j];
+                scr[(row0 * HBN + col8 * 8 + j) * 2 + 1] = gq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < HBN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 24; ++r) {
+                s += scr[(r * HBN + tid) * 2];
+                q += scr[(r * HBN + tid) * 2 + 1];
+            }
+            float* dst = p.gn_part + (((size_t)b * g.halo_tpi + tin) * g.n_out + n0 + tid) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+    stamp(5);
+}
+
+// out[frag stream] <- w[N][9 * Cin] (k = (ky * 3 + kx) * Cin + c, the layout of every other 3x3 path): one thread per 16-byte lane slot
+__global__ void conv_wreg_pack_kernel(const h16* __restrict__ w, int N, int Cin, h16* __restrict__ out) {
+    const long long total = (long long)N * 9 * Cin / 8;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int nchunks = Cin / 64;
+    const long long per_ntile = (long long)20 * nchunks * 9 * 64;           // lane slots per 160-column block
+    const int ntile = (int)(idx / per_ntile);
+    long long rem = idx - (long long)ntile * per_ntile;
+    // stream order inside a block: (group, K half) streams of nchunks * 9 * NT fragments, starting at (2 * tile0 + kg * NT) tile-streams
+    const long long per_tile_stream = (long long)nchunks * 9 * 64;          // lane slots of one tile column and K half
+    const int ts = (int)(rem / per_tile_stream);                             // 0..19 = 2 * tile0 + kg * NT + (position inside the wave stream)
+    int grp, tile0, NT;
+    if (ts < 6) { grp = 0; tile0 = 0; NT = 3; }
+    else if (ts < 10) { grp = 1; tile0 = 3; NT = 2; }
+    else if (ts < 14) { grp = 2; tile0 = 5; NT = 2; }
+    else { grp = 3; tile0 = 7; NT = 3; }
+    (void)grp;
+    const long long in_grp = rem - (long long)2 * tile0 * per_tile_stream;  // lane slot inside the group's two wave streams
+    const long long per_wave = per_tile_stream * NT;
+    const int kg = (int)(in_grp / per_wave);
+    long long s = in_grp - (long long)kg * per_wave;                         // lane slot inside the wave stream
+    const int lane = (int)(s & 63);
+    s >>= 6;                                                                 // fragment index = ((chunk * 3 + kx) * 3 + ky) * NT + t
+    const int t = (int)(s % NT);
+    s /= NT;
+    const int ky = (int)(s % 3);
+    s /= 3;
+    const int kx = (int)(s % 3);
+    const int chunk = (int)(s / 3);
+    const int n = ntile * HBN + (tile0 + t) * 16 + (lane & 15);
+    const long long k = (long long)(ky * 3 + kx) * Cin + chunk * 64 + kg * 32 + 8 * (lane >> 4);
+    *reinterpret_cast<uint4*>(out + idx * 8) = *reinterpret_cast<const uint4*>(w + (long long)n * 9 * Cin + k);
+}
+
+}  // namespace
+
+extern "C" int bc_conv_wreg_pack(const bc_half* w, int N, int Cin, bc_half* out, bc_stream stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    BC_CHECK_ARG(w && out && N > 0 && N % HBN == 0 && Cin > 0 && Cin % 64 == 0, "bc_conv_wreg_pack: N %% 160 == 0 and Cin %% 64 == 0 (N=%d Cin=%d)", N, Cin);
+    BC_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)out % 16 == 0) && w != out, "bc_conv_wreg_pack: 16-byte aligned, out of place");
+    const long long total = (long long)N * 9 * Cin / 8;
+    hipLaunchKernelGGL(conv_wreg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const h16*>(w), N, Cin,
+                       reinterpret_cast<h16*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
+    BcGemm& p = g.p;
+    g.halo_tx = p.Wout / TW;
+    g.halo_tpi = g.halo_tx * (p.Hout / TH);
+    g.halo_nch = p.Cin / 64;
+    g.halo_dbg = 0;
+    g.halo_stamps = nullptr;
+    int sk = std::max(1, std::min(p.splitk, g.halo_nch));
+    g.halo_cps = bc_ceil_div(g.halo_nch, sk);
+    p.splitk = bc_ceil_div(g.halo_nch, g.halo_cps);
+    BC_CHECK_ARG(g.halo_cps <= MAX_CH, "bc_gemm(wreg conv): %d channel chunks per split exceed %d (raise splitk)", g.halo_cps, MAX_CH);
+    BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(wreg conv): splitk=%d needs a slab", p.splitk);
+    const int B = p.M / (p.Hout * p.Wout);
+    BC_CHECK_ARG((long long)p.M * std::max(p.lda, p.lda2) < 2147483647LL, "bc_gemm(wreg conv): activation of %d pixels x stride %d exceeds 32-bit element offsets",
+                 p.M, std::max(p.lda, p.lda2));
+    dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    {
+        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
+        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
+        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && grid.x >= 4);
+    }
+    // BC_WREG_STAMPS=1 (diagnostics; synchronises the stream after every launch): where the cycles of a three-tile wave and of a staging wave go
+    static const bool want_stamps = getenv("BC_WREG_STAMPS") != nullptr;
+    static unsigned long long* stamp_buf = nullptr;
+    const size_t nwg_s = (size_t)grid.x * grid.y * grid.z;
+    if (want_stamps && nwg_s <= 4096) {
+        if (!stamp_buf) BC_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&stamp_buf), 4096 * 16 * sizeof(unsigned long long)));
+        BC_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, nwg_s * 16 * sizeof(unsigned long long), stream));
+        g.halo_stamps = stamp_buf;
+    }
+    struct StampReport {
+        hipStream_t stream; size_t n; unsigned long long* buf; const BcGemm& p; int cps;
+        ~StampReport() {
+            if (!buf) return;
+            if (hipStreamSynchronize(stream) != hipSuccess) return;
+            std::vector<unsigned long long> h(n * 16);
+            if (hipMemcpy(h.data(), buf, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+            for (int w = 0; w < 2; ++w) {
+                double d[5] = {0, 0, 0, 0, 0};
+                for (size_t i = 0; i < n; ++i)
+                    for (int k = 0; k < 5; ++k) d[k] += (double)(h[(i * 2 + w) * 8 + k + 1] - h[(i * 2 + w) * 8 + k]);
+                fprintf(stderr, "[wreg stamps] M=%d N=%d Cin=%d sk=%d cps=%d wgs=%zu %s | avg ticks: setup+table %.0f, ring prefill + first halo %.0f, "
+                        "loop %.0f (%.0f per tap), k-half sum %.0f, stores %.0f\n", p.M, p.N, p.Cin, p.splitk, cps, n, w ? "staging wave " : "3-tile wave  ",
+                        d[0] / n, d[1] / n, d[2] / n, d[2] / n / (cps * 9), d[3] / n, d[4] / n);
+            }
+        }
+    } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
+    static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
+    if (p.a_part1) {
+        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && p.a_ns1 > 0 && (!p.A2 || (p.a_part2 && p.a_ns2 > 0)),
+                     "bc_gemm(wreg conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
+        const int cpg = p.Cin / p.a_groups;
+        BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && (8 * (g.halo_cps * 64 + 2 * cpg) + p.a_groups + 8) * 8 <= NBUF * HALO_BYTES,
+                     "bc_gemm(wreg conv): channel span %d per workgroup too wide for the in-kernel GroupNorm finalize (max %d): use "
+                     "bc_gn_finalize + a_affine or raise splitk", g.halo_cps * 64 + 2 * cpg, FIN_MAX_CH);
+        BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_wreg_kernel<2>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg_kernel<2>), grid, dim3(512), LDS_TOTAL, stream, g);
+    } else if (p.a_affine) {
+        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_wreg_kernel<1>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg_kernel<1>), grid, dim3(512), LDS_TOTAL, stream, g);
+    } else {
+        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_wreg_kernel<0>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg_kernel<0>), grid, dim3(512), LDS_TOTAL, stream, g);
+    }
+    BC_CHECK_LAUNCH();
+    return 0;
+}

@@ -458,7 +458,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         const int pads = p.conv_nopad_lo ? 1 : 2;
         BC_CHECK_ARG(p.Hout == (p.Hv + pads - 3) / p.stride + 1 && p.Wout == (p.Wv + pads - 3) / p.stride + 1,
                      "bc_gemm: conv output size %dx%d inconsistent with input %dx%d stride %d", p.Hout, p.Wout, p.Hv, p.Wv, p.stride);
-        BC_CHECK_ARG(p.A2 == nullptr || p.tile_cfg == BC_TILE_HALO, "bc_gemm: conv mode takes a single source (except BC_TILE_HALO)");
+        BC_CHECK_ARG(p.A2 == nullptr || p.tile_cfg == BC_TILE_HALO || p.tile_cfg == BC_TILE_WREG, "bc_gemm: conv mode takes a single source (except BC_TILE_HALO / BC_TILE_WREG)");
         p.rows_per_batch = p.Hout * p.Wout;
         if (p.out_w <= 0) p.out_w = p.Wout;
         g.fast_k = (p.Cin % BK == 0);
@@ -490,7 +490,8 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     } else {
         BC_CHECK_ARG(p.ldc >= g.n_out, "bc_gemm: ldc=%d < n_out=%d", p.ldc, g.n_out);
     }
-    const bool halo = p.tile_cfg == BC_TILE_HALO;
+    const bool wreg = p.tile_cfg == BC_TILE_WREG;
+    const bool halo = p.tile_cfg == BC_TILE_HALO || wreg;
     if (halo) {
         if (p.lda <= 0) p.lda = p.A2 ? p.C1 : p.Cin;          // pixel stride of A: 0 = its channel count (a wider NHWC view passes its own)
         if (p.A2 && p.lda2 <= 0) p.lda2 = p.Cin - p.C1;
@@ -524,7 +525,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     static const int force_tile = getenv("BC_GEMM_TILE") ? atoi(getenv("BC_GEMM_TILE")) : 0;
     if (force_generic) fast_ok = false;
     if (halo) {
-        g.cfg = BC_TILE_HALO; g.bm = 128; g.bn = 160;
+        g.cfg = wreg ? BC_TILE_WREG : BC_TILE_HALO; g.bm = 128; g.bn = 160;
     } else {
         int cfg = (force_tile > 0 && force_tile < BC_TILE_COUNT) ? force_tile : p.tile_cfg;
         int sk = p.splitk, bm = 0, bn = 0;
@@ -544,7 +545,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
                          p.M % p.rows_per_batch == 0,
                      "bc_gemm: fused GroupNorm partials need the fast path or split-K, fp16 row-major output and rows_per_batch%%%d==0", slab_rows);
     }
-    int rc = halo ? bc_conv_halo_launch(g, stream) : fast_ok ? bc_gemm_fast_try(g, stream) : -1;
+    int rc = wreg ? bc_conv_wreg_launch(g, stream) : halo ? bc_conv_halo_launch(g, stream) : fast_ok ? bc_gemm_fast_try(g, stream) : -1;
     if (rc > 0) return rc;
     if (rc < 0) {
         BC_CHECK_ARG(!p.gn_part || p.splitk > 1, "bc_gemm: fused GroupNorm partials are only produced by the fast path or the split-K reducer");

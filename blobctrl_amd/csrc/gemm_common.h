@@ -310,3 +310,5 @@ int bc_conv_halo_max_chunks_impl();
 void bc_gemm_set_probe(hipEvent_t e);      // gemm.hip: event recorded between the main kernel and the split-K reducer (nullptr: off)
 bool bc_gemm_probe_hit();
 int bc_conv_halo_launch(bcg::GemmArgs& g, hipStream_t stream);
+// conv_wreg.hip: the same convolution with the weights streamed into VGPRs from a packed fragment stream (BC_TILE_WREG).
+int bc_conv_wreg_launch(bcg::GemmArgs& g, hipStream_t stream);

@@ -94,8 +94,12 @@ class TrunkPlan:
             kw.update(R=R.t, ldr=R.C)
         kw.update(self._r2(r2, Hout, Wout))
         Cin = x.C + (x2.C if x2 is not None else 0)
+        wkey = wname + ".weight"
         if halo:
-            kw.update(tile_cfg=_lib.TILE_HALO, lda=x.C)
+            wreg = not os.environ.get("BC_NO_WREG")                  # conv_wreg.hip (weights streamed into VGPRs) instead of conv_halo.hip
+            kw.update(tile_cfg=_lib.TILE_WREG if wreg else _lib.TILE_HALO, lda=x.C)
+            if wreg:
+                wkey = pw.wreg(wname + ".weight")
             if x2 is not None:
                 kw.update(A2=x2.t, C1=x.C, lda2=x2.C)
             if affine is not None:
@@ -104,7 +108,7 @@ class TrunkPlan:
             assert x2 is None and affine is None
             if tile_cfg:
                 kw.update(tile_cfg=tile_cfg)
-        rec.gemm(A=x.t, W=pw.h[wname + ".weight"], M=M, N=Cout, K=9 * Cin, out=out,
+        rec.gemm(A=x.t, W=pw.h[wkey], M=M, N=Cout, K=9 * Cin, out=out,
                  out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,
                  conv=dict(Cin=Cin, Hin=x.H, Win=x.W, Hv=Hv, Wv=Wv, Hout=Hout, Wout=Wout, stride=stride),
                  bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, want_gn=not out_f32, **kw)

@@ -347,7 +347,7 @@ class Recorder:
             fast = fast and C1 % 64 == 0
         if os.environ.get("BC_GEMM_GENERIC"):
             fast = False
-        if tile_cfg == _lib.TILE_HALO:
+        if tile_cfg in (_lib.TILE_HALO, _lib.TILE_WREG):
             # LDS-resident input-halo convolution (conv_halo.hip): split-K counts 64-channel chunks; fill ~one workgroup per CU
             nch = conv["Cin"] // 64
             base = (M // 128) * (N // 160)
@@ -363,7 +363,7 @@ class Recorder:
                 splitk = 1 if base >= full else max(1, min(nch // min_cps, -(-target // base)))
             splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))
-            cfg, sk, bm, bn = _lib.TILE_HALO, -(-nch // cps), 128, 160
+            cfg, sk, bm, bn = tile_cfg, -(-nch // cps), 128, 160
             fast, mode = True, "halo"
             if a_gn is not None:
                 # GroupNorm in front of the convolution: a_gn = dict(x1, C1, x2, C2, B, HW, G, eps, gamma, beta).  The finalize runs
@@ -387,7 +387,7 @@ class Recorder:
                                               a_gn["gamma"], a_gn["beta"])
                     g.a_affine = ptr(a_affine)
         else:
-            assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO"
+            assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO / TILE_WREG"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
         g.splitk = sk
         g.tile_cfg = cfg
@@ -414,7 +414,8 @@ class Recorder:
         self.keep.append(refs)
         for t in refs:
             self.register(t)
-        variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
+        variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "conv_wreg_kernel<" if cfg == _lib.TILE_WREG else
+                   "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
         self._push(kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out

@@ -49,6 +49,28 @@ def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
     return p.reshape(co, 9 * cip)
 
 
+WREG_TILES = ((0, 3), (3, 2), (5, 2), (7, 3))      # (first column tile, tiles) of the four column groups of csrc/conv_wreg.hip
+
+
+def pack_conv_wreg(w: torch.Tensor) -> torch.Tensor:
+    """Packed 3x3 weights [N][9 * Cin] (k = (ky * 3 + kx) * Cin + c: `pack_conv3x3`) -> the per-wave fragment streams of BC_TILE_WREG
+    (csrc/conv_wreg.hip, same as `bc_conv_wreg_pack`): per 160-column block, per (column group, K half of the 64-channel chunk) one
+    contiguous stream [chunk][kx][ky][tile][lane = 16 (k sub-chunk) + row][8]."""
+    N, K = w.shape
+    Cin = K // 9
+    assert N % 160 == 0 and Cin % 64 == 0 and K == 9 * Cin, (N, K)
+    nch = Cin // 64
+    # [block, tile 10, row 16, ky, kx, chunk, kg, q 4, 8]
+    v = w.reshape(N // 160, 10, 16, 3, 3, nch, 2, 4, 8)
+    parts = []
+    for blk in range(N // 160):
+        for t0, nt in WREG_TILES:
+            g = v[blk, t0:t0 + nt]                                   # [t, row, ky, kx, chunk, kg, q, 8]
+            g = g.permute(5, 4, 3, 2, 0, 6, 1, 7)                     # [kg, chunk, kx, ky, t, q, row, 8]
+            parts.append(g.reshape(-1))
+    return torch.cat(parts).reshape(N, K)
+
+
 def pack_matrix(w: torch.Tensor) -> torch.Tensor:
     w = w.reshape(w.shape[0], -1)
     co, ci = w.shape
@@ -71,6 +93,13 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
 
 class PackedTrunk:
     """Device-resident packed weights of one trunk (UNet or BlobNet)."""
+
+    def wreg(self, key: str) -> str:
+        """Key of the BC_TILE_WREG fragment stream of the packed 3x3 weight `key` (made on first use, kept beside the matrix)."""
+        k2 = key + "_wreg"
+        if k2 not in self.h:
+            self.h[k2] = pack_conv_wreg(self.h[key])
+        return k2
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, block_out_channels, layers_per_block=2):
         self.device = device

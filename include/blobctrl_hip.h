@@ -122,7 +122,14 @@ enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_12
         * Hout % 8 == 0; workgroup = 8 x 16 pixels x 160 channels; takes two channel-concatenated sources (A | A2, C1 % 64 == 0,
         * lda / lda2 = their pixel strides) and the fused GroupNorm prologue (a_affine); splitk counts 64-channel chunks.  Never
         * chosen by BC_TILE_AUTO: callers ask for it (bc_conv_halo_eligible). */
-       BC_TILE_HALO = 8 };
+       BC_TILE_HALO = 8,
+       /* the same convolution, tile, prologue and epilogue with the weights streamed straight into VGPRs (conv_wreg.hip): `W` is the
+        * fragment stream bc_conv_wreg_pack wrote for this layer (not the row-major matrix), ldw is ignored.  Same eligibility. */
+       BC_TILE_WREG = 9 };
+/* Re-order a 3x3 weight matrix w[N][9 * Cin] (k = (ky * 3 + kx) * Cin + c; N % 160 == 0, Cin % 64 == 0) into the per-wave fragment
+ * streams of BC_TILE_WREG (same size, out of place): per 160-column block, per (column group 3|2|2|3 tiles, K half of the 64-channel
+ * chunk) one contiguous stream [chunk][kx][ky][tile][64 lanes][8]; lane l holds w[n0 + 16 tile + (l & 15)][k0 + 8 (l >> 4) .. + 8]. */
+int bc_conv_wreg_pack(const bc_half* w, int N, int Cin, bc_half* out, bc_stream stream);
 /* 1 when a convolution can run on BC_TILE_HALO. */
 int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, int Hout, int Wout, int stride);
 /* most 64-channel chunks one workgroup of BC_TILE_HALO may take: callers keep ceil(Cin / 64 / splitk) <= this */

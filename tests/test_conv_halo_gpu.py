@@ -1,4 +1,5 @@
-"""Parity of the LDS-resident input-halo convolution with the fused GroupNorm(+SiLU) prologue (conv_halo.hip, BC_TILE_HALO)
+"""Parity of the LDS-resident input-halo convolution with the fused GroupNorm(+SiLU) prologue - both builds: weights by LDS-DMA
+(conv_halo.hip, BC_TILE_HALO) and weights streamed into VGPRs from the packed fragment stream (conv_wreg.hip, BC_TILE_WREG) -
 against a plain PyTorch fp32 statement of resnet.py:327-341 / 351-366 (torch.cat -> GroupNorm -> SiLU -> conv3x3 [+ bias, time
 embedding row vector, residual, BlobNet right-half residual]) computed on the CPU from the same fp16-rounded inputs."""
 import math
@@ -11,6 +12,23 @@ pytestmark = pytest.mark.gpu
 
 from tests.common import g  # noqa: E402
 from tests.test_kernels_gpu import close, h, rec, run  # noqa: E402,F401
+
+
+@pytest.fixture(params=["halo", "wreg"])
+def tile(request):
+    return request.param
+
+
+def tcfg(tile):
+    from blobctrl_amd import _lib
+    return _lib.TILE_WREG if tile == "wreg" else _lib.TILE_HALO
+
+
+def wmat(w, tile):
+    """fp16 device weights of a 3x3 convolution in the layout the tile configuration reads."""
+    from blobctrl_amd.weights import pack_conv3x3, pack_conv_wreg
+    p = pack_conv3x3(w).half()
+    return (pack_conv_wreg(p) if tile == "wreg" else p).cuda()
 
 
 def nhwc(x):            # [B,C,H,W] fp32 -> token-major fp16 on the GPU
@@ -28,14 +46,14 @@ def conv_ref(x, w, b):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,sk", [(1, 8, 16, 64, 160, 1), (2, 16, 32, 128, 320, 1), (1, 24, 16, 192, 160, 1),
                                                (2, 8, 16, 256, 160, 2), (1, 8, 32, 640, 320, 5), (1, 16, 16, 320, 160, None)])
-def test_halo_conv_plain(rec, B, H, W, Cin, Cout, sk):
+def test_halo_conv_plain(rec, tile, B, H, W, Cin, Cout, sk):
     from blobctrl_amd import _lib
     from blobctrl_amd.weights import pack_conv3x3
     x, w, b = g(1, B, Cin, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
     M = B * H * W
-    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), W=wmat(w, tile), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
                                     conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
-                                    tile_cfg=_lib.TILE_HALO, splitk=sk))
+                                    tile_cfg=tcfg(tile), splitk=sk))
     close(from_nhwc(out, B, H, W), conv_ref(x, w, b), what=f"halo conv {B}x{Cin}->{Cout}@{H}x{W} sk={sk}")
 
 
@@ -43,7 +61,7 @@ def test_halo_conv_plain(rec, B, H, W, Cin, Cout, sk):
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout,sk,silu", [(2, 16, 16, 128, 0, 160, 1, True), (1, 8, 32, 64, 128, 320, 1, True),
                                                        (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False),
                                                        (1, 8, 16, 640, 320, 160, 3, True)])
-def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, sk, silu, finalize, monkeypatch):
+def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, Cout, sk, silu, finalize, monkeypatch):
     monkeypatch.setenv("BC_GN_FINALIZE_IN_KERNEL_BYTES", "1000000")          # (the in-kernel finalize is opt-in)
     """GroupNorm statistics from a standalone pass -> bc_gn_finalize -> affine applied in the halo staging (zero padding AFTER the
     activation), two channel-concatenated sources, and the whole ResBlock epilogue: bias + time-embedding row vector + residual +
@@ -67,8 +85,8 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, s
             kw = dict(a_gn=dict(x1=t1, C1=C1, x2=t2, C2=C2, B=B, HW=HW, G=G, eps=1e-5, gamma=gamma.cuda(), beta=beta.cuda()))
         if C2:
             kw.update(A2=t2, C1=C1, lda2=C2)
-        out = rec.gemm(A=t1, lda=C1, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
-                       conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=HW, tile_cfg=_lib.TILE_HALO,
+        out = rec.gemm(A=t1, lda=C1, W=wmat(w, tile), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
+                       conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=HW, tile_cfg=tcfg(tile),
                        splitk=sk, a_act=_lib.ACT_SILU if silu else _lib.ACT_NONE, rowvec=h(temb), ld_rowvec=Cout,
                        R=nhwc(R), ldr=Cout, R2=nhwc(R2), ldr2=Cout, r2_xmin=W - H if W > H else 0, r2_bmod=1, out_w=W, want_gn=True,
                        **kw)
@@ -91,7 +109,7 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, B, H, W, C1, C2, Cout, s
     assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
 
 
-def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec):
+def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec, tile):
     """The production shape family: 320 -> 320 @ 64 x 128, batch 2, against GroupNorm pass + implicit-GEMM kernel (both HIP)."""
     from blobctrl_amd import _lib
     from blobctrl_amd.weights import pack_conv3x3
@@ -104,8 +122,8 @@ def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec):
     def fn():
         t = nhwc(x)
         ab = rec.gn_affine(t, C, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda())
-        fused = rec.gemm(A=t, lda=C, W=h(pack_conv3x3(w)), M=M, N=C, K=9 * C, out=rec.empty(M, C), bias=b.cuda(), conv=conv,
-                         rows_per_batch=HW, tile_cfg=_lib.TILE_HALO, a_affine=ab, a_act=_lib.ACT_SILU)
+        fused = rec.gemm(A=t, lda=C, W=wmat(w, tile), M=M, N=C, K=9 * C, out=rec.empty(M, C), bias=b.cuda(), conv=conv,
+                         rows_per_batch=HW, tile_cfg=tcfg(tile), a_affine=ab, a_act=_lib.ACT_SILU)
         y = rec.groupnorm(t, C, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda(), True)
         plain = rec.gemm(A=y, W=h(pack_conv3x3(w)), M=M, N=C, K=9 * C, out=rec.empty(M, C), bias=b.cuda(), conv=conv,
                          rows_per_batch=HW)
@@ -114,7 +132,7 @@ def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec):
     close(fused, plain, rtol=4e-3, what="fused vs unfused resblock conv")
 
 
-def test_halo_conv_single_source_with_a_wider_pixel_stride(rec):
+def test_halo_conv_single_source_with_a_wider_pixel_stride(rec, tile):
     """`lda` is the PIXEL stride of A (blobctrl_hip.h): a single-source halo convolution over the first 128 channels of a
     192-channel NHWC buffer (lda = 192 > Cin = 128) must read that view, not a packed 128-channel image."""
     from blobctrl_amd import _lib
@@ -122,11 +140,25 @@ def test_halo_conv_single_source_with_a_wider_pixel_stride(rec):
     B, H, W, Cwide, Cin, Cout = 2, 8, 16, 192, 128, 160
     x, w, b = g(1, B, Cwide, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
     M = B * H * W
-    out = run(rec, lambda: rec.gemm(A=nhwc(x), lda=Cwide, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), lda=Cwide, W=wmat(w, tile), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
                                     bias=b.cuda(), conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
-                                    tile_cfg=_lib.TILE_HALO))
+                                    tile_cfg=tcfg(tile)))
     close(from_nhwc(out, B, H, W), conv_ref(x[:, :Cin], w, b), what="halo conv over a strided single-source view")
     with pytest.raises(_lib.BlobCtrlHipError):
-        run(rec, lambda: rec.gemm(A=nhwc(x), lda=64, W=h(pack_conv3x3(w)), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
+        run(rec, lambda: rec.gemm(A=nhwc(x), lda=64, W=wmat(w, tile), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout),
                                   conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=H * W,
-                                  tile_cfg=_lib.TILE_HALO))
+                                  tile_cfg=tcfg(tile)))
+
+
+@pytest.mark.parametrize("N,Cin", [(160, 64), (320, 320), (1280, 128)])
+def test_wreg_pack_kernel_equals_the_host_packing(N, Cin):
+    """bc_conv_wreg_pack (device) and weights.pack_conv_wreg (host) write the same fragment streams."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_conv_wreg
+    lib = _lib.load()
+    w = (g(11, N, 9 * Cin) * 8).half()
+    wd = w.cuda()
+    out = torch.empty_like(wd)
+    _lib.check(lib.bc_conv_wreg_pack(wd.data_ptr(), N, Cin, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "bc_conv_wreg_pack")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), pack_conv_wreg(w))

@@ -12,6 +12,7 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 from blobctrl_amd import _lib  # noqa: E402
 from blobctrl_amd.launch import Recorder  # noqa: E402
+from blobctrl_amd.weights import pack_conv_wreg  # noqa: E402
 from tools.tune_gemm import time_launch, time_launch_cold  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -32,6 +33,7 @@ for (B, H, W, C1, C2, Co) in SHAPES:
     x1 = torch.randn(B, HW, C1, device=dev, dtype=torch.float16)
     x2 = torch.randn(B, HW, C2, device=dev, dtype=torch.float16) if C2 else None
     wt = (torch.randn(Co, 9 * Cin, device=dev) / math.sqrt(9 * Cin)).half()
+    wt_wreg = pack_conv_wreg(wt)
     bias = torch.randn(Co, device=dev)
     gamma, beta = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
     conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1)
@@ -52,12 +54,13 @@ for (B, H, W, C1, C2, Co) in SHAPES:
         nch = Cin // 64
         if sk is not None and (sk > nch or -(-nch // sk) > 40 or (B * H * W // 128) * (Co // 160) * sk > 1024):
             continue
-        s2 = rec.begin(f"halo_sk{sk}")
         kw = dict(A2=x2, C1=C1, lda2=C2) if C2 else {}
-        rec.gemm(A=x1, lda=C1, W=wt, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW,
-                 tile_cfg=_lib.TILE_HALO, splitk=sk, a_act=_lib.ACT_SILU, want_gn=True,
-                 a_gn=dict(x1=x1, C1=C1, x2=x2, C2=C2, B=B, HW=HW, G=32, eps=1e-5, gamma=gamma, beta=beta), **kw)
-        segs[f"halo_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
+        for name, cfg, wm in (("halo", _lib.TILE_HALO, wt), ("wreg", _lib.TILE_WREG, wt_wreg)):
+            s2 = rec.begin(f"{name}_sk{sk}")
+            rec.gemm(A=x1, lda=C1, W=wm, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW,
+                     tile_cfg=cfg, splitk=sk, a_act=_lib.ACT_SILU, want_gn=True,
+                     a_gn=dict(x1=x1, C1=C1, x2=x2, C2=C2, B=B, HW=HW, G=32, eps=1e-5, gamma=gamma, beta=beta), **kw)
+            segs[f"{name}_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
     for rnd in range(3):
         for k, s in segs.items():
             res.setdefault(k, []).append(time_launch_cold(rec, s, stream, 6, thrash, [t for t in (x1, x2) if t is not None])
