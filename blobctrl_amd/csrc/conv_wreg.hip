@@ -52,7 +52,8 @@ constexpr int TS = HBN + 4;                     // epilogue tile row stride (flo
 constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
 constexpr int LDS_LOOP = OFF_AB + MAX_CH * 512;
 constexpr int LDS_EPI = OFF_SCR + 24 * HBN * 2 * 4;
-constexpr int LDS_TOTAL = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+constexpr int OFF_EPI = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;   // bias[160] | time-embedding row[160] (floats), staged in the prologue
+constexpr int LDS_TOTAL = OFF_EPI + 2 * HBN * 4;
 static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES, "LDS budget");
 constexpr int FIN_MAX_CH = 720;                 // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
 
@@ -106,14 +107,12 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     // SOURCE address; the lane that brings a slot in by LDS-DMA is the lane that later normalises it in place.
     const int sidx = ((wave >= 2 ? wave - 2 : 0) << 6) | lane;
     int pixv[6], csubv[6];
-    unsigned in_halo = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int hp = (sidx >> 3) + 32 * q;
         const int hy = hp / HSTR, hx = hp - hy * HSTR;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inh = hp < HPIX;
-        in_halo |= inh ? 1u << q : 0u;
         const bool in_img = inh && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         pixv[q] = in_img ? (b * H + gy) * W + gx : -1;
         csubv[q] = (sidx & 7) ^ (((hx >> 1) & 3) << 1);
@@ -139,19 +138,16 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     const unsigned slot_addr = lds0 + sidx * 16;
     const unsigned ab_base = lds0 + OFF_AB;
     struct Pending { u32x4v raw; f32x4v t0, t1, t2, t3; };
-    auto tr_issue = [&](auto qc, int cl, int buf, Pending& pd) {
-        constexpr int q = decltype(qc)::value;
-        const unsigned sa = slot_addr + buf * HALO_BYTES;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pd.raw) : "v"(sa), "n"(4096 * q) : "memory");
-        const unsigned ab_addr = ab_base + cl * 512 + csubv[q] * 64;     // (64 channels x (a, b) x 4 bytes per chunk)
+    // in-place pass over one 16-byte slot: `sa` = its LDS address, `ab_addr` = the (a, b) pairs of its 8 channels, `outside` = the pixel
+    // lies outside the image (zero padding, applied AFTER norm + activation)
+    auto tr_issue = [&](unsigned sa, unsigned ab_addr, Pending& pd) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(pd.raw) : "v"(sa) : "memory");
         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
                      "ds_read_b128 %3, %4 offset:48"
                      : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
     };
-    auto tr_finish = [&](auto qc, int buf, Pending& pd, auto waitc) {
-        constexpr int q = decltype(qc)::value;
-        constexpr int WAITN = decltype(waitc)::value;            // LDS operations issued after this slot's five reads
-        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3) : "n"(WAITN) : "memory");
+    auto tr_finish = [&](unsigned sa, bool outside, Pending& pd) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3)::"memory");
         __builtin_amdgcn_sched_barrier(0);
         const float aa[8] = {pd.t0[0], pd.t0[2], pd.t1[0], pd.t1[2], pd.t2[0], pd.t2[2], pd.t3[0], pd.t3[2]};
         const float bb[8] = {pd.t0[1], pd.t0[3], pd.t1[1], pd.t1[3], pd.t2[1], pd.t2[3], pd.t3[1], pd.t3[3]};
@@ -165,21 +161,40 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             if (p.a_act == BC_ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
             o[j] = (h16)v;
         }
-        if (pixv[q] < 0) outraw = (u32x4v){0u, 0u, 0u, 0u};       // zero padding is applied AFTER norm + activation
-        const unsigned sa = slot_addr + buf * HALO_BYTES;
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(sa), "v"(outraw), "n"(4096 * q) : "memory");
+        if (outside) outraw = (u32x4v){0u, 0u, 0u, 0u};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(outraw) : "memory");
     };
-    // the in-place pass over three of this lane's six slots of chunk `cl` in image `buf`: all reads first, then the arithmetic
-    auto transform3 = [&](auto q0c, int cl, int buf) {
-        constexpr int q0 = decltype(q0c)::value;
-        Pending pa, pb, pc;
-        if (in_halo >> q0 & 1) tr_issue(IC<q0>{}, cl, buf, pa);
-        if (in_halo >> (q0 + 1) & 1) tr_issue(IC<q0 + 1>{}, cl, buf, pb);
-        if (in_halo >> (q0 + 2) & 1) tr_issue(IC<q0 + 2>{}, cl, buf, pc);
-        // (in_halo is not wave-uniform: the waits below are conservative - zero - whenever a later slot may have been skipped)
-        if (in_halo >> q0 & 1) tr_finish(IC<q0>{}, buf, pa, IC<0>{});
-        if (in_halo >> (q0 + 1) & 1) tr_finish(IC<q0 + 1>{}, buf, pb, IC<0>{});
-        if (in_halo >> (q0 + 2) & 1) tr_finish(IC<q0 + 2>{}, buf, pc, IC<0>{});
+    // Every lane of the workgroup owns three 16-byte slots of every halo image for the in-place pass: bytes [tid * 16 + 8192 q, + 16),
+    // q < 3, = halo pixel (tid >> 3) + 64 q, slot tid & 7 (the LDS-DMA that filled them was issued by a staging wave and is known to
+    // have landed: see the loop).  tinfo: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
+    unsigned tinfo = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int hp = (tid >> 3) + 64 * q;
+        const int hy = hp / HSTR, hx = hp - hy * HSTR;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const unsigned inh = hp < HPIX, outside = !((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);
+        tinfo |= (inh | outside << 1 | (unsigned)((tid & 7) ^ (((hx >> 1) & 3) << 1)) << 2) << (8 * q);
+    }
+    const unsigned tslot = lds0 + tid * 16;
+    auto transform_slot = [&](int q, int cl, int buf) {          // one slot of chunk `cl` in image `buf`
+        const unsigned inf = tinfo >> (8 * q);
+        if (inf & 1) {
+            Pending pd;
+            const unsigned sa = tslot + buf * HALO_BYTES + 8192 * q;
+            tr_issue(sa, ab_base + cl * 512 + ((inf >> 2) & 7) * 64, pd);      // (64 channels x (a, b) x 4 bytes per chunk)
+            tr_finish(sa, (inf >> 1) & 1, pd);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto transform_first = [&]() {                                // image 0, all three slots with the reads issued together
+        Pending pd[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (tinfo >> (8 * q) & 1) tr_issue(tslot + 8192 * q, ab_base + ((tinfo >> (8 * q + 2)) & 7) * 64, pd[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (tinfo >> (8 * q) & 1) tr_finish(tslot + 8192 * q, (tinfo >> (8 * q + 1)) & 1, pd[q]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
@@ -267,24 +282,28 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         BC_WREG_LOAD_GROUP(0, wb)
         BC_WREG_LOAD_GROUP(1, wb)
         BC_WREG_LOAD_GROUP(2, wb)                                 // chunk 0 (flies during the staging below)
-        if (STG) issue_a(0, 0, true);
+        if (STG) {
+            issue_a(0, 0, true);
+            issue_a(1, 1, nch > 1);
+        }
         if (AFFINE == 1) {                                        // (its global loads fly together with the ring and the first halo rows)
             const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
             float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
             for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
         }
+        if (p.splitk == 1 && tid < HBN) {                         // bias and time-embedding row of this image: the epilogue finds them in LDS
+            float* ev = reinterpret_cast<float*>(smem + OFF_EPI);
+            ev[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+            ev[HBN + tid] = p.rowvec ? (float)(rowvec_base(p) + (size_t)b * p.ld_rowvec)[n0 + tid] : 0.f;
+        }
         stamp(1);
         if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first halo rows (and the ring: chunk 0 of the weights is needed right after anyway)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                             // affine table visible (AFFINE: written above by everybody)
+        __builtin_amdgcn_s_barrier();                             // affine table and raw rows of chunks 0 and 1 visible
         asm volatile("" ::: "memory");
-        if (STG) {
-            if (AFFINE) {
-                transform3(IC<0>{}, 0, 0);
-                transform3(IC<3>{}, 0, 0);
-            }
-            issue_a(1, 1, nch > 1);
-        }
+        stamp(6);
+        if (AFFINE) transform_first();
+        stamp(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // halo image 0 complete
         asm volatile("" ::: "memory");
@@ -303,9 +322,12 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-        // The staging waves carry 2/3 of a three-tile wave's MFMAs plus the in-place pass; their SIMD partner has nothing else to do.
-        // Raised priority lets their MFMAs through first, the partner fills the matrix pipe while they normalise.
-        if (STG) __builtin_amdgcn_s_setprio(3);
+        // A three-tile wave's own chunk (3456 cycles of MFMA issue + its share of the in-place pass) is as long as the matrix pipe's
+        // (5760 cycles for both waves of the SIMD): its MFMAs go first, the two-tile partner fills the pipe while it normalises.
+#ifndef BC_WREG_PRIO
+#define BC_WREG_PRIO 2
+#endif
+        if ((BC_WREG_PRIO == 1 && STG) || (BC_WREG_PRIO == 2 && !STG)) __builtin_amdgcn_s_setprio(3);
         int buf = 0;                                              // image of chunk cl
         for (int cl = 0; cl < nch; ++cl) {
             const int buf1 = buf + 1 == NBUF ? 0 : buf + 1;       // image of chunk cl + 1
@@ -347,29 +369,21 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (STG && AFFINE && more && kx >= 1) {
-                    // in-place pass over chunk cl + 1 (three slots after kx = 1, three after kx = 2).  Its LDS-DMA is older than the
-                    // ring loads of chunk cl - 1 this wave has already consumed (cl >= 1); for cl = 0 it was issued after the ring
-                    // prefill, with at most the DMA of chunk 2 and this chunk's first refill behind it.
-                    if (kx == 1) {
-                        wait_vm_c<6 + G>();
-                        transform3(IC<0>{}, cl + 1, buf1);
-                    } else {
-                        transform3(IC<3>{}, cl + 1, buf1);
-                    }
-                }
+                // in-place pass over chunk cl + 1: every wave normalises one of its three slots after each kx group (its SIMD partner
+                // keeps the matrix pipe busy meanwhile).  The rows landed before the barrier that ended chunk cl - 1.
+                if (AFFINE && more) transform_slot(kx, cl + 1, buf1);
                 // this group's slots are free: the same group of the next chunk
                 BC_WREG_LOAD_GROUP(kx, wb)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (STG && !AFFINE) wait_vm_c<6 + 3 * G>();           // (plain convolution: the rows of chunk cl + 1 have landed)
+            if (STG) wait_vm_c<3 * G>();                          // the rows of chunk cl + 2 (LDS-DMA at the top of this chunk) have landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // image of chunk cl is free; image of chunk cl + 1 is complete
             asm volatile("" ::: "memory");
             buf = buf1;
         }
 
-        if (STG) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         stamp(3);
         // ---- the two K halves are summed through LDS (the halo images are dead: every wave passed the last barrier) ----
         const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
@@ -416,20 +430,92 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         stamp(5);
         return;
     }
+    // Same arithmetic, in the same order, as epi8_store (gemm_common.h); bias and the time-embedding row come from LDS, and the
+    // residual loads of all (up to six) rows of a thread are issued before the first one is used.
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
     if (act) {
         const float alpha = scalar_alpha(p);
-        Cols8 cols;
-        cols8_init(g, cols, n0 + col8 * 8, n0 + col8 * 8, false, alpha);
-        const float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int row = row0; row < HBM; row += 24) {
-            const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
+        const int n_first = n0 + col8 * 8;
+        const float* ev = reinterpret_cast<const float*>(smem + OFF_EPI) + col8 * 8;
+        float bias_v[8], rvec[8], cs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bias_v[j] = ev[j];
+            rvec[j] = ev[HBN + j];
+            cs[j] = (p.colscale ? p.colscale[n_first + j] : 1.0f) * alpha;
+        }
+        const float ab = p.alpha_bstride > 0 ? batch_alpha(g, b) : 1.0f;
+        constexpr int NR = 6;                                       // rows row0 + 24 k < 128
+        uint4 rr[NR], rr2[NR];
+        int mrow[NR];
+        bool has2[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = row0 + 24 * k;
+            const int py = ty0 + (row >> 4), px = tx0 + (row & 15);
+            mrow[k] = b * rpb + py * W + px;
+            has2[k] = false;
+            if (row < HBM) {
+                if (p.R) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
+                if (p.R2) {
+                    const int pix = py * W + px;
+                    const int x = pix - (int)fdiv((unsigned)pix, g.div_outw) * (int)g.div_outw.d;
+                    has2[k] = x >= p.r2_xmin;
+                    if (has2[k]) rr2[k] = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)(b % p.r2_bmod) * rpb + pix) * p.ldr2 + n_first);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = row0 + 24 * k;
+            if (row >= HBM) continue;
             const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
             const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            epi8_store(g, cols, v, gt, m, gs, gq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bias_v[j];
+            if (p.rowvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rvec[j];
+            }
+            if (p.act == BC_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
+            } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+            } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= cs[j];
+            if (p.alpha_bstride > 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= ab;
+            }
+            if (p.R) {
+                const h16* rh = reinterpret_cast<const h16*>(&rr[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+            }
+            if (has2[k]) {
+                const h16* rh = reinterpret_cast<const h16*>(&rr2[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+            }
+            uint4 outraw;
+            h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (h16)v[j];
+                const float f = (float)o[j];
+                gs[j] += f;
+                gq[j] += f * f;
+            }
+            bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[k] * p.ldc + n_first, outraw);
         }
     }
     if (p.gn_part) {
@@ -546,9 +632,16 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
                 double d[5] = {0, 0, 0, 0, 0};
                 for (size_t i = 0; i < n; ++i)
                     for (int k = 0; k < 5; ++k) d[k] += (double)(h[(i * 2 + w) * 8 + k + 1] - h[(i * 2 + w) * 8 + k]);
-                fprintf(stderr, "[wreg stamps] M=%d N=%d Cin=%d sk=%d cps=%d wgs=%zu %s | avg ticks: setup+table %.0f, ring prefill + first halo %.0f, "
-                        "loop %.0f (%.0f per tap), k-half sum %.0f, stores %.0f\n", p.M, p.N, p.Cin, p.splitk, cps, n, w ? "staging wave " : "3-tile wave  ",
-                        d[0] / n, d[1] / n, d[2] / n, d[2] / n / (cps * 9), d[3] / n, d[4] / n);
+                double e[3] = {0, 0, 0};                              // stamp 1 -> 6 (landing + barrier), 6 -> 7 (first in-place pass), 7 -> 2
+                for (size_t i = 0; i < n; ++i) {
+                    const unsigned long long* q = &h[(i * 2 + w) * 8];
+                    e[0] += (double)(q[6] - q[1]);
+                    e[1] += (double)(q[7] - q[6]);
+                    e[2] += (double)(q[2] - q[7]);
+                }
+                fprintf(stderr, "[wreg stamps] M=%d N=%d Cin=%d sk=%d cps=%d wgs=%zu %s | avg ticks: setup+table %.0f, first halo %.0f (landing %.0f, pass %.0f, "
+                        "next DMA + barrier %.0f), loop %.0f (%.0f per tap), k-half sum %.0f, stores %.0f\n", p.M, p.N, p.Cin, p.splitk, cps, n,
+                        w ? "staging wave " : "3-tile wave  ", d[0] / n, d[1] / n, e[0] / n, e[1] / n, e[2] / n, d[2] / n, d[2] / n / (cps * 9), d[3] / n, d[4] / n);
             }
         }
     } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
