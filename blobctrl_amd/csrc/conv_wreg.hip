@@ -279,25 +279,38 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     }
         const h16* wb = reinterpret_cast<const h16*>(p.W) + ((long long)ntile * 20 + 2 * tile0 + kg * NT) * g.halo_nch * per_chunk +
                         (long long)c_begin * NT * per_chunk;     // wave-uniform stream pointer (chunk cl)
-        BC_WREG_LOAD_GROUP(0, wb)
-        BC_WREG_LOAD_GROUP(1, wb)
-        BC_WREG_LOAD_GROUP(2, wb)                                 // chunk 0 (flies during the staging below)
+        // Request order = order of use: the first two halo images, ring group 0, the tables; then the rest of chunk 0's weights.  (A
+        // workgroup's first requests - 48 KiB of halo rows + 144-216 KiB of weights - take ~5000 cycles at the per-CU fetch rate: the
+        // first MFMA waits only for what it needs.)
         if (STG) {
             issue_a(0, 0, true);
             issue_a(1, 1, nch > 1);
         }
-        if (AFFINE == 1) {                                        // (its global loads fly together with the ring and the first halo rows)
+        BC_WREG_LOAD_GROUP(0, wb)
+        {   // affine table of the chunk range, bias and time-embedding row of this image -> LDS: all global loads first, then the stores
             const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
             float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
-            for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
+            const bool tok = AFFINE == 1 && tid < nch * 32, eok = p.splitk == 1 && tid < HBN;
+            float4 tv = {0.f, 0.f, 0.f, 0.f};
+            float bv = 0.f, rv = 0.f;
+            if (tok) tv = src[tid];
+            if (eok) {
+                if (p.bias) bv = p.bias[n0 + tid];
+                if (p.rowvec) rv = (float)(rowvec_base(p) + (size_t)b * p.ld_rowvec)[n0 + tid];
+            }
+            if (tok) dst[tid] = tv;
+            if (AFFINE == 1)
+                for (int i = tid + 512; i < nch * 32; i += 512) dst[i] = src[i];
+            if (eok) {                                            // (the epilogue finds them in LDS)
+                float* ev = reinterpret_cast<float*>(smem + OFF_EPI);
+                ev[tid] = bv;
+                ev[HBN + tid] = rv;
+            }
         }
-        if (p.splitk == 1 && tid < HBN) {                         // bias and time-embedding row of this image: the epilogue finds them in LDS
-            float* ev = reinterpret_cast<float*>(smem + OFF_EPI);
-            ev[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
-            ev[HBN + tid] = p.rowvec ? (float)(rowvec_base(p) + (size_t)b * p.ld_rowvec)[n0 + tid] : 0.f;
-        }
+        BC_WREG_LOAD_GROUP(1, wb)
+        BC_WREG_LOAD_GROUP(2, wb)
         stamp(1);
-        if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first halo rows (and the ring: chunk 0 of the weights is needed right after anyway)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");  // the halo rows (and ring group 0) have landed; groups 1 and 2 may fly
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // affine table and raw rows of chunks 0 and 1 visible
         asm volatile("" ::: "memory");
@@ -385,25 +398,34 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
 
         __builtin_amdgcn_s_setprio(0);
         stamp(3);
-        // ---- the two K halves are summed through LDS (the halo images are dead: every wave passed the last barrier) ----
-        const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
-        if (kg == 1) {
+        // ---- the two K halves are summed through LDS (the halo images are dead: every wave passed the last barrier).  The partner
+        // waves (same column group, other K half) hold the same fragment layout: each sends the half of its accumulators the OTHER one
+        // finalises (K half 0: pixel rows 0-3, K half 1: rows 4-7) as 16-byte fragments, adds what it receives, and writes its own four
+        // pixel rows of the row-major tile.
+        char* xch = smem + tile0 * 8192;                          // [row tile 8][tile NT][lane 64] x 16 bytes per column group
+        const int i_keep = kg * 4, i_send = 4 - i_keep;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + t * 16] = acc[i][t][r];
-        }
+            for (int t = 0; t < NT; ++t)
+                *reinterpret_cast<f32x4v*>(xch + (((i_send + ii) * NT + t) * 64 + lane) * 16) = kg ? acc[ii][t] : acc[4 + ii][t];
         __syncthreads();
-        if (kg == 0) {
+        f32x4v fin[4][NT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                const f32x4v o = *reinterpret_cast<const f32x4v*>(xch + (((i_keep + ii) * NT + t) * 64 + lane) * 16);
+                fin[ii][t] = (kg ? acc[4 + ii][t] : acc[ii][t]) + o;
+            }
+        __syncthreads();                                          // every fragment has been read: the tile may overwrite the exchange area
+        const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tilef[(er + i * 16 + r) * TS + ec + t * 16] += acc[i][t][r];
-        }
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tilef[(er + (i_keep + ii) * 16 + r) * TS + ec + t * 16] = fin[ii][t][r];
         __syncthreads();
     };
     if (three) body(IC<3>{}, IC<0>{});

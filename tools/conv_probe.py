@@ -58,7 +58,7 @@ for (B, H, W, C1, C2, Co) in SHAPES:
         for name, cfg, wm in (("halo", _lib.TILE_HALO, wt), ("wreg", _lib.TILE_WREG, wt_wreg)):
             s2 = rec.begin(f"{name}_sk{sk}")
             rec.gemm(A=x1, lda=C1, W=wm, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW,
-                     tile_cfg=cfg, splitk=sk, a_act=_lib.ACT_SILU, want_gn=True,
+                     tile_cfg=cfg, splitk=sk, a_act=_lib.ACT_SILU, want_gn=not os.environ.get("PROBE_NO_GN"),
                      a_gn=dict(x1=x1, C1=C1, x2=x2, C2=C2, B=B, HW=HW, G=32, eps=1e-5, gamma=gamma, beta=beta), **kw)
             segs[f"{name}_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
     for rnd in range(3):
