@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                      "ds_read_b128 %3, %4 offset:48"
                      : "=&v"(pd.t0), "=&v"(pd.t1), "=&v"(pd.t2), "=&v"(pd.t3) : "v"(ab_addr) : "memory");
     };
-    auto tr_finish = [&](unsigned sa, bool outside, Pending& pd) {
+    auto tr_finish = [&](unsigned sa, bool outside, bool store, Pending& pd) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pd.raw), "+v"(pd.t0), "+v"(pd.t1), "+v"(pd.t2), "+v"(pd.t3)::"memory");
         __builtin_amdgcn_sched_barrier(0);
         const float aa[8] = {pd.t0[0], pd.t0[2], pd.t1[0], pd.t1[2], pd.t2[0], pd.t2[2], pd.t3[0], pd.t3[2]};
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             o[j] = (h16)v;
         }
         if (outside) outraw = (u32x4v){0u, 0u, 0u, 0u};
-        asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(outraw) : "memory");
+        if (store) asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(outraw) : "memory");
     };
-    // Every lane of the workgroup owns three 16-byte slots of every halo image for the in-place pass: bytes [tid * 16 + 8192 q, + 16),
+    // FIRST image: every lane of the workgroup owns three 16-byte slots for the in-place pass: bytes [tid * 16 + 8192 q, + 16),
     // q < 3, = halo pixel (tid >> 3) + 64 q, slot tid & 7 (the LDS-DMA that filled them was issued by a staging wave and is known to
     // have landed: see the loop).  tinfo: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
     unsigned tinfo = 0;
@@ -177,24 +177,27 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         tinfo |= (inh | outside << 1 | (unsigned)((tid & 7) ^ (((hx >> 1) & 3) << 1)) << 2) << (8 * q);
     }
     const unsigned tslot = lds0 + tid * 16;
-    auto transform_slot = [&](int q, int cl, int buf) {          // one slot of chunk `cl` in image `buf`
-        const unsigned inf = tinfo >> (8 * q);
-        if (inf & 1) {
-            Pending pd;
-            const unsigned sa = tslot + buf * HALO_BYTES + 8192 * q;
-            tr_issue(sa, ab_base + cl * 512 + ((inf >> 2) & 7) * 64, pd);      // (64 channels x (a, b) x 4 bytes per chunk)
-            tr_finish(sa, (inf >> 1) & 1, pd);
-        }
+    // in the loop the pass belongs to the staging waves (the three-tile waves have neither the registers nor the issue slots to spare):
+    // two of the lane's six DMA slots after each kx group, reads of both issued before the arithmetic
+    auto transform_pair = [&](auto kxc, int cl, int buf) {
+        constexpr int q0 = 2 * decltype(kxc)::value;
+        Pending pa, pb;
+        const unsigned sa = slot_addr + buf * HALO_BYTES + 4096 * q0, ab = ab_base + cl * 512;      // (64 channels x (a, b) x 4 bytes per chunk)
+        const bool in0 = (sidx >> 3) + 32 * q0 < HPIX, in1 = (sidx >> 3) + 32 * (q0 + 1) < HPIX;
+        // (reads and arithmetic are unconditional - the padding slots of the image are readable - only the store is predicated: the
+        // registers the asm reads land in reach their wait on a straight path)
+        tr_issue(sa, ab + csubv[q0] * 64, pa);
+        tr_issue(sa + 4096, ab + csubv[q0 + 1] * 64, pb);
+        tr_finish(sa, pixv[q0] < 0, in0, pa);
+        tr_finish(sa + 4096, pixv[q0 + 1] < 0, in1, pb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     auto transform_first = [&]() {                                // image 0, all three slots with the reads issued together
         Pending pd[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (tinfo >> (8 * q) & 1) tr_issue(tslot + 8192 * q, ab_base + ((tinfo >> (8 * q + 2)) & 7) * 64, pd[q]);
+        for (int q = 0; q < 3; ++q) tr_issue(tslot + 8192 * q, ab_base + ((tinfo >> (8 * q + 2)) & 7) * 64, pd[q]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (tinfo >> (8 * q) & 1) tr_finish(tslot + 8192 * q, (tinfo >> (8 * q + 1)) & 1, pd[q]);
+        for (int q = 0; q < 3; ++q) tr_finish(tslot + 8192 * q, (tinfo >> (8 * q + 1)) & 1, (tinfo >> (8 * q)) & 1, pd[q]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
@@ -335,27 +338,42 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[i][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 
-        // A three-tile wave's own chunk (3456 cycles of MFMA issue + its share of the in-place pass) is as long as the matrix pipe's
-        // (5760 cycles for both waves of the SIMD): its MFMAs go first, the two-tile partner fills the pipe while it normalises.
+        // The staging waves carry 2/3 of a three-tile wave's MFMAs plus the in-place pass; their SIMD partner has nothing else to do.
+        // Raised priority lets their MFMAs through first, the partner fills the matrix pipe while they normalise.
 #ifndef BC_WREG_PRIO
-#define BC_WREG_PRIO 2
+#define BC_WREG_PRIO 1
 #endif
         if ((BC_WREG_PRIO == 1 && STG) || (BC_WREG_PRIO == 2 && !STG)) __builtin_amdgcn_s_setprio(3);
+        // The last chunk is peeled (the pass loop below is unrolled, `more` is a constant in each copy): a register the inline asm
+        // loads into must reach its wait on a straight path - a refill under a run-time condition makes hipcc join two versions of
+        // the ring at the end of the branch, possibly by a register copy issued while the load is still in flight.
         int buf = 0;                                              // image of chunk cl
-        for (int cl = 0; cl < nch; ++cl) {
+        int cl = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+        const bool more = pass == 0;
+        const int cl_end = more ? nch - 1 : nch;
+        for (; cl < cl_end; ++cl) {
             const int buf1 = buf + 1 == NBUF ? 0 : buf + 1;       // image of chunk cl + 1
             const int buf2 = buf1 + 1 == NBUF ? 0 : buf1 + 1;     // image of chunk cl + 2 (last read during chunk cl - 1)
-            const bool more = cl + 1 < nch;
             if (STG) issue_a(cl + 2, buf2, cl + 2 < nch);
-            if (more) wb += 3 * G * 512;                          // -> chunk cl + 1 (the last chunk re-reads itself: see issue_a)
+            wb += 3 * G * 512;                                    // -> chunk cl + 1
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                // this group's fragments have landed (see the ring comment for what may still fly)
-                if (NT == 3) asm volatile("s_waitcnt vmcnt(%9)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),
-                                          "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + 5]), "+v"(ring[kx * G + 6]), "+v"(ring[kx * G + 7]),
-                                          "+v"(ring[kx * G + G - 1]) : "n"(2 * G + (STG ? 6 : 0)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),
-                                  "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + G - 1]) : "n"(2 * G + (STG ? 6 : 0)) : "memory");
+                // this group's fragments have landed.  Younger operations that may still fly: the two groups refilled after it and, in a
+                // staging wave, the six LDS-DMA pieces issued at the top of the chunk; the LAST chunk refills nothing (a load still
+                // in flight at the end of the loop would land in a register hipcc has meanwhile given to something else), so there
+                // the count shrinks group by group
+#define BC_WREG_WAIT(N)                                                                                                                 \
+    if (NT == 3) asm volatile("s_waitcnt vmcnt(%9)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]), \
+                              "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + 5]), "+v"(ring[kx * G + 6]), "+v"(ring[kx * G + 7]),             \
+                              "+v"(ring[kx * G + G - 1]) : "n"(N) : "memory");                                                          \
+    else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),       \
+                      "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + G - 1]) : "n"(N) : "memory");
+                constexpr int D = STG ? 6 : 0;
+                if (more || kx == 0) { BC_WREG_WAIT(2 * G + D) }
+                else if (kx == 1) { BC_WREG_WAIT(G + D) }
+                else { BC_WREG_WAIT(D) }
                 const unsigned abase = lds0 + buf * HALO_BYTES + a_off[kx];
                 u32x4v a[3];
                 asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(abase) : "memory");
@@ -382,18 +400,25 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // in-place pass over chunk cl + 1: every wave normalises one of its three slots after each kx group (its SIMD partner
-                // keeps the matrix pipe busy meanwhile).  The rows landed before the barrier that ended chunk cl - 1.
-                if (AFFINE && more) transform_slot(kx, cl + 1, buf1);
+                // in-place pass over chunk cl + 1 (staging waves; the rows landed before the barrier that ended chunk cl - 1)
+                if (STG && AFFINE && more) {
+                    if (kx == 0) transform_pair(IC<0>{}, cl + 1, buf1);
+                    else if (kx == 1) transform_pair(IC<1>{}, cl + 1, buf1);
+                    else transform_pair(IC<2>{}, cl + 1, buf1);
+                }
                 // this group's slots are free: the same group of the next chunk
-                BC_WREG_LOAD_GROUP(kx, wb)
+                if (more) { BC_WREG_LOAD_GROUP(kx, wb) }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (STG) wait_vm_c<3 * G>();                          // the rows of chunk cl + 2 (LDS-DMA at the top of this chunk) have landed
+            if (STG) {                                            // the rows of chunk cl + 2 (LDS-DMA at the top of this chunk) have landed
+                if (more) wait_vm_c<3 * G>();
+                else wait_vm_c<0>();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // image of chunk cl is free; image of chunk cl + 1 is complete
             asm volatile("" ::: "memory");
             buf = buf1;
+        }
         }
 
         __builtin_amdgcn_s_setprio(0);

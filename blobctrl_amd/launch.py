@@ -360,7 +360,10 @@ class Recorder:
                 # kernels fill the idle CUs - but this kernel's own average goes from 37.5 to 45.8 us (0.24 -> 0.19 of peak) and the
                 # serialised kernel time of a step rises by 0.76 ms: not the default.)
                 full = int(os.environ.get("BC_HALO_FULL", str(target * 2 // 3)))
-                splitk = 1 if base >= full else max(1, min(nch // min_cps, -(-target // base)))
+                # conv_wreg.hip: with five chunks or fewer a half-filled pass is also the faster one in isolation (64 x 128 BlobNet: 43.8 us
+                # unsplit vs 45.7 us as two K halves + reducer, cold weights); with ten chunks the split wins (32 x 64 UNet: 61.4 vs 54.5)
+                short = tile_cfg == _lib.TILE_WREG and base >= target // 2 and nch <= 5
+                splitk = 1 if (base >= full or short) else max(1, min(nch // min_cps, -(-target // base)))
             splitk = max(splitk, -(-nch // self.lib.bc_conv_halo_max_chunks()))     # (the workgroup's affine table lives in LDS)
             cps = -(-nch // max(1, splitk))
             cfg, sk, bm, bn = tile_cfg, -(-nch // cps), 128, 160
