@@ -350,3 +350,26 @@ def test_rowchain_weight_streams_follow_the_kernels_consumption_order(C):
     j0 = 128 * c + hpw * wave + 16 * ps
     assert torch.equal(v_o[off:off + 16], b1[j0:j0 + 16]) and torch.equal(v_o[off + 16:off + 32], b1[4 * C + j0:4 * C + j0 + 16])
     assert torch.equal(v_o[-C:], sd["blobnet_down_blocks.1.bias"])
+
+
+@pytest.mark.parametrize("N,Cin", [(160, 64), (320, 192)])
+def test_conv_wreg_fragment_streams(N, Cin):
+    """weights.pack_conv_wreg (host side of csrc/conv_wreg.hip, = bc_conv_wreg_pack on the device: tests/test_conv_halo_gpu.py): per
+    160-column block four column groups of 3 | 2 | 2 | 3 MFMA column tiles x 2 K halves, each ONE contiguous stream
+    [chunk][kx][ky][tile][lane][8]; lane l of a fragment holds W[n0 + 16 tile + (l & 15)][(ky * 3 + kx) * Cin + 64 chunk + 32 kg + 8 (l >> 4) : + 8]."""
+    from blobctrl_amd.weights import WREG_TILES, pack_conv_wreg
+    w = torch.arange(N * 9 * Cin, dtype=torch.float32).reshape(N, 9 * Cin) % 2039      # (exact in fp16)
+    w = w.half()
+    s = pack_conv_wreg(w).reshape(-1, 64, 8)                                           # [fragment][lane][8]
+    nch = Cin // 64
+    rng = np.random.Generator(np.random.PCG64(2))
+    for _ in range(300):
+        blk, grp, kg = rng.integers(N // 160), rng.integers(4), rng.integers(2)
+        t0, nt = WREG_TILES[grp]
+        chunk, kx, ky, t, lane = rng.integers(nch), rng.integers(3), rng.integers(3), rng.integers(nt), rng.integers(64)
+        stream0 = (blk * 20 + 2 * t0 + kg * nt) * nch * 9                              # first fragment of this wave's stream
+        frag = stream0 + ((chunk * 3 + kx) * 3 + ky) * nt + t
+        n = blk * 160 + (t0 + t) * 16 + (lane & 15)
+        k = (ky * 3 + kx) * Cin + chunk * 64 + kg * 32 + 8 * (lane >> 4)
+        assert torch.equal(s[frag, lane], w[n, k:k + 8]), (blk, grp, kg, chunk, kx, ky, t, lane)
+    assert sorted(s.reshape(-1).tolist()) == sorted(w.reshape(-1).tolist())            # a permutation: nothing lost, nothing doubled
