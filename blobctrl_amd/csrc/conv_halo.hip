@@ -488,7 +488,10 @@ int bc_conv_halo_max_chunks_impl() { return MAX_CH; }
 // Eligibility of the halo kernel for a conv problem (the host-side planners mirror this).
 int bc_conv_halo_ok(const BcGemm& p) {
     if (p.a_mode != BC_A_CONV3X3 || p.stride != 1 || p.conv_nopad_lo) return 0;
-    if (p.Hv != p.Hin || p.Wv != p.Win || p.Hout != p.Hin || p.Wout != p.Win) return 0;
+    // BC_TILE_WREG also takes the exact 2x nearest upsample in front of a plain convolution (no GroupNorm prologue, single source)
+    const bool ups2 = p.tile_cfg == BC_TILE_WREG && p.Hv == 2 * p.Hin && p.Wv == 2 * p.Win && !p.A2 && !p.a_affine && !p.a_part1;
+    if (!ups2 && (p.Hv != p.Hin || p.Wv != p.Win)) return 0;
+    if (p.Hout != p.Hv || p.Wout != p.Wv) return 0;
     if (p.Cin % 64 != 0 || p.N % HBN != 0 || p.Wout % TW != 0 || p.Hout % TH != 0) return 0;
     if (p.A2 && (p.C1 % 64 != 0)) return 0;
     return 1;

@@ -87,7 +87,10 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     const int b = tile / g.halo_tpi;
     const int tin = tile - b * g.halo_tpi;
     const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
-    const int H = p.Hin, W = p.Win;
+    // H x W = the image the convolution runs over; with UPS2 (exact nearest-neighbour 2x upsample in front: D/models/upsampling.py:
+    // F.interpolate(scale_factor=2.0, mode="nearest") -> conv) that is the VIRTUAL image and a halo pixel reads source pixel (y/2, x/2)
+    const int H = p.Hv, W = p.Wv;
+    const bool ups2 = p.Hv != p.Hin;
     const int c_begin = split * g.halo_cps;
     const int nch = min(g.halo_nch, c_begin + g.halo_cps) - c_begin;
 
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inh = hp < HPIX;
         const bool in_img = inh && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        pixv[q] = in_img ? (b * H + gy) * W + gx : -1;
+        pixv[q] = !in_img ? -1 : ups2 ? (b * p.Hin + (gy >> 1)) * p.Win + (gx >> 1) : (b * H + gy) * W + gx;
         csubv[q] = (sidx & 7) ^ (((hx >> 1) & 3) << 1);
     }
     // raw rows of chunk c_begin + cl -> halo image `buf` (staging waves only).  `valid` false: six reads of the zero line instead (the

@@ -106,7 +106,13 @@ class TrunkPlan:
                 kw.update(a_act=affine[1], **({"a_gn": affine[0]} if isinstance(affine[0], dict) else {"a_affine": affine[0]}))
         else:
             assert x2 is None and affine is None
-            if tile_cfg:
+            # the exact 2x nearest upsample in front of a plain convolution also runs on conv_wreg.hip (source pixel = halo pixel / 2)
+            ups_wreg = up_to is not None and (Hv, Wv) == (2 * x.H, 2 * x.W) and stride == 1 and Cin % 64 == 0 and Cout % 160 == 0 and \
+                Wv % 16 == 0 and Hv % 8 == 0 and not os.environ.get("BC_NO_WREG") and not os.environ.get("BC_NO_WREG_UPS")
+            if ups_wreg:
+                kw.update(tile_cfg=_lib.TILE_WREG, lda=x.C)
+                wkey = pw.wreg(wname + ".weight")
+            elif tile_cfg:
                 kw.update(tile_cfg=tile_cfg)
         rec.gemm(A=x.t, W=pw.h[wkey], M=M, N=Cout, K=9 * Cin, out=out,
                  out_mode=_lib.OUT_F32 if out_f32 else _lib.OUT_F16,

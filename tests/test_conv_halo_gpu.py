@@ -162,3 +162,19 @@ def test_wreg_pack_kernel_equals_the_host_packing(N, Cin):
     _lib.check(lib.bc_conv_wreg_pack(wd.data_ptr(), N, Cin, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "bc_conv_wreg_pack")
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), pack_conv_wreg(w))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,sk", [(1, 4, 8, 64, 160, 1), (2, 8, 16, 128, 320, 1), (1, 16, 16, 256, 160, 2), (2, 8, 8, 1280, 160, None)])
+def test_wreg_conv_behind_a_2x_nearest_upsample(rec, B, H, W, Cin, Cout, sk):
+    """Upsample2D (D/models/upsampling.py: F.interpolate(scale_factor=2.0, mode="nearest") -> conv3x3) on BC_TILE_WREG: the halo rows
+    are fetched from source pixel (y / 2, x / 2); the virtual image never exists."""
+    from blobctrl_amd import _lib
+    x, w, b = g(1, B, Cin, H, W), g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout)
+    Hv, Wv = 2 * H, 2 * W
+    M = B * Hv * Wv
+    R2 = g(9, 1, Cout, Hv, Wv)
+    out = run(rec, lambda: rec.gemm(A=nhwc(x), lda=Cin, W=wmat(w, "wreg"), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b.cuda(),
+                                    conv=dict(Cin=Cin, Hin=H, Win=W, Hv=Hv, Wv=Wv, Hout=Hv, Wout=Wv, stride=1), rows_per_batch=Hv * Wv,
+                                    tile_cfg=_lib.TILE_WREG, splitk=sk, R2=nhwc(R2), ldr2=Cout, r2_xmin=0, r2_bmod=1, out_w=Wv))
+    ref = F.conv2d(F.interpolate(x.half().float(), scale_factor=2.0, mode="nearest"), w.half().float(), b, padding=1) + R2.half().float()
+    close(from_nhwc(out, B, Hv, Wv), ref, what=f"upsample + conv {B}x{Cin}->{Cout}@{H}x{W}->{Hv}x{Wv} sk={sk}")
