@@ -377,7 +377,9 @@ class Recorder:
                 # Every workgroup re-reduces span x nslab partials: measured a LOSS against one bc_gn_finalize launch when that is
                 # 170 KB per workgroup (64 x 128 level: 63.9 vs 55.5 us per conv), a gain when it is a few KB (low-resolution levels)
                 vol = span * max(ns1, ns2) * 8
-                limit = int(os.environ.get("BC_GN_FINALIZE_IN_KERNEL_BYTES", "0"))      # (default off: no gain in the step, see DESIGN)
+                # in the kernel's prologue where every workgroup re-reduces at most 30 KB (the 16 x 32 and 8 x 16 levels: 9.81 -> 9.74 ms
+                # per step, round 3); above that the redundant reduction costs more than the launch it saves (60 KB: +0.05 ms, all: +0.4)
+                limit = int(os.environ.get("BC_GN_FINALIZE_IN_KERNEL_BYTES", "30000"))
                 if span <= 712 and vol <= limit:
                     g.a_part1, g.a_ns1, g.a_part2, g.a_ns2 = ptr(pa1), ns1, ptr(pa2), ns2
                     g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), G_, a_gn["eps"]
