@@ -178,3 +178,39 @@ def test_wreg_conv_behind_a_2x_nearest_upsample(rec, B, H, W, Cin, Cout, sk):
                                     tile_cfg=_lib.TILE_WREG, splitk=sk, R2=nhwc(R2), ldr2=Cout, r2_xmin=0, r2_bmod=1, out_w=Wv))
     ref = F.conv2d(F.interpolate(x.half().float(), scale_factor=2.0, mode="nearest"), w.half().float(), b, padding=1) + R2.half().float()
     close(from_nhwc(out, B, Hv, Wv), ref, what=f"upsample + conv {B}x{Cin}->{Cout}@{H}x{W}->{Hv}x{Wv} sk={sk}")
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 32, 64, 320, 0, 320), (2, 8, 16, 1280, 1280, 1280), (1, 8, 16, 1280, 0, 1280)])
+def test_conv_is_bit_reproducible_under_changing_cache_state(rec, tile, B, H, W, C1, C2, Cout):
+    """The same launch, repeated with the caches disturbed in between, must give the same bits (tools/conv_repeat.py is the long
+    form).  This is the screen for the failure class DESIGN 3.7 describes: a load still in flight when its destination register is
+    re-used is right whenever it lands early - i.e. in every quiet, isolated run - and wrong under memory load; the split-K shapes
+    with two or three chunks per workgroup (short loops) showed it first."""
+    from blobctrl_amd import _lib
+    Cin, HW, M = C1 + C2, H * W, B * H * W
+    x1 = h(g(1, B, HW, C1))
+    x2 = h(g(4, B, HW, C2)) if C2 else None
+    w, b = g(2, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), g(3, Cout).cuda()
+    gamma, beta = (1.0 + 0.2 * g(5, Cin)).cuda(), (0.3 * g(6, Cin)).cuda()
+    thrash = torch.zeros(48 << 20, dtype=torch.float32, device="cuda")
+
+    def fn():
+        kw = dict(A2=x2, C1=C1, lda2=C2) if C2 else {}
+        return rec.gemm(A=x1, lda=C1, W=wmat(w, tile), M=M, N=Cout, K=9 * Cin, out=rec.empty(M, Cout), bias=b,
+                        conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1), rows_per_batch=HW, tile_cfg=tcfg(tile),
+                        a_act=_lib.ACT_SILU, want_gn=True,
+                        a_gn=dict(x1=x1, C1=C1, x2=x2, C2=C2, B=B, HW=HW, G=32, eps=1e-5, gamma=gamma, beta=beta), **kw)
+    seg = rec.begin("repeat")
+    out = fn()
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = None
+    for r in range(12):
+        if r % 2:
+            thrash.add_(1.0)
+        seg.run(stream)
+        torch.cuda.synchronize()
+        o = out.clone()
+        assert torch.isfinite(o.float()).all()
+        if ref is None:
+            ref = o
+        assert torch.equal(o, ref), f"repeat {r} differs: max abs {float((o.float() - ref.float()).abs().max()):.3g}"
