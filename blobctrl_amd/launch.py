@@ -352,8 +352,13 @@ class Recorder:
             nch = conv["Cin"] // 64
             base = (M // 128) * (N // 160)
             if splitk is None:
-                target = int(os.environ.get("BC_HALO_CTAS", "256"))
-                min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "2"))               # fewest 64-channel chunks per workgroup
+                # Workgroups a split pass aims for and the fewest 64-channel chunks per workgroup.  With conv_wreg.hip (tap loop 867
+                # instead of 1445 cycles) a workgroup's fixed costs weigh more and a pass that leaves CUs to the other trunk is worth
+                # more than one that fills the chip: 192 / 3 instead of round 2's 256 / 2 - the UNet's 32 x 64 convolutions (128 pixel x
+                # column tiles) now run unsplit, the 8 x 16 level in 5 instead of 10 splits - is 9.53 -> 9.29 ms per step (same box,
+                # two rounds; 128 ... 192 within 0.05 ms of each other, 224: 9.56, 384: 9.79).
+                target = int(os.environ.get("BC_HALO_CTAS", "192" if tile_cfg == _lib.TILE_WREG else "256"))
+                min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "3" if tile_cfg == _lib.TILE_WREG else "2"))
                 # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the 64 x 128
                 # BlobNet and 32 x 64 UNet convolutions run as one pass instead of two K halves + a reducer: 13 reducer launches and
                 # 0.7 GB of slab traffic less, and the step gains 0.4 % (10.59 -> 10.55 ms, round 3, same box) because the other trunk's
