@@ -293,6 +293,9 @@ class Recorder:
             hit = tuning_table().get(f"{mode}|{M}|{N}|{K}")
             if hit:
                 tile_cfg, sk = int(hit[0]), int(hit[1])
+            cap = os.environ.get("BC_SPLITK_MAX")              # diagnostics: cap the split-K of the GEMM family (the tile is then the cost model's)
+            if cap and (sk < 0 or sk > int(cap)):
+                tile_cfg, sk = 0, (int(cap) if sk > int(cap) else sk)
         c, s_, bm, bn = C.c_int(tile_cfg), C.c_int(sk), C.c_int(0), C.c_int(0)
         _lib.check(self.lib.bc_gemm_plan(M, N, K, 1 if fast else 0, C.byref(c), C.byref(s_), C.byref(bm), C.byref(bn)),
                    "bc_gemm_plan")
