@@ -346,8 +346,22 @@ def roofline(pipe, plan, res=512, batch=1):
         if (m["variant"] or m["kind"]) == dom and m.get("shape") and len(m["shape"]) >= 4 and isinstance(m["shape"][1], int):
             mode, M_, N_, K_ = m["shape"][:4]
             alg.append(2 * (M_ * (K_ // 9 if mode in ("halo", "conv1", "conv2", "ups") else K_) + N_ * K_ + M_ * N_))
+    # The same figure over the launches of that kernel whose grid fills the chip (>= one workgroup per CU).  The plan deliberately leaves
+    # some passes half-filled (the other trunk's kernels run beside them: DESIGN 3.7); alone in this serial replay such a launch shows
+    # half the throughput, which says nothing about the kernel.  `frac` above is over ALL its launches, as they are shipped.
+    full_grid = None
+    if dom.startswith("conv_wreg_kernel") or dom.startswith("conv_halo_kernel"):
+        fl = fms = fn = 0
+        for m, ms in timed:
+            if (m["variant"] or m["kind"]) == dom and m.get("shape") and len(m["shape"]) >= 5:
+                _, M_, N_, _, sk_ = m["shape"][:5]
+                if -(-M_ // 128) * (N_ // 160) * sk_ >= 256:
+                    fl, fms, fn = fl + m["flops"], fms + ms, fn + 1
+        if fn:
+            full_grid = dict(launches=fn, avg_launch_us=round(fms * 1e3 / fn, 2), achieved=round(fl / (fms * 1e-3) / 1e12, 2),
+                             frac=round(fl / (fms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                frac=round(achieved / MFMA_PEAK_TFLOPS, 4), full_grid_launches=full_grid, traffic=traffic, traffic_source=traffic_source,
                 algorithmic_bytes_per_launch=int(sum(alg) / len(alg)) if alg else None, launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3), event_overhead_us=round(overhead_ms * 1e3, 2)), \
