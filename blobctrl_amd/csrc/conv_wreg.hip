@@ -14,11 +14,14 @@
 //     twice and the matrix pipes are evenly loaded;
 //   * every wave covers all 8 pixel rows of the tile, so an A fragment (16 pixels of halo row r at x shift kx) serves the three taps
 //     (ky = 0..2) that read row r: 10 ds_read_b128 per kx group instead of 24, 0.4 LDS reads per MFMA;
-//   * one barrier per CHUNK: the halo images are triple-buffered; the four two-tile waves (which have matrix-pipe time to spare) issue
-//     the LDS-DMA of chunk c + 2 and run the in-place pass over chunk c + 1 while everybody multiplies chunk c.
-// LDS accesses of the loop are inline asm with counted lgkmcnt waits (hipcc would order plain LDS reads behind every LDS-DMA in
-// flight); the weight ring is plain C++ (the compiler counts vmcnt for it, the LDS-DMA of a wave is always older than the ring loads
-// that follow it, so "ring data arrived" implies "halo rows arrived").
+//   * one barrier per CHUNK: the halo images are triple-buffered; the four two-tile waves (which have matrix-pipe time to spare, and run
+//     at raised priority) issue the LDS-DMA of chunk c + 2 and run the in-place pass over chunk c + 1 while everybody multiplies chunk c.
+// Every LDS access of the loop and the whole weight ring are inline asm with hand-counted lgkmcnt / vmcnt waits: hipcc orders plain
+// LDS reads behind every LDS-DMA in flight, and with an LDS-DMA in the same loop it drains the memory counter (vmcnt(0)) at the first
+// use of any loaded register.  Two rules follow for registers the asm loads into (both learnt the hard way): they must
+// reach their wait on a straight path (no load or wait under a run-time condition: the last chunk is PEELED instead), and nothing may
+// still be in flight when such a register dies - hipcc re-uses it at once and the late data lands in somebody else's value.
+// Vector-memory operations complete in issue order, so a counted vmcnt states exactly which of them have landed.
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -170,9 +173,9 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         if (outside) outraw = (u32x4v){0u, 0u, 0u, 0u};
         if (store) asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(outraw) : "memory");
     };
-    // FIRST image: every lane of the workgroup owns three 16-byte slots for the in-place pass: bytes [tid * 16 + 8192 q, + 16),
-    // q < 3, = halo pixel (tid >> 3) + 64 q, slot tid & 7 (the LDS-DMA that filled them was issued by a staging wave and is known to
-    // have landed: see the loop).  tinfo: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
+    // FIRST image (prologue): every lane of the workgroup owns three 16-byte slots for the in-place pass: bytes [tid * 16 + 8192 q,
+    // + 16), q < 3, = halo pixel (tid >> 3) + 64 q, slot tid & 7 (the staging waves waited for the LDS-DMA that filled them and a
+    // barrier has passed since).  tinfo: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
     unsigned tinfo = 0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
