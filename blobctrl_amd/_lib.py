@@ -87,10 +87,10 @@ _SIGNATURES = {
     "bc_add_cls_pos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_rowchain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "bc_rowchain_stream_frags": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "bc_rowchain_stream_frags": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bc_rowchain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
-                              C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                              C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     # ---- plan runtime (plan.hip)
     "bc_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bc_plan_destroy": (C.c_int, [C.c_void_p]),
@@ -133,7 +133,7 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
        "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23}
 OP_SIGNAL, OP_WAIT = 20, 21
-CHAIN_IN, CHAIN_MID, CHAIN_OUT = 0, 1, 2
+CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL = 0, 1, 2, 3, 4
 _KIND = {C.c_void_p: "p", C.c_int: "i", C.c_float: "f", C.c_longlong: "l", C.c_char_p: "p"}
 
 

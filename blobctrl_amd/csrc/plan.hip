@@ -49,7 +49,7 @@ const char* op_signature(int op) {
         case BC_OP_GAUSSIAN_SAMPLE: return "ppiiifp";
         case BC_OP_SIGNAL:
         case BC_OP_WAIT: return "i";
-        case BC_OP_ROWCHAIN: return "iiiipppppiiipppppipffppi";
+        case BC_OP_ROWCHAIN: return "iiiipppppiiipppppipffppipi";
         case BC_OP_ASSEMBLE_IM2COL: return "pippiiiiip";
         default: return nullptr;
     }
@@ -165,7 +165,7 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
         case BC_OP_ROWCHAIN:
             return bc_rowchain(I(0), I(1), I(2), I(3), CP(bc_half, 4), CP(float, 5), CP(bc_half, 6), CP(bc_half, 7), CP(bc_half, 8), I(9), I(10),
                                I(11), CP(bc_half, 12), CP(float, 13), MP(bc_half, 14), MP(bc_half, 15), MP(bc_half, 16), I(17), MP(float, 18),
-                               F(19), F(20), CP(float, 21), CP(int, 22), I(23), s);
+                               F(19), F(20), CP(float, 21), CP(int, 22), I(23), MP(float, 24), I(25), s);
         case BC_OP_SIGNAL: {
             hipEvent_t ev;
             int rc = plan_event(pl, I(0), &ev);

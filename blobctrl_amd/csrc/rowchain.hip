@@ -75,6 +75,8 @@ struct RowChainArgs {
     const float* alpha_dev;
     const int* alpha_idx;
     int alpha_bstride;
+    float* part;             // OUT_FF (written) / OUT_TAIL (read): fp32 partial sums of the feed-forward [nsplit][M][C]
+    int nsplit;              // OUT_FF: workgroups per 64-row block (each takes NCH / nsplit hidden chunks); OUT_TAIL: slabs to add
     unsigned long long* stamps;   // BC_RC_STAMPS diagnostics: [workgroup][16] s_memtime stamps (null in production)
 };
 
@@ -389,7 +391,11 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
-    const int m0 = bc_xcd_remap(blockIdx.x, gridDim.x) * RC_BM;
+    // OUT_FF: nsplit workgroups share a row block, each with its own slice of the hidden chunks (and its own weight stream)
+    constexpr bool FF = KIND == BC_CHAIN_OUT_FF, TAIL = KIND == BC_CHAIN_OUT_TAIL;
+    const int wg = bc_xcd_remap(blockIdx.x, gridDim.x);
+    const int z = FF ? wg % a.nsplit : 0;
+    const int m0 = (FF ? wg / a.nsplit : wg) * RC_BM;
     const int b = m0 / a.rows_per_batch;
     const int pix0 = m0 - b * a.rows_per_batch;
     const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);        // this lane's fragment offset inside a (k-step, row-tile) KiB
@@ -402,11 +408,12 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     };
     stamp(0);
 
-    constexpr int RC_R = RC_C == 320 ? (KIND == BC_CHAIN_OUT ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16))
-                                     : (KIND == BC_CHAIN_OUT ? 10 : (KIND == BC_CHAIN_IN ? 14 : 12));   // (8 waves: two per SIMD hide more latency)
+    constexpr bool FFLOOP = KIND == BC_CHAIN_OUT || FF;      // kinds that run the feed-forward loop
+    constexpr int RC_R = RC_C == 320 ? (FFLOOP ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16))
+                                     : (FFLOOP ? 10 : (KIND == BC_CHAIN_IN ? 14 : 12));   // (8 waves: two per SIMD hide more latency)
     static_assert(RC_R <= RC_RPAD, "stream padding");
     WRing<RC_R> ring;
-    ring.p = a.wstream + (size_t)wave * a.wave_frags * 64 + lane;
+    ring.p = a.wstream + ((size_t)z * CF::NW + wave) * a.wave_frags * 64 + lane;
     ring_fill(ring);
 
     f32x4v acc[RC_NT][4];
@@ -467,14 +474,16 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
         return;
     }
 
-    // MID / OUT: X = attention output rows, S = the residual stream
-    rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
-    rows_to_S<RC_C>(a.res + (size_t)m0 * RC_C, S, cm);
-    lds_barrier();
-    stamp(1);
-    gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);               // attn.to_out
-    stamp(2);
-    epi_bias_res<RC_C, true>(acc, vec, S, wave, m, q);                        // + bias + residual (own columns only: no barrier needed)
+    // MID / OUT / OUT_FF: X = attention output rows, S = the residual stream
+    if (!TAIL) {
+        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
+        rows_to_S<RC_C>(a.res + (size_t)m0 * RC_C, S, cm);
+        lds_barrier();
+        stamp(1);
+        gemm_seg<RC_NT, RC_KS, 0, true>(acc, ring, X + xfo);           // attn.to_out
+        stamp(2);
+        epi_bias_res<RC_C, true>(acc, vec, S, wave, m, q);                    // + bias + residual (own columns only: no barrier needed)
+    }
 
     if (KIND == BC_CHAIN_MID) {
         layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
@@ -492,16 +501,20 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     }
 
     // ---- OUT: LayerNorm3 -> GEGLU feed-forward accumulated ON TOP of h2 (acc keeps the residual in fp32) ----
+    // ---- OUT_FF: the same for the hidden chunks [z, z + 1) * NCH / nsplit; only slice 0 keeps h2 under its partial sum ----
+    if (!TAIL) {
     layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
     lds_barrier();
     stamp(3);
+    if (FF && z != 0) zero_acc(acc);
+    const int c_lo = FF ? z * (RC_NCH / a.nsplit) : 0, c_hi = FF ? c_lo + RC_NCH / a.nsplit : RC_NCH;
     {
         const float* b1 = vec + 3 * RC_C;                               // [chunk][wave][pass][value 16 | gate 16]
         constexpr int POS_FF = (RC_NT * RC_KS) % RC_R;
         constexpr int TP = CF::TP, HPW = CF::HW_;                        // (value, gate) tile passes per chunk, hidden units per wave
-        static_assert(KIND != BC_CHAIN_OUT || (TP * 2 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0,
+        static_assert(!FFLOOP || (TP * 2 * RC_KS + RC_NT * (RC_HC / 32)) % RC_R == 0,
                       "a feed-forward chunk must consume a whole number of rings");
-        for (int c = 0; c < RC_NCH; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             char* P = S + (c & 1) * 16384;
             const float* bb = b1 + (c * CF::NW + wave) * (2 * HPW) + 4 * q;
             // (the chunk's GEGLU biases are fetched here, a GEMM pass ahead of their use: behind the pass's sched_barriers they cost
@@ -536,11 +549,30 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
             if (stamps) acc_t[2] += __builtin_amdgcn_s_memtime() - tc;
         }
     }
+    }
     stamp(4);
     if (stamps && tid == 0) {
         stamps[(size_t)blockIdx.x * 16 + 8] = acc_t[0];
         stamps[(size_t)blockIdx.x * 16 + 9] = acc_t[1];
         stamps[(size_t)blockIdx.x * 16 + 10] = acc_t[2];
+    }
+    if (FF) {                                                            // this slice's partial sum (fp32), one 16-byte store per tile
+        float* dst = a.part + ((size_t)z * a.M + m0) * RC_C + 80 * wave + 4 * q;
+#pragma unroll
+        for (int t = 0; t < RC_NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4v*>(dst + (size_t)(16 * mt + m) * RC_C + 16 * t) = acc[t][mt];
+        stamp(7);
+        return;
+    }
+    if (TAIL) {                                                          // h2 + the whole feed-forward = the slices' partial sums, in order
+        const float* src = a.part + (size_t)m0 * RC_C + 80 * wave + 4 * q;
+        for (int zz = 0; zz < a.nsplit; ++zz)
+#pragma unroll
+            for (int t = 0; t < RC_NT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[t][mt] += *reinterpret_cast<const f32x4v*>(src + ((size_t)zz * a.M + 16 * mt + m) * RC_C + 16 * t);
     }
     // (lane-derived values are laundered here: without it hipcc keeps the LDS addresses of the epilogues before and after the
     //  feed-forward loop alive ACROSS it - common subexpressions - and spills two dozen registers around the loop)
@@ -557,7 +589,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     rows_to_S<RC_C>(a.res2 + (size_t)m0 * RC_C, S, cm);
     lds_barrier();
     zero_acc(acc);
-    constexpr int POS_PO = (RC_NT * RC_KS) % RC_R;                      // (the feed-forward consumed whole rings)
+    constexpr int POS_PO = TAIL ? 0 : (RC_NT * RC_KS) % RC_R;           // (the feed-forward consumed whole rings; OUT_TAIL's stream starts here)
     stamp(5);
     gemm_seg<RC_NT, RC_KS, POS_PO, true>(acc, ring, X + xfo);          // proj_out
     stamp(6);
@@ -642,19 +674,22 @@ int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
     RcStampReport report{stream, nwg, a.stamps, KIND};
     static std::atomic<unsigned long long> lds_set{0};
     BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<RC_C, KIND, BLOB>), CF::LDS));
-    hipLaunchKernelGGL((rowchain_kernel<RC_C, KIND, BLOB>), dim3(a.M / RC_BM), dim3(CF::NTH), CF::LDS, stream, a);
+    hipLaunchKernelGGL((rowchain_kernel<RC_C, KIND, BLOB>), dim3(a.M / RC_BM * (KIND == BC_CHAIN_OUT_FF ? a.nsplit : 1)), dim3(CF::NTH), CF::LDS, stream, a);
     BC_CHECK_LAUNCH();
     return 0;
 }
 
 template <int RC_C>
-long long stream_frags(int kind, int blobnet) {
+long long stream_frags(int kind, int blobnet, int nsplit) {
     using CF = RCfg<RC_C>;
     const long long g = CF::G;
+    const long long per_chunk = CF::TP * 2 * CF::KS + RC_NT * (RC_HC / 32);
     long long n = 0;
     if (kind == BC_CHAIN_IN) n = 4 * g;
     else if (kind == BC_CHAIN_MID) n = 2 * g;
-    else if (kind == BC_CHAIN_OUT) n = 2 * g + CF::NCH * (CF::TP * 2 * CF::KS + RC_NT * (RC_HC / 32)) + (blobnet ? g : 0);
+    else if (kind == BC_CHAIN_OUT) n = 2 * g + CF::NCH * per_chunk + (blobnet ? g : 0);
+    else if (kind == BC_CHAIN_OUT_FF && nsplit > 0 && CF::NCH % nsplit == 0) n = g + CF::NCH / nsplit * per_chunk;
+    else if (kind == BC_CHAIN_OUT_TAIL) n = g + (blobnet ? g : 0);
     else return -1;
     return n + RC_RPAD;
 }
@@ -664,6 +699,8 @@ int dispatch_chain(int kind, bool blob, const RowChainArgs& a, hipStream_t s) {
     switch (kind) {
         case BC_CHAIN_IN: return launch_chain<RC_C, BC_CHAIN_IN, false>(a, s);
         case BC_CHAIN_MID: return launch_chain<RC_C, BC_CHAIN_MID, false>(a, s);
+        case BC_CHAIN_OUT_FF: return launch_chain<RC_C, BC_CHAIN_OUT_FF, false>(a, s);
+        case BC_CHAIN_OUT_TAIL: return blob ? launch_chain<RC_C, BC_CHAIN_OUT_TAIL, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT_TAIL, false>(a, s);
         default: return blob ? launch_chain<RC_C, BC_CHAIN_OUT, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT, false>(a, s);
     }
 }
@@ -674,29 +711,34 @@ extern "C" int bc_rowchain_supported(int channels, int M, int rows_per_batch) {
     return (channels == 320 || channels == 640) && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0 && rows_per_batch % RC_BM == 0;
 }
 
-extern "C" long long bc_rowchain_stream_frags(int channels, int kind, int blobnet) {
+extern "C" long long bc_rowchain_stream_frags(int channels, int kind, int blobnet, int nsplit) {
     // fragments (1 KiB per wave-instruction) of ONE wave's weight stream, incl. the padding at the end; -1: unsupported
-    if (channels == 320) return stream_frags<320>(kind, blobnet);
-    if (channels == 640) return stream_frags<640>(kind, blobnet);
+    if (channels == 320) return stream_frags<320>(kind, blobnet, nsplit);
+    if (channels == 640) return stream_frags<640>(kind, blobnet, nsplit);
     return -1;
 }
 
 extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
                            const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                            const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
-                           float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream) {
+                           float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit,
+                           bc_stream stream) {
     BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
                  "rows_per_batch %% %d == 0 (channels=%d M=%d rows_per_batch=%d)", RC_BM, channels, M, rows_per_batch);
-    BC_CHECK_ARG(x && wstream && vec && out0, "bc_rowchain: null pointer");
-    BC_CHECK_ARG(kind == BC_CHAIN_IN || kind == BC_CHAIN_MID || kind == BC_CHAIN_OUT, "bc_rowchain: unknown kind %d", kind);
-    const bool blob = kind == BC_CHAIN_OUT && out1 != nullptr;
+    BC_CHECK_ARG(kind >= BC_CHAIN_IN && kind <= BC_CHAIN_OUT_TAIL, "bc_rowchain: unknown kind %d", kind);
+    BC_CHECK_ARG(wstream && vec && (x || kind == BC_CHAIN_OUT_TAIL) && (out0 || kind == BC_CHAIN_OUT_FF), "bc_rowchain: null pointer");
+    const bool blob = (kind == BC_CHAIN_OUT || kind == BC_CHAIN_OUT_TAIL) && out1 != nullptr;
+    if (kind == BC_CHAIN_OUT_FF || kind == BC_CHAIN_OUT_TAIL)
+        BC_CHECK_ARG(part && nsplit >= 1 && (4 * channels / 128) % nsplit == 0, "bc_rowchain(OUT_FF / OUT_TAIL): needs the partial-sum buffer and nsplit "
+                     "dividing the %d hidden chunks (nsplit=%d)", 4 * channels / 128, nsplit);
     RowChainArgs a;
     a.kind = kind; a.M = M; a.rows_per_batch = rows_per_batch;
     a.x = reinterpret_cast<const h16*>(x); a.affine = affine;
     a.res = reinterpret_cast<const h16*>(res); a.res2 = reinterpret_cast<const h16*>(res2);
     a.r2 = reinterpret_cast<const h16*>(r2); a.r2_xmin = r2_xmin; a.r2_bmod = r2_bmod > 0 ? r2_bmod : 1; a.out_w = out_w > 0 ? out_w : 1;
     a.wstream = reinterpret_cast<const uint4*>(wstream);
-    a.wave_frags = bc_rowchain_stream_frags(channels, kind, blob ? 1 : 0);
+    a.wave_frags = bc_rowchain_stream_frags(channels, kind, blob ? 1 : 0, nsplit);
+    a.part = part; a.nsplit = nsplit > 0 ? nsplit : 1;
     a.vec = vec;
     a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1); a.out2 = reinterpret_cast<h16*>(out2);
     a.ldvt = ldvt; a.gn_part = gn_part; a.ln_eps = ln_eps;
@@ -706,8 +748,9 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
     if (kind == BC_CHAIN_IN)
         BC_CHECK_ARG(out1 && out2 && ldvt >= rows_per_batch && ldvt % 8 == 0, "bc_rowchain(IN): needs out1 (q|k), out2 (V^T) and ldvt >= rows_per_batch, ldvt %% 8 == 0");
     if (kind == BC_CHAIN_MID) BC_CHECK_ARG(res && out1, "bc_rowchain(MID): needs res and out1");
-    if (kind == BC_CHAIN_OUT) {
-        BC_CHECK_ARG(res && res2, "bc_rowchain(OUT): needs res and res2");
+    if (kind == BC_CHAIN_OUT_FF) BC_CHECK_ARG(res, "bc_rowchain(OUT_FF): needs res");
+    if (kind == BC_CHAIN_OUT || kind == BC_CHAIN_OUT_TAIL) {
+        BC_CHECK_ARG((res || kind == BC_CHAIN_OUT_TAIL) && res2, "bc_rowchain(OUT / OUT_TAIL): needs res and res2");
         BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT): r2 needs out_w dividing rows_per_batch");
     }
     return channels == 320 ? dispatch_chain<320>(kind, blob, a, s) : dispatch_chain<640>(kind, blob, a, s);

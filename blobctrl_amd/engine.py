@@ -184,6 +184,15 @@ class TrunkPlan:
             min_blocks = int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640_BLOB_UP", "32"))
         return M // 64 >= min_blocks
 
+    def rowchain_ff_split(self, Cc, M):
+        """Workgroups per 64-row block for the feed-forward of the row-chain's block end (1 = the one-launch form).  A row block's
+        feed-forward is MFMA-bound on ONE CU (640 channels: 120 of the launch's 150 us); with 64 row blocks (UNet, 32 x 64 level) or 32
+        (BlobNet) three quarters of the chip idle meanwhile.  BC_ROWCHAIN_FF_SPLIT_640 / _320 override (must divide 20 / 10 chunks)."""
+        blocks = M // 64
+        if Cc == 640:
+            return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", "2")) if blocks <= 64 else 1
+        return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_320", "1")) if blocks <= 128 else 1
+
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
         """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
         LayerNorm -> q | k | V^T ; attention ; [to_out + residual -> LayerNorm -> attn2.to_q ; cross-attention ;] to_out + residual ->
@@ -198,10 +207,10 @@ class TrunkPlan:
         bp = p + "transformer_blocks.0."
         cache = pw.__dict__.setdefault("_rowchain", {})
 
-        def packed(kind, zname=None):
-            key = (p, kind, zname)
+        def packed(kind, zname=None, nsplit=1):
+            key = (p, kind, zname, nsplit)
             if key not in cache:
-                cache[key] = pack_rowchain(pw, p, kind, zname)
+                cache[key] = pack_rowchain(pw, p, kind, zname, nsplit)
             return cache[key]
         ab = rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"])
         h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
@@ -234,8 +243,18 @@ class TrunkPlan:
             zname, alpha, alpha_dev, alpha_idx, alpha_bstride = zero
             res_out = rec.empty(M, Cc)
             kw.update(out1=res_out, alpha=alpha, alpha_dev=alpha_dev, alpha_idx=alpha_idx, alpha_bstride=alpha_bstride)
-        w, v = packed(_lib.CHAIN_OUT, zero[0] if zero is not None else None)
-        rec.rowchain(_lib.CHAIN_OUT, Cc, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
+        zname = zero[0] if zero is not None else None
+        nsplit = self.rowchain_ff_split(Cc, M)
+        if nsplit > 1:
+            # the block end as two launches, the feed-forward's hidden chunks spread over `nsplit` workgroups per row block
+            ffp = rec.empty(nsplit, M, Cc, dtype=torch.float32)
+            w, v = packed(_lib.CHAIN_OUT_FF, zname, nsplit)
+            rec.rowchain(_lib.CHAIN_OUT_FF, Cc, M, HW, a, w, v, None, res=h, part=ffp, nsplit=nsplit)
+            w, v = packed(_lib.CHAIN_OUT_TAIL, zname)
+            rec.rowchain(_lib.CHAIN_OUT_TAIL, Cc, M, HW, None, w, v, out, res2=x.t, gn_part=part, part=ffp, nsplit=nsplit, **kw)
+        else:
+            w, v = packed(_lib.CHAIN_OUT, zname)
+            rec.rowchain(_lib.CHAIN_OUT, Cc, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
         rec.parts[out.data_ptr()] = (part, nslab)
         return Act(out, Cc, x.H, x.W), res_out
 

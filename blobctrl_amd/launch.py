@@ -517,16 +517,20 @@ class Recorder:
     # ------------------------------------------------------------------ row-chain (fused transformer-block glue, csrc/rowchain.hip)
     def rowchain(self, kind, Cc, M, rows_per_batch, x, wstream, vec, out0, out1=None, out2=None, ldvt=0, affine=None, res=None, res2=None,
                  r2=None, r2_xmin=0, r2_bmod=1, out_w=0, gn_part=None, ln_eps=1e-5, alpha=1.0, alpha_dev=None, alpha_idx=None,
-                 alpha_bstride=0):
-        mult = {_lib.CHAIN_IN: 4, _lib.CHAIN_MID: 2, _lib.CHAIN_OUT: 14 + (1 if out1 is not None else 0)}[kind]
-        refs = (x, wstream, vec, out0, out1, out2, affine, res, res2, r2, gn_part, alpha_dev, alpha_idx)
+                 alpha_bstride=0, part=None, nsplit=1):
+        """`part` / `nsplit`: the split form of the block end (CHAIN_OUT_FF writes, CHAIN_OUT_TAIL reads the fp32 partial sums
+        [nsplit][M][C] of the feed-forward: include/blobctrl_hip.h)."""
+        mult = {_lib.CHAIN_IN: 4, _lib.CHAIN_MID: 2, _lib.CHAIN_OUT: 14 + (1 if out1 is not None else 0), _lib.CHAIN_OUT_FF: 13,
+                _lib.CHAIN_OUT_TAIL: 1 + (1 if out1 is not None else 0)}[kind]
+        refs = (x, wstream, vec, out0, out1, out2, affine, res, res2, r2, gn_part, alpha_dev, alpha_idx, part)
         self.keep.append(refs)
         for t in refs:
             self.register(t)
-        name = {_lib.CHAIN_IN: "in", _lib.CHAIN_MID: "mid", _lib.CHAIN_OUT: "out"}[kind]
+        name = {_lib.CHAIN_IN: "in", _lib.CHAIN_MID: "mid", _lib.CHAIN_OUT: "out", _lib.CHAIN_OUT_FF: f"out_ff/{nsplit}", _lib.CHAIN_OUT_TAIL: "out_tail"}[kind]
         self._op("bc_rowchain", (kind, Cc, M, rows_per_batch, x, affine, res, res2, r2, r2_xmin, r2_bmod, out_w, wstream, vec, out0, out1, out2,
-                                 ldvt, gn_part, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride), "rowchain",
-                 flops=2 * M * Cc * Cc * mult, variant=f"rowchain_kernel<{name}{',zero' if kind == _lib.CHAIN_OUT and out1 is not None else ''}>",
+                                 ldvt, gn_part, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride, part, nsplit), "rowchain",
+                 flops=2 * M * Cc * Cc * mult,
+                 variant=f"rowchain_kernel<{name}{',zero' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else ''}>",
                  shape=("rowchain_" + name, M, Cc, mult * Cc))
         return out0
 

@@ -239,7 +239,7 @@ def _frag_stream(w: torch.Tensor, row_starts, k0: int = 0, k1: int = None) -> to
     return x.permute(0, 3, 1, 4, 2, 5).reshape(nw, -1, 64, 8).contiguous()  # [wave][s][tile][q][m][8] -> lane = 16 q + m
 
 
-def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str] = None):
+def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str] = None, nsplit: int = 1):
     """Weights of one 320- or 640-channel Transformer2D block `p` (e.g. "down_blocks.0.attentions.0.") as rowchain.hip consumes them:
     (wstream [C / 80 waves][fragments][64][8] fp16 in exact consumption order + RC_RPAD fragments of padding, vec fp32).
     kind 0 IN: proj_in, to_q, to_k, to_v | vec = proj_in bias, norm1 gamma, norm1 beta
@@ -247,6 +247,8 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
     kind 2 OUT: attnX.to_out, per 128-wide hidden chunk (ff.net.0.proj (value, gate) tile pairs, ff.net.2 K-slice), proj_out[, zero-conv]
                 | vec = to_out bias, norm3 gamma, beta, GEGLU bias per (chunk, wave, pass: value 16 | gate 16), ff.net.2 bias, proj_out bias
                 [, zero-conv bias]
+    kind 3 OUT_FF (nsplit slices): per slice z: attnX.to_out, the hidden chunks [z, z + 1) * (4C / 128) / nsplit -> wstream
+                [nsplit][waves][fragments][64][8]; kind 4 OUT_TAIL: proj_out[, zero-conv].  Both take the vec of kind 2.
     Built on the device from the trunk's packed matrices (every rank builds its own: nothing to broadcast)."""
     h, f = pw.h, pw.f
     bp = p + "transformer_blocks.0."
@@ -273,22 +275,36 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
         bv, bg = b1[:, 0].reshape(hid), b1[:, 1].reshape(hid)
         w1o = torch.cat([wv, wg], 0)
         w2 = h[bp + "ff.net.2.weight"]
-        segs = [_frag_stream(h[bp + att + ".to_out.0.weight"], nC)]
-        ffb = []
+        seg_to_out = _frag_stream(h[bp + att + ".to_out.0.weight"], nC)
+        ffb, chunks = [], []
         hpw = RC_HC // nw                         # hidden units of a chunk per wave (32 / 16)
         for c in range(hid // RC_HC):
+            cs = []
             for tp in range(hpw // 16):           # (value tile, gate tile) passes over K per chunk
-                segs.append(_frag_stream(w1o, [[RC_HC * c + hpw * w + 16 * tp, hid + RC_HC * c + hpw * w + 16 * tp] for w in range(nw)]))
-            segs.append(_frag_stream(w2, nC, RC_HC * c, RC_HC * (c + 1)))
+                cs.append(_frag_stream(w1o, [[RC_HC * c + hpw * w + 16 * tp, hid + RC_HC * c + hpw * w + 16 * tp] for w in range(nw)]))
+            cs.append(_frag_stream(w2, nC, RC_HC * c, RC_HC * (c + 1)))
+            chunks.append(cs)
             for w in range(nw):
                 for tp in range(hpw // 16):
                     j0 = RC_HC * c + hpw * w + 16 * tp
                     ffb += [bv[j0:j0 + 16], bg[j0:j0 + 16]]
-        segs.append(_frag_stream(h[p + "proj_out.weight"], nC))
+        seg_proj_out = _frag_stream(h[p + "proj_out.weight"], nC)
+        if kind == 2:
+            segs = [seg_to_out] + [x for cs in chunks for x in cs] + [seg_proj_out]
+        elif kind == 4:
+            segs = [seg_proj_out]
         vec = [f[bp + att + ".to_out.0.bias"], f[bp + "norm3.weight"], f[bp + "norm3.bias"], torch.cat(ffb), f[bp + "ff.net.2.bias"],
                f[p + "proj_out.bias"]]
         if zero_name is not None:
-            segs.append(_frag_stream(h[zero_name + ".weight"], nC))
+            if kind != 3:
+                segs.append(_frag_stream(h[zero_name + ".weight"], nC))
             vec.append(f[zero_name + ".bias"])
+        if kind == 3:
+            nchunks = len(chunks)
+            assert nchunks % nsplit == 0, (nchunks, nsplit)
+            pad = torch.zeros(nw, RC_RPAD, 64, 8, dtype=torch.float16, device=seg_to_out.device)
+            per = nchunks // nsplit
+            slices = [torch.cat([seg_to_out] + [x for cs in chunks[z * per:(z + 1) * per] for x in cs] + [pad], 1) for z in range(nsplit)]
+            return torch.stack(slices).contiguous(), torch.cat([v.reshape(-1).float() for v in vec]).contiguous()
     pad = torch.zeros(nw, RC_RPAD, 64, 8, dtype=torch.float16, device=segs[0].device)
     return torch.cat(segs + [pad], 1).contiguous(), torch.cat([v.reshape(-1).float() for v in vec]).contiguous()

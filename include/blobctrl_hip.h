@@ -263,18 +263,24 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  *                 pixel x = (row % out_w) >= r2_xmin) -> out0 [M][C] and gn_part [B][rows_per_batch/64][C][2] (per-channel sum,
  *                 sum of squares of the fp16 output per 64-row slab; NULL: none).  With out1 != NULL (BlobNet) the block
  *                 output also goes through the zero-conv: out1 = (W out0 + b) * alpha * alpha_dev[*alpha_idx (* bstride + image)].
+ *   BC_CHAIN_OUT_FF + BC_CHAIN_OUT_TAIL  the same block end as two launches with the feed-forward's hidden chunks split over `nsplit`
+ *                 workgroups per row block (a 64-row workgroup of the one-launch form does the whole feed-forward on one CU: at 640
+ *                 channels that is 120 us of MFMA work; with few row blocks most of the chip idles meanwhile).  OUT_FF (x, res as for
+ *                 OUT; grid = row blocks x nsplit): to_out + res -> LayerNorm -> its NCH / nsplit hidden chunks -> part[z][M][C] fp32
+ *                 (slice 0 on top of the residual stream).  OUT_TAIL (res2, r2, out0, out1, gn_part as for OUT): sum of the nsplit
+ *                 slices + ff.net.2 bias -> proj_out + res2 (+ r2) [-> zero-conv].  nsplit divides 4C / 128.
  * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
- * consumption order; bc_rowchain_stream_frags(channels, kind, blobnet) gives the length).  M % rows_per_batch == 0,
+ * consumption order, for OUT_FF one set per slice; bc_rowchain_stream_frags(channels, kind, blobnet, nsplit) gives the length).  M % rows_per_batch == 0,
  * rows_per_batch % 64 == 0.  Every workgroup streams the block's whole weight set (4.1 MB at 320 channels, 16.4 MB at 640): worth it
  * from a few dozen row blocks upwards (the engine takes the 640-channel form from 64 row blocks).
  * --------------------------------------------------------------------------------------------------------------- */
-enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2 };
+enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
-long long bc_rowchain_stream_frags(int channels, int kind, int blobnet);
+long long bc_rowchain_stream_frags(int channels, int kind, int blobnet, int nsplit);
 int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
                 const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                 const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
-                float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, bc_stream stream);
+                float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit, bc_stream stream);
 
 /* Layout helpers at the nn.Module boundary (NCHW <-> token-major NHWC, fp32/fp16). */
 int bc_nchw_to_nhwc_f16(const void* src, int src_is_f32, int B, int C, int HW, int Cpad, bc_half* dst, bc_stream stream);

@@ -22,8 +22,10 @@ def _block_sd(cross, seed, zero=False, C=320):
     return sd
 
 
-def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320):
+def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1):
     monkeypatch.setenv("BC_ROWCHAIN_MIN_BLOCKS_640", "1")      # (the engine takes the 640-channel form only from 256 row blocks upwards)
+    monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", str(split))  # feed-forward of the block end over `split` workgroups per row block
+    monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_320", str(split))
     if fused:
         monkeypatch.delenv("BC_NO_ROWCHAIN", raising=False)
     else:
@@ -53,12 +55,16 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320):
     return rec, out, pre, part
 
 
-@pytest.mark.parametrize("cross,B,H,W,with_r2,zero,C", [(True, 2, 16, 32, True, False, 320), (True, 1, 8, 24, True, False, 320),
-                                                        (False, 1, 16, 32, False, True, 320), (False, 2, 8, 8, False, True, 320),
-                                                        (True, 2, 8, 8, True, False, 320), (True, 2, 16, 32, True, False, 640),
-                                                        (False, 1, 8, 24, False, True, 640), (True, 1, 8, 8, True, False, 640)])
-def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C):
-    _, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C)
+@pytest.mark.parametrize("cross,B,H,W,with_r2,zero,C,split", [
+    (True, 2, 16, 32, True, False, 320, 1), (True, 1, 8, 24, True, False, 320, 1), (False, 1, 16, 32, False, True, 320, 1),
+    (False, 2, 8, 8, False, True, 320, 1), (True, 2, 8, 8, True, False, 320, 1), (True, 2, 16, 32, True, False, 640, 1),
+    (False, 1, 8, 24, False, True, 640, 1), (True, 1, 8, 8, True, False, 640, 1),
+    # the block end as OUT_FF + OUT_TAIL, the hidden chunks over 2 / 4 / 5 workgroups per row block
+    (True, 2, 16, 32, True, False, 640, 2), (False, 1, 8, 24, False, True, 640, 4), (True, 1, 8, 8, True, False, 640, 5),
+    (True, 2, 16, 32, True, False, 320, 2), (False, 1, 16, 32, False, True, 320, 5)])
+def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C, split):
+    rec_f, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
+    assert any("out_ff" in (m["variant"] or "") for m in rec_f.seg.meta) == (split > 1)
     _, out_u, pre_u, _ = _record(monkeypatch, False, cross, B, H, W, with_r2, zero, C)
     a, b = out_f.t.float().cpu().numpy(), out_u.t.float().cpu().numpy()
     rel = np.abs(a - b).max() / np.abs(b).max()
@@ -83,5 +89,8 @@ def test_rowchain_rejects_unsupported_shapes():
     lib = _lib.load()
     assert lib.bc_rowchain_supported(320, 2 * 8192, 8192) == 1 and lib.bc_rowchain_supported(640, 4096, 2048) == 1
     assert lib.bc_rowchain_supported(1280, 1024, 512) == 0 and lib.bc_rowchain_supported(320, 96, 96) == 0
-    assert lib.bc_rowchain_stream_frags(320, 0, 0) == 220 and lib.bc_rowchain_stream_frags(320, 2, 1) == 770
-    assert lib.bc_rowchain_stream_frags(640, 1, 0) == 220 and lib.bc_rowchain_stream_frags(640, 2, 0) == 1420
+    assert lib.bc_rowchain_stream_frags(320, 0, 0, 1) == 220 and lib.bc_rowchain_stream_frags(320, 2, 1, 1) == 770
+    assert lib.bc_rowchain_stream_frags(640, 1, 0, 1) == 220 and lib.bc_rowchain_stream_frags(640, 2, 0, 1) == 1420
+    # split block end: OUT_FF = to_out + 20 / nsplit chunks of 60 fragments (+ 20 padding), OUT_TAIL = proj_out [+ zero-conv]
+    assert lib.bc_rowchain_stream_frags(640, 3, 0, 2) == 100 + 10 * 60 + 20 and lib.bc_rowchain_stream_frags(640, 3, 0, 3) == -1
+    assert lib.bc_rowchain_stream_frags(640, 4, 1, 2) == 220 and lib.bc_rowchain_stream_frags(320, 3, 0, 5) == 50 + 2 * 60 + 20

@@ -94,6 +94,17 @@ def main():
         if m["sid"] == 0 and m["kind"] not in ("event_record", "event_wait"):
             t += dur[i]
             unet_cum.append((i, t))
+    for sid, name in ((0, "UNet"), (1, "BlobNet")):
+        kinds = {}
+        for i, m in enumerate(seg.meta):
+            if m["sid"] == sid and m["kind"] not in ("event_record", "event_wait"):
+                k = (m.get("variant") or m["kind"]).split("<")[0] + ("/" + m["kind"] if m["kind"] not in (m.get("variant") or "") else "")
+                a = kinds.setdefault(k, [0, 0.0])
+                a[0] += 1
+                a[1] += dur[i]
+        print(f"{name} queue by kernel / op kind (launches, ms):")
+        for k, (n_, ms) in sorted(kinds.items(), key=lambda kv: -kv[1][1])[:14]:
+            print(f"    {k:44s} {n_:4d} {ms:7.3f}")
     first_wait = next((i for i, m in enumerate(seg.meta) if m["sid"] == 0 and m["kind"] == "event_wait" and i > 2), None)
     if first_wait is not None:
         before = sum(dur[i] for i, m in enumerate(seg.meta) if m["sid"] == 0 and i < first_wait and m["kind"] not in ("event_record", "event_wait"))
