@@ -190,6 +190,8 @@ class TrunkPlan:
         (BlobNet) three quarters of the chip idle meanwhile.  BC_ROWCHAIN_FF_SPLIT_640 / _320 override (must divide 20 / 10 chunks)."""
         blocks = M // 64
         if Cc == 640:
+            if self.cfg.is_blobnet and os.environ.get("BC_ROWCHAIN_FF_SPLIT_640_BLOB"):
+                return int(os.environ["BC_ROWCHAIN_FF_SPLIT_640_BLOB"]) if blocks <= 64 else 1
             return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", "2")) if blocks <= 64 else 1
         return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_320", "1")) if blocks <= 128 else 1
 
