@@ -373,3 +373,29 @@ def test_conv_wreg_fragment_streams(N, Cin):
         k = (ky * 3 + kx) * Cin + chunk * 64 + kg * 32 + 8 * (lane >> 4)
         assert torch.equal(s[frag, lane], w[n, k:k + 8]), (blk, grp, kg, chunk, kx, ky, t, lane)
     assert sorted(s.reshape(-1).tolist()) == sorted(w.reshape(-1).tolist())            # a permutation: nothing lost, nothing doubled
+
+
+def test_rowchain_split_block_end_streams():
+    """weights.pack_rowchain for the two-launch block end (csrc/rowchain.hip BC_CHAIN_OUT_FF / BC_CHAIN_OUT_TAIL): slice z of OUT_FF =
+    to_out + the hidden chunks [z, z + 1) * NCH / nsplit of the one-launch stream, OUT_TAIL = its proj_out (+ zero-conv) tail; the fp32
+    vector is the one-launch vector."""
+    import torch
+    from blobctrl_amd import synth, weights
+    C, boc = 640, (640, 1280)
+    sd = synth.synth_state_dict(synth.trunk_param_shapes(4 + 1 + 3, boc, 1, None, None, blobnet=True), 3)
+    pw = weights.PackedTrunk(sd, "cpu", boc, 1)
+    p = "down_blocks.0.attentions.0."
+    w_one, v_one = weights.pack_rowchain(pw, p, 2, "blobnet_down_blocks.1")
+    nw, ks, nch, per_chunk = C // 80, C // 32, 4 * C // 128, 60
+    g = 5 * ks
+    for nsplit in (2, 4, 5):
+        w_ff, v_ff = weights.pack_rowchain(pw, p, 3, "blobnet_down_blocks.1", nsplit)
+        per = nch // nsplit
+        assert tuple(w_ff.shape) == (nsplit, nw, g + per * per_chunk + weights.RC_RPAD, 64, 8) and torch.equal(v_ff, v_one)
+        for z in range(nsplit):
+            assert torch.equal(w_ff[z][:, :g], w_one[:, :g])                                            # to_out, repeated in every slice
+            assert torch.equal(w_ff[z][:, g:g + per * per_chunk], w_one[:, g + z * per * per_chunk:g + (z + 1) * per * per_chunk])
+            assert float(w_ff[z][:, g + per * per_chunk:].abs().max()) == 0.0                           # ring padding
+    w_t, v_t = weights.pack_rowchain(pw, p, 4, "blobnet_down_blocks.1")
+    assert tuple(w_t.shape) == (nw, 2 * g + weights.RC_RPAD, 64, 8) and torch.equal(v_t, v_one)
+    assert torch.equal(w_t[:, :2 * g], w_one[:, g + nch * per_chunk:g + nch * per_chunk + 2 * g])      # proj_out, zero-conv
