@@ -13,9 +13,12 @@ LIB_PATH = os.environ.get("BLOBCTRL_HIP_LIB") or os.path.join(_HERE, "libblobctr
 A_DENSE, A_CONV3X3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
-TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160", "wreg128x160"]
+TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160", "wreg128x160",
+              "gw64x128", "gw64x256", "gw64x320"]
 TILE_HALO = 8
 TILE_WREG = 9
+TILE_GW64x128, TILE_GW64x256, TILE_GW64x320 = 10, 11, 12
+GW_TILES = {TILE_GW64x128: 2, TILE_GW64x256: 4, TILE_GW64x320: 5}      # configuration -> 16-column tiles per wave (BN = 64 NT)
 
 
 class BcGemm(C.Structure):
@@ -38,6 +41,8 @@ class BcGemm(C.Structure):
         ("a_affine", C.c_void_p), ("a_act", C.c_int),
         ("a_part1", C.c_void_p), ("a_ns1", C.c_int), ("a_part2", C.c_void_p), ("a_ns2", C.c_int),
         ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("a_groups", C.c_int), ("a_eps", C.c_float),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("C_t", C.c_void_p), ("ldc_t", C.c_int), ("n_t0", C.c_int),
     ]
 
 
@@ -52,6 +57,9 @@ _SIGNATURES = {
     "bc_conv_halo_eligible": (C.c_int, [C.c_int] * 8),
     "bc_conv_halo_max_chunks": (C.c_int, []),
     "bc_conv_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_gemm_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_gemm_wreg_stream_elems": (C.c_longlong, [C.c_int, C.c_int]),
+    "bc_gemm_wreg_eligible": (C.c_int, [C.c_int] * 5),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -485,10 +485,27 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     if (p.R) BC_CHECK_ARG(p.ldr >= g.n_out, "bc_gemm: ldr too small");
     if (p.R2) BC_CHECK_ARG(p.ldr2 >= g.n_out && p.r2_bmod > 0, "bc_gemm: bad R2 params");
     if (p.rowvec) BC_CHECK_ARG(p.ld_rowvec >= p.N, "bc_gemm: ld_rowvec too small");
+    const bool gw = bc_gemm_wreg_nt(p.tile_cfg) != 0;
+    BC_CHECK_ARG(gw || (!p.ln_colsum && !p.C_t), "bc_gemm: ln_colsum / C_t need a BC_TILE_GW* configuration");
     if (p.out_mode == BC_OUT_F16_T) {
         BC_CHECK_ARG(p.M % p.rows_per_batch == 0 && p.ldc >= p.rows_per_batch, "bc_gemm: transposed output needs M%%rows_per_batch==0, ldc>=rows_per_batch");
     } else {
-        BC_CHECK_ARG(p.ldc >= g.n_out, "bc_gemm: ldc=%d < n_out=%d", p.ldc, g.n_out);
+        BC_CHECK_ARG(p.ldc >= (p.C_t ? p.n_t0 : g.n_out), "bc_gemm: ldc=%d < n_out=%d", p.ldc, g.n_out);
+    }
+    if (gw) {
+        BC_CHECK_ARG(bc_gemm_wreg_ok(p, p.tile_cfg), "bc_gemm: BC_TILE_GW* needs dense A, M%%64==0, N%%(64 NT)==0, K%%320==0 (C1%%320==0), fp16 row-major "
+                     "output, no split-K / row vector / A prologue (M=%d N=%d K=%d C1=%d)", p.M, p.N, p.K, p.C1);
+        g.nk = p.K / 32; g.kt_per_split = g.nk; p.splitk = 1;
+        g.div_rpb = make_fastdiv((unsigned)p.rows_per_batch);
+        g.div_outw = make_fastdiv((unsigned)p.out_w);
+        g.div_wout = make_fastdiv(1u);
+        g.cfg = p.tile_cfg; g.bm = 64; g.bn = 64 * bc_gemm_wreg_nt(p.tile_cfg);
+        auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+        g.vec_epilogue = g.n_out % 8 == 0 && p.ldc % 8 == 0 && al16(p.C) && (!p.R || (p.ldr % 8 == 0 && al16(p.R))) &&
+                         (!p.R2 || (p.ldr2 % 8 == 0 && al16(p.R2))) && (!p.C_t || al16(p.C_t));
+        BC_CHECK_ARG(g.vec_epilogue, "bc_gemm: BC_TILE_GW* needs 16-byte aligned C / R / R2 / C_t and widths %% 8 == 0");
+        g.vec_transposed = 0; g.nband = 1;
+        return bc_gemm_wreg_launch(g, stream);
     }
     const bool wreg = p.tile_cfg == BC_TILE_WREG;
     const bool halo = p.tile_cfg == BC_TILE_HALO || wreg;

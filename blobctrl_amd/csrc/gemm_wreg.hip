@@ -1,0 +1,397 @@
+// Small-M GEMM with the WEIGHTS STREAMED STRAIGHT INTO VGPRs (gfx950, v_mfma_f32_16x16x32_f16): the projections of the 1280-channel
+// levels of both nets (16 x 32, 8 x 16, mid: M = 128 ... 1024 token rows), BC_TILE_GW64x128 / GW64x256 / GW64x320.
+//
+// Reference ops (diffusers/src/diffusers/models/): attention_processor.py:2191-2224 (to_q / to_k / to_v / to_out), attention.py:447-541
+// (norm1 / norm2 / norm3 in front of them, the residual adds behind them), activations.py:113-123 + attention.py:1161-1167 (GEGLU
+// feed-forward), transformers/transformer_2d.py:484,521 (proj_in / proj_out), resnet.py:368 (conv_shortcut),
+// blobctrl/models/blobnet.py:860-864,921-924 (zero-convs).
+//
+// Why another GEMM kernel.  At M <= 1024 a projection is a few GFLOP: the LDS-DMA tiles of gemm_fast.hip run their k-loop at the
+// per-CU LDS-DMA rate (~22 B/clk) and spend as long again outside it.  Same recipe as conv_wreg.hip / rowchain.hip:
+//   * a workgroup (4 waves) owns 64 token rows x BN = 64 NT columns; wave w owns the 16 NT columns [16 NT w, 16 NT (w + 1)) for ALL 64
+//     rows, so no weight is shared between waves and the weights stream L2/HBM -> VGPR from a per-wave fragment stream
+//     (bc_gemm_wreg_pack: lane l of a 1-KiB fragment holds W[n + (l & 15)][k + 8 (l >> 4) .. + 8]; k-step outermost) through a register
+//     ring that stays RING fragments ahead of the MFMAs - no LDS, no barrier inside the k-loop;
+//   * the activation rows are the operand the four waves SHARE: they go through LDS as X = [k-step][64 rows][32 k] (64-byte rows, 16-byte
+//     chunks XOR-swizzled: every ds_read_b128 fragment read conflict-free) in chunks of 320 k, double-buffered; the next chunk's rows are
+//     in flight in registers while the current one is multiplied; one barrier per chunk;
+//   * the product is swapped (D^T = W . X^T): a lane holds 4 consecutive output channels of one row - one 16-byte LDS store parks them
+//     in the fp32 epilogue tile; the row-major pass is the shared 8-column epilogue of the GEMM family (epi8_store: bias, GEGLU,
+//     scale, residual, BlobNet right-half residual, GroupNorm partials);
+//   * LayerNorm in front of the projection is FOLDED (BcGemm.ln_colsum): the host scales W by gamma, the rows enter raw, their
+//     statistics are accumulated (v_dot2_f32_f16) while they are staged, and the epilogue applies
+//         rstd_r (acc[r][n] - mean_r colsum[n]) + bias'[n],   colsum[n] = sum_k W'[n][k],  bias' = bias + W beta:
+//     no LayerNorm launch, no normalised activation in HBM;
+//   * q | k | V^T in one launch (BcGemm.C_t): column tiles from n_t0 on are written transposed [B][N - n_t0][ldc_t].
+// XCD placement: consecutive workgroups of an XCD share a COLUMN tile (all its row blocks), so an XCD's L2 fetches each weight
+// stream once.
+#include <stdlib.h>
+#include "gemm_common.h"
+
+using namespace bcg;
+
+namespace {
+
+constexpr int GW_BM = 64;               // rows per workgroup
+constexpr int GW_KC = 10;               // k-steps (of 32) per LDS chunk: 320 k
+constexpr int GW_XBUF = GW_KC * 4096;   // one operand chunk: [10][64 rows][64 B]
+constexpr int GW_NPF = 10;              // 16-byte pieces a thread stages per chunk (2 rows x 5)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ h16x8 as_h8(uint4 v) { return __builtin_bit_cast(h16x8, v); }
+
+__device__ __forceinline__ void lds_barrier() {
+    // LDS visibility only: the weight ring's global loads stay in flight across it (a __syncthreads() would drain them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int R>
+struct WRing {
+    uint4 f[R];
+    const uint4* p;          // this lane's next fragment to LOAD
+};
+
+// X operand image: byte offset of the 16-byte chunk kc (0..3) of `row` in k-step s (rowchain.hip's layout)
+__device__ __forceinline__ int x_off(int s, int row, int kc) { return s * 4096 + row * 64 + ((kc ^ ((0 - ((row & 15) >> 2)) & 3)) << 4); }
+
+// One chunk: acc[t][mt] += W-tile t (16 channels) x rows-tile mt (16 rows) over GW_KC k-steps.  Issue order per k-step pinned with
+// sched_barrier as in rowchain.hip (left alone hipcc sinks the ring refills and the prefetch distance collapses): refill the slots the
+// PREVIOUS step consumed, read the NEXT step's operand fragments, then this step's MFMAs run under both.  (NT * GW_KC) % R == 0, so the
+// ring position is 0 at the top of every chunk.
+template <int NT, int R>
+__device__ __forceinline__ void gemm_chunk(f32x4v (&acc)[NT][4], WRing<R>& r, const char* xb) {
+    h16x8 xq[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xq[0][mt] = *reinterpret_cast<const h16x8*>(xb + mt * 1024);
+#pragma unroll
+    for (int s = 0; s < GW_KC; ++s) {
+        if (s > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r.f[((s - 1) * NT + t) % R] = r.p[t * 64];
+            r.p += NT * 64;
+        }
+        if (s + 1 < GW_KC) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xq[(s + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(xb + (s + 1) * 4096 + mt * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h16x8 w = as_h8(r.f[(s * NT + t) % R]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xq[s & 1][mt], acc[t][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r.f[((GW_KC - 1) * NT + t) % R] = r.p[t * 64];
+    r.p += NT * 64;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// fp32 epilogue tile [64][BN]: float4 slot (row, c0) lives at column c0 ^ ((row & 7) << 2) - the 8 lanes of a ds_write_b128 service
+// group hold 8 different rows of one column block and land on 8 different 16-byte bank groups.
+template <int BN>
+__device__ __forceinline__ int tile_off(int row, int c0) { return row * BN + (c0 ^ ((row & 7) << 2)); }
+
+template <int NT, int R>
+__global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
+    constexpr int BN = 64 * NT;
+    static_assert((NT * GW_KC) % R == 0, "a chunk must consume a whole number of rings");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BcGemm& p = g.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int nrb = p.M / GW_BM;
+    const int wg = bc_xcd_remap(blockIdx.x, gridDim.x);
+    const int jt = wg / nrb;                          // column tile (slow index: an XCD's workgroups share it)
+    const int m0 = (wg - jt * nrb) * GW_BM, n0 = jt * BN;
+    const int KS = p.K >> 5;
+    const int nchunk = KS / GW_KC;
+
+    WRing<R> ring;
+    ring.p = reinterpret_cast<const uint4*>(p.W) + ((size_t)(jt * 4 + wave) * KS * NT) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < R; ++i) ring.f[i] = ring.p[i * 64];
+    ring.p += R * 64;
+
+    // ---- activation staging: thread (v8 = tid & 7, row = tid >> 3) moves the 16-byte pieces v8 + 8 k (k < 5) of the rows row, row + 32 of a chunk
+    const int srow = tid >> 3, v8 = tid & 7;
+    const int xbase = x_off(v8 >> 2, srow, v8 & 3);
+    const h16* a1 = reinterpret_cast<const h16*>(p.A) + (size_t)(m0 + srow) * p.lda + v8 * 8;
+    const h16* a2 = p.A2 ? reinterpret_cast<const h16*>(p.A2) + (size_t)(m0 + srow) * p.lda2 + v8 * 8 : nullptr;
+    const int lda32 = 32 * p.lda, lda32_2 = 32 * p.lda2;
+    uint4 pf[GW_NPF];
+    auto issue = [&](int c) {
+        const int k0 = c * (GW_KC * 32);
+        const bool second = a2 != nullptr && k0 >= p.C1;           // (workgroup-uniform: C1 % 320 == 0)
+        const h16* src = second ? a2 + (k0 - p.C1) : a1 + k0;
+        const int ld32 = second ? lda32_2 : lda32;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            pf[2 * k] = *reinterpret_cast<const uint4*>(src + k * 64);
+            pf[2 * k + 1] = *reinterpret_cast<const uint4*>(src + k * 64 + ld32);
+        }
+    };
+    float st[2][2] = {{0.f, 0.f}, {0.f, 0.f}};       // LayerNorm fold: (sum, sum of squares) of this thread's pieces of its two rows
+    const bool ln = p.ln_colsum != nullptr;
+    auto land = [&](int c) {
+        char* xb = smem + (c & 1) * GW_XBUF + xbase;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint4 d = pf[2 * k + j];
+                if (ln) {
+                    const h16x2 one = {(h16)1.0f, (h16)1.0f};
+                    const h16x2* e = reinterpret_cast<const h16x2*>(&d);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        st[j][0] = __builtin_amdgcn_fdot2(e[i], one, st[j][0], false);
+                        st[j][1] = __builtin_amdgcn_fdot2(e[i], e[i], st[j][1], false);
+                    }
+                }
+                *reinterpret_cast<uint4*>(xb + k * 2 * 4096 + j * 32 * 64) = d;
+            }
+    };
+
+    f32x4v acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    land(0);
+    if (nchunk > 1) issue(1);
+    lds_barrier();
+    const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);      // this lane's fragment offset inside a (k-step, row-tile) KiB
+    for (int c = 0; c < nchunk; ++c) {
+        gemm_chunk<NT, R>(acc, ring, smem + (c & 1) * GW_XBUF + xfo);
+        if (c + 1 < nchunk) {
+            land(c + 1);                              // (the buffer's last readers passed the previous barrier)
+            if (c + 2 < nchunk) issue(c + 2);
+        }
+        lds_barrier();
+    }
+
+    // ------------------------------------------------------------------------------------------------ epilogue
+    // (every wave is past the last barrier: the operand buffers are free)
+    float* tile = reinterpret_cast<float*>(smem);
+    float* stat = reinterpret_cast<float*>(smem + GW_BM * BN * 4);     // [64 rows][2] = (mean, rstd) of the LayerNorm fold
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c0 = 16 * NT * wave + 16 * t + 4 * q;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4v*>(tile + tile_off<BN>(16 * mt + m, c0)) = acc[t][mt];
+    }
+    if (ln) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s = st[j][0], ss = st[j][1];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                s += __shfl_xor(s, o);
+                ss += __shfl_xor(ss, o);
+            }
+            if (v8 == 0) {
+                const float mean = s / (float)p.K;
+                const float var = fmaxf(ss / (float)p.K - mean * mean, 0.f);
+                stat[(srow + 32 * j) * 2] = mean;
+                stat[(srow + 32 * j) * 2 + 1] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+            }
+        }
+    }
+    __syncthreads();
+
+    if (p.C_t && n0 >= p.n_t0) {
+        // transposed output (V^T for the attention kernel): thread = (column, 8 consecutive tokens) -> one 16-byte store
+        const int b = (int)fdiv((unsigned)m0, g.div_rpb);
+        const int pix0 = m0 - b * (int)g.div_rpb.d;
+        const int nt_out = p.N - p.n_t0;
+        for (int idx = tid; idx < BN * 8; idx += 256) {
+            const int col = idx >> 3, mc = idx & 7;
+            const int n = n0 + col;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float cs = ln ? p.ln_colsum[n] : 0.f;
+            uint4 outraw;
+            h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = mc * 8 + j;
+                float v = tile[tile_off<BN>(row, col & ~3) + (col & 3)];
+                if (ln) v = stat[row * 2 + 1] * (v - stat[row * 2] * cs);
+                o[j] = (h16)(v + bias);
+            }
+            bc_st16(reinterpret_cast<h16*>(p.C_t) + ((size_t)b * nt_out + (n - p.n_t0)) * p.ldc_t + pix0 + mc * 8, outraw);
+        }
+        return;
+    }
+
+    // ---- row-major pass, 8 output columns per thread (gemm_fast.hip's, with the LayerNorm fold in front of the bias) ----
+    const float alpha = scalar_alpha(p);
+    const bool geglu = p.act == BC_ACT_GEGLU;
+    const int TSO = geglu ? BN / 2 : BN;            // output columns of this block
+    const int CPR = TSO / 8;                        // 8-column chunks per tile row
+    const int RG = 256 / CPR;                       // rows one pass of the block covers
+    const int col8 = tid % CPR, rg = tid / CPR;
+    const bool active = rg < RG;
+    const int c_out = col8 * 8;
+    const int n_first = (geglu ? n0 / 2 : n0) + c_out;
+    const int cv = geglu ? (c_out >> 5) * 64 + (c_out & 31) : c_out;      // tile column of the (value) accumulators
+    Cols8 cols;
+    cols8_init(g, cols, n_first, n0 + cv, geglu, alpha);
+    float csv[8], csg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        csv[j] = ln ? p.ln_colsum[n0 + cv + j] : 0.f;
+        csg[j] = (ln && geglu) ? p.ln_colsum[n0 + cv + 32 + j] : 0.f;
+    }
+    float gs[8], gq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+    if (active) {
+        for (int row = rg; row < GW_BM; row += RG) {
+            const float4 lo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv));
+            const float4 hi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 4));
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (geglu) {
+                const float4 glo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 32));
+                const float4 ghi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 36));
+                gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
+                gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
+            }
+            if (ln) {
+                const float mean = stat[row * 2], rstd = stat[row * 2 + 1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = rstd * (v[j] - mean * csv[j]);
+                    gt[j] = rstd * (gt[j] - mean * csg[j]);
+                }
+            }
+            epi8_store(g, cols, v, gt, m0 + row, gs, gq);
+        }
+    }
+    if (p.gn_part) {
+        // per-channel (sum, sum of squares) of the fp16 output over the block's 64 rows: threads of equal col8 combine through LDS
+        __syncthreads();                            // tile fully consumed; reuse its head as scratch [RG][TSO][2]
+        float* scr = reinterpret_cast<float*>(smem);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                scr[((rg * TSO) + c_out + j) * 2] = gs[j];
+                scr[((rg * TSO) + c_out + j) * 2 + 1] = gq[j];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < TSO; c += 256) {
+            float s = 0.f, qq = 0.f;
+            for (int r = 0; r < RG; ++r) {
+                s += scr[(r * TSO + c) * 2];
+                qq += scr[(r * TSO + c) * 2 + 1];
+            }
+            const int b = (int)fdiv((unsigned)m0, g.div_rpb);
+            const int slab = (m0 - b * (int)g.div_rpb.d) / GW_BM;
+            const int nslab = (int)g.div_rpb.d / GW_BM;
+            float* dst = p.gn_part + (((size_t)b * nslab + slab) * g.n_out + (geglu ? n0 / 2 : n0) + c) * 2;
+            dst[0] = s;
+            dst[1] = qq;
+        }
+    }
+}
+
+template <int NT, int R>
+int launch_gw(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BN = 64 * NT;
+    constexpr int LDS = (2 * GW_XBUF > GW_BM * BN * 4 ? 2 * GW_XBUF : GW_BM * BN * 4) + GW_BM * 2 * 4;
+    static_assert(2 * LDS <= 160 * 1024 + 2 * 512, "two workgroups per CU");
+    static std::atomic<unsigned long long> lds_set{0};
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_wreg_kernel<NT, R>), LDS));
+    const int grid = (g.p.M / GW_BM) * (g.p.N / BN);
+    hipLaunchKernelGGL((gemm_wreg_kernel<NT, R>), dim3(grid), dim3(256), LDS, stream, g);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void gw_pack_kernel(const h16* __restrict__ w, int ldw, int N, int K, int NT, uint4* __restrict__ out) {
+    // one thread per 16-byte piece of the stream [column tile][wave][k-step][tile][lane = 16 q + r][8]
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * K / 8;
+    if (idx >= total) return;
+    const int KS = K / 32;
+    const int lane = (int)(idx & 63);
+    long long f = idx >> 6;                          // fragment index
+    const int t = (int)(f % NT); f /= NT;
+    const int s = (int)(f % KS); f /= KS;
+    const int wave = (int)(f & 3);
+    const int jt = (int)(f >> 2);
+    const int n = jt * 64 * NT + wave * 16 * NT + 16 * t + (lane & 15);
+    const int k = 32 * s + 8 * (lane >> 4);
+    out[idx] = *reinterpret_cast<const uint4*>(w + (size_t)n * ldw + k);
+}
+
+}  // namespace
+
+int bc_gemm_wreg_nt(int tile_cfg) {
+    return tile_cfg == BC_TILE_GW64x128 ? 2 : tile_cfg == BC_TILE_GW64x256 ? 4 : tile_cfg == BC_TILE_GW64x320 ? 5 : 0;
+}
+
+// 1 when bc_gemm can run this problem on the given BC_TILE_GW* configuration
+int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg) {
+    const int nt = bc_gemm_wreg_nt(tile_cfg);
+    if (!nt || p.a_mode != BC_A_DENSE) return 0;
+    if (p.M <= 0 || p.M % GW_BM || p.N % (64 * nt) || p.K % (32 * GW_KC)) return 0;
+    if (p.A2 && (p.C1 % (32 * GW_KC) || p.C1 <= 0 || p.C1 >= p.K)) return 0;
+    if (p.out_mode != BC_OUT_F16 || p.splitk > 1 || p.rowvec || p.a_affine || p.a_part1) return 0;
+    if (p.act != BC_ACT_NONE && p.act != BC_ACT_GEGLU && p.act != BC_ACT_GELU && p.act != BC_ACT_SILU && p.act != BC_ACT_QUICK_GELU) return 0;
+    if (p.ln_colsum && p.A2) return 0;               // (the statistics cover one source)
+    if (p.C_t) {
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (p.n_t0 <= 0 || p.n_t0 % (64 * nt) || p.n_t0 >= p.N || rpb % GW_BM || p.M % rpb || p.ldc_t < rpb || p.ldc_t % 8 ||
+            p.act != BC_ACT_NONE || p.R || p.R2 || p.colscale || p.gn_part || p.alpha_dev || p.alpha != 1.0f)
+            return 0;
+    }
+    if (p.gn_part) {
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (rpb % GW_BM || p.M % rpb) return 0;
+    }
+    return 1;
+}
+
+int bc_gemm_wreg_launch(const GemmArgs& g, hipStream_t stream) {
+    switch (g.cfg) {
+        case BC_TILE_GW64x128: return launch_gw<2, 20>(g, stream);
+        case BC_TILE_GW64x256: return launch_gw<4, 20>(g, stream);
+        case BC_TILE_GW64x320: return launch_gw<5, 10>(g, stream);
+        default: bc_set_error("bc_gemm: not a BC_TILE_GW* configuration (%d)", g.cfg); return 1;
+    }
+}
+
+extern "C" int bc_gemm_wreg_eligible(int M, int N, int K, int C1, int tile_cfg) {
+    BcGemm p = {};
+    p.a_mode = BC_A_DENSE; p.M = M; p.N = N; p.K = K; p.C1 = C1; p.out_mode = BC_OUT_F16; p.splitk = 1; p.alpha = 1.0f;
+    p.A2 = C1 > 0 ? reinterpret_cast<const bc_half*>(&p) : nullptr;       // (only tested for non-null)
+    return bc_gemm_wreg_ok(p, tile_cfg);
+}
+
+extern "C" long long bc_gemm_wreg_stream_elems(int N, int K) {
+    // elements (bc_half) of a packed stream incl. the tail the register ring reads past the last fragment (never used)
+    return (long long)N * K + 32 * 512;
+}
+
+extern "C" int bc_gemm_wreg_pack(const bc_half* w, int ldw, int N, int K, int tile_cfg, bc_half* out, bc_stream stream) {
+    const int nt = bc_gemm_wreg_nt(tile_cfg);
+    BC_CHECK_ARG(w && out && nt && N > 0 && N % (64 * nt) == 0 && K > 0 && K % 32 == 0 && ldw >= K && ldw % 8 == 0,
+                 "bc_gemm_wreg_pack: needs a BC_TILE_GW* configuration, N %% %d == 0 and K %% 32 == 0 (N=%d K=%d)", 64 * nt, N, K);
+    BC_CHECK_ARG(w != out, "bc_gemm_wreg_pack: out of place only");
+    const long long total = (long long)N * K / 8;
+    hipLaunchKernelGGL(gw_pack_kernel, dim3(bc_ceil_div(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const h16*>(w), ldw, N, K, nt, reinterpret_cast<uint4*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}

@@ -60,7 +60,8 @@ const size_t kGemmPtrFields[] = {
     offsetof(BcGemm, A), offsetof(BcGemm, A2), offsetof(BcGemm, W), offsetof(BcGemm, bias), offsetof(BcGemm, rowvec),
     offsetof(BcGemm, rowvec_idx), offsetof(BcGemm, colscale), offsetof(BcGemm, alpha_dev), offsetof(BcGemm, alpha_idx),
     offsetof(BcGemm, R), offsetof(BcGemm, R2), offsetof(BcGemm, C), offsetof(BcGemm, gn_part), offsetof(BcGemm, a_affine),
-    offsetof(BcGemm, a_part1), offsetof(BcGemm, a_part2), offsetof(BcGemm, a_gamma), offsetof(BcGemm, a_beta)};
+    offsetof(BcGemm, a_part1), offsetof(BcGemm, a_part2), offsetof(BcGemm, a_gamma), offsetof(BcGemm, a_beta),
+    offsetof(BcGemm, ln_colsum), offsetof(BcGemm, C_t)};
 
 struct Rec {
     int op = 0, sid = 0, enabled = 1;
@@ -219,7 +220,7 @@ int get_streams(BcPlan* pl, const bc_stream* streams, int n, hipStream_t* out) {
 
 // ---- file format helpers ----
 const uint32_t kMagic = 0x4E4C5042u;   // "BPLN"
-const uint32_t kVersion = 1;
+const uint32_t kVersion = 2;        // 2: BcGemm grew ln_colsum / C_t (round 4)
 
 struct Writer {
     FILE* f;

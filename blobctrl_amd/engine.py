@@ -162,7 +162,14 @@ class TrunkPlan:
             kw = {}
             if skip is not None:
                 kw.update(A2=skip.t, C1=x.C, lda=x.C, lda2=skip.C)
-            sc = Act(self.dense(x.t, M, Cin, p + "conv_shortcut", Cout, kind="conv1x1", **kw), Cout, x.H, x.W)
+            gw = self.gw_tile(M, Cout, Cin, x.C if skip is not None else 0) if Cout >= 1280 else 0
+            if gw:                                        # low-resolution levels: weights streamed into VGPRs (gemm_wreg.hip)
+                w, _, b = pw.gw(p + "conv_shortcut.weight", gw, bias=p + "conv_shortcut.bias")
+                out = self.rec.empty(M, Cout)
+                self.rec.gemm(A=x.t, W=w, M=M, N=Cout, K=Cin, out=out, bias=b, tile_cfg=gw, kind="conv1x1", **kw)
+                sc = Act(out, Cout, x.H, x.W)
+            else:
+                sc = Act(self.dense(x.t, M, Cin, p + "conv_shortcut", Cout, kind="conv1x1", **kw), Cout, x.H, x.W)
         else:
             assert skip is None and Cin == Cout
             sc = x
@@ -260,6 +267,61 @@ class TrunkPlan:
         rec.parts[out.data_ptr()] = (part, nslab)
         return Act(out, Cc, x.H, x.W), res_out
 
+    def gw_tile(self, M, N, K, C1=0, prefer=None):
+        """BC_TILE_GW* configuration for a projection of the low-resolution levels (csrc/gemm_wreg.hip), or 0 = the LDS-DMA tiles.
+        Measured per shape on an MI355X (tools/gw_probe.py, cold weights, graph replay): at M <= 1024 every projection is latency-bound
+        (~11 us whatever the kernel), so the choice only matters where a launch disappears with it (LayerNorm folded, q | k | V^T in one
+        launch) or the grid fills the chip (N >= 2560)."""
+        if os.environ.get("BC_NO_GW") or M > 1024:
+            return 0
+        order = prefer or (_lib.TILE_GW64x128,)
+        for cfg in order:
+            if self.rec.lib.bc_gemm_wreg_eligible(M, N, K, C1, cfg):
+                return cfg
+        return 0
+
+    def transformer_gw(self, p, x: Act, r2=None):
+        """One Transformer2D block of the 1280-channel levels on gemm_wreg.hip: the three LayerNorms are folded into the projections
+        behind them (no LayerNorm launch, no normalised activation in HBM), q | k | V^T come out of ONE launch: 15 launches -> 11."""
+        rec, pw, B = self.rec, self.pw, self.B
+        Cc, HW = x.C, x.H * x.W
+        M = B * HW
+        d = Cc // self.heads
+        scale = d ** -0.5
+        bp = p + "transformer_blocks.0."
+        G128, G256, G320 = _lib.TILE_GW64x128, _lib.TILE_GW64x256, _lib.TILE_GW64x320
+
+        def proj(a_t, wname, N, K, cfg, ln=None, bias=True, extra=(), **kw):
+            w, cs, b = pw.gw(wname + ".weight", cfg, ln=ln, bias=(wname + ".bias") if bias else None, extra=extra)
+            n_out = N // 2 if kw.get("act") == _lib.ACT_GEGLU else N
+            out = kw.pop("out", None)
+            if out is None:
+                out = rec.empty(M, kw.get("n_t0") or n_out)
+            rec.gemm(A=a_t, W=w, M=M, N=N, K=K, out=out, bias=b, tile_cfg=cfg, ln_colsum=cs, **kw)
+            return out
+        n = self.groupnorm(x, None, p + "norm", 1e-6, False)
+        h = proj(n.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1")
+        # --- self attention: LayerNorm1 folded; q | k row-major, V transposed for the attention kernel
+        ldvt = (HW + 63) // 64 * 64
+        vt = rec.zeros(B, Cc, ldvt)
+        qk = proj(h, bp + "attn1.to_qk", 3 * Cc, Cc, G256, ln=bp + "norm1", bias=False, extra=(bp + "attn1.to_v.weight",), C_t=vt, ldc_t=ldvt,
+                  n_t0=2 * Cc, rows_per_batch=HW, kind="qkv")
+        a = rec.empty(M, Cc)
+        rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
+                      scale, q_off=0, k_off=Cc)
+        h = proj(a, bp + "attn1.to_out.0", Cc, Cc, G128, R=h, ldr=Cc, kind="attn_out")
+        if pw.has_cross:
+            q = proj(h, bp + "attn2.to_q", Cc, Cc, G128, ln=bp + "norm2", bias=False, kind="qkv")
+            ck, cvt, T, ldc_vt = self.ctx_kv[bp]
+            a = rec.empty(M, Cc)
+            rec.attention(q, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
+            h = proj(a, bp + "attn2.to_out.0", Cc, Cc, G128, R=h, ldr=Cc, kind="attn_out")
+        # --- GEGLU feed-forward: LayerNorm3 folded into ff.net.0; ff.net.2 (K = 4C) stays on the LDS-DMA tiles with split-K
+        g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G320 if M >= 512 else G256, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
+        h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
+        out = proj(h, p + "proj_out", Cc, Cc, G128, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True, **self._r2(r2, x.H, x.W))
+        return Act(out, Cc, x.H, x.W), None
+
     def transformer(self, p, x: Act, r2=None, zero=None):
         """transformer_2d.py:479-527 + attention.py:421-541 (one BasicTransformerBlock).  Returns (output, zero-conv residual or None)."""
         rec, pw, B = self.rec, self.pw, self.B
@@ -267,6 +329,8 @@ class TrunkPlan:
         M = B * HW
         if self.rowchain_ok(Cc, M, HW, p):
             return self.transformer_rowchain(p, x, r2, zero)
+        if Cc % 320 == 0 and HW % 64 == 0 and self.gw_tile(M, Cc, Cc):
+            return self.transformer_gw(p, x, r2)
         d = Cc // self.heads
         scale = d ** -0.5
         bp = p + "transformer_blocks.0."

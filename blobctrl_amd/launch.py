@@ -305,7 +305,7 @@ class Recorder:
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rowvec_idx=None, rowvec_step=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None,
-             a_affine=None, a_act=_lib.ACT_NONE, a_gn=None):
+             a_affine=None, a_act=_lib.ACT_NONE, a_gn=None, ln_colsum=None, ln_eps=1e-5, C_t=None, ldc_t=0, n_t0=0):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
@@ -336,7 +336,9 @@ class Recorder:
         g.R2, g.ldr2, g.r2_xmin, g.r2_bmod, g.out_w = ptr(R2), ldr2, r2_xmin, r2_bmod, out_w
         g.out_mode = out_mode
         g.C = out.data_ptr() + out_offset * out.element_size()
-        g.ldc = ldc if ldc is not None else n_out
+        g.ldc = ldc if ldc is not None else (n_t0 if C_t is not None else n_out)
+        g.ln_colsum, g.ln_eps = ptr(ln_colsum), ln_eps
+        g.C_t, g.ldc_t, g.n_t0 = ptr(C_t), ldc_t, n_t0
         # mirror of the C-side fast-path eligibility (bc_gemm)
         fast = K % 64 == 0
         mode = "dense"
@@ -399,6 +401,11 @@ class Recorder:
                     a_affine = self.gn_affine(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"], G_, a_gn["eps"],
                                               a_gn["gamma"], a_gn["beta"])
                     g.a_affine = ptr(a_affine)
+        elif tile_cfg in _lib.GW_TILES:
+            # small-M projection with the weights streamed into VGPRs (gemm_wreg.hip); W is the stream packed for this configuration
+            assert not conv and a_affine is None and splitk in (None, 1) and rowvec is None
+            cfg, sk, bm, bn = tile_cfg, 1, 64, 64 * _lib.GW_TILES[tile_cfg]
+            fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "")
         else:
             assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO / TILE_WREG"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
@@ -423,12 +430,12 @@ class Recorder:
         idx = self.lib.bc_plan_add_gemm(self.plan, self.seg.id, self.sid, C.byref(g))
         if idx < 0 or idx != len(self.seg.meta):
             _lib.check(1, "bc_plan_add_gemm")
-        refs = (A, A2, W, out, bias, R, R2, rowvec, rowvec_idx, colscale, alpha_dev, alpha_idx, part, a_affine)
+        refs = (A, A2, W, out, bias, R, R2, rowvec, rowvec_idx, colscale, alpha_dev, alpha_idx, part, a_affine, ln_colsum, C_t)
         self.keep.append(refs)
         for t in refs:
             self.register(t)
         variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "conv_wreg_kernel<" if cfg == _lib.TILE_WREG else
-                   "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
+                   "gemm_wreg_kernel<" if cfg in _lib.GW_TILES else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
         self._push(kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
         return out

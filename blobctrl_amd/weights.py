@@ -91,8 +91,48 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
     return torch.cat([wv, wg], dim=1).reshape(2 * n, -1).contiguous(), torch.cat([bv, bg], dim=1).reshape(2 * n).contiguous()
 
 
+def pack_gemm_wreg(w: torch.Tensor, nt: int) -> torch.Tensor:
+    """[N][K] matrix -> the per-wave fragment streams of a BC_TILE_GW* configuration with `nt` 16-column tiles per wave
+    (csrc/gemm_wreg.hip, same bytes as `bc_gemm_wreg_pack`): [column tile][wave 4][k-step][tile][lane = 16 q + r][8], lane l holding
+    w[n0 + 16 tile + (l & 15)][32 s + 8 (l >> 4) : + 8]; followed by the 32 fragments the register ring reads past the end (zeros)."""
+    N, K = w.shape
+    assert N % (64 * nt) == 0 and K % 32 == 0, (N, K, nt)
+    v = w.reshape(N // (64 * nt), 4, nt, 16, K // 32, 4, 8)            # [j, wave, t, r, s, q, e]
+    v = v.permute(0, 1, 4, 2, 5, 3, 6).reshape(-1)                      # [j, wave, s, t, q, r, e]
+    return torch.cat([v, torch.zeros(32 * 512, dtype=w.dtype, device=w.device)])
+
+
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm -> Linear folded for BcGemm.ln_colsum (csrc/gemm_wreg.hip): returns (W' = fp16(W diag(gamma)), colsum of the ROUNDED
+    W' in fp32, bias' = bias + W beta in fp32), so that Linear(LN(x)) = rstd (x W'^T - mean colsum) + bias'."""
+    wf = w.float()
+    w2 = (wf * gamma.float()[None, :]).half()
+    cs = w2.float().sum(1)
+    b2 = wf @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return w2, cs.contiguous(), b2.contiguous()
+
+
 class PackedTrunk:
     """Device-resident packed weights of one trunk (UNet or BlobNet)."""
+
+    def gw(self, key: str, tile_cfg: int, ln: Optional[str] = None, bias: Optional[str] = None, extra=()):
+        """Fragment stream of the matrix `key` (or of the row-concatenation key + extra) for a BC_TILE_GW* configuration, made on first
+        use.  `ln` = name prefix of a LayerNorm folded into it (gamma into the weights, beta into the bias, column sums for the
+        kernel's mean correction): returns (stream, colsum or None, bias tensor or None)."""
+        from . import _lib
+        nt = _lib.GW_TILES[tile_cfg]
+        ck = ("gw", key, tuple(extra), nt, ln)
+        cache = self.__dict__.setdefault("_gw", {})
+        if ck not in cache:
+            w = self.h[key] if not extra else torch.cat([self.h[key]] + [self.h[e] for e in extra], 0)
+            b = self.f[bias] if bias else None
+            cs = None
+            if ln is not None:
+                w, cs, b = fold_layernorm(w, b, self.f[ln + ".weight"], self.f[ln + ".bias"])
+            cache[ck] = (pack_gemm_wreg(w, nt), cs, b)
+        return cache[ck]
 
     def wreg(self, key: str) -> str:
         """Key of the BC_TILE_WREG fragment stream of the packed 3x3 weight `key` (made on first use, kept beside the matrix)."""

@@ -111,6 +111,14 @@ typedef struct BcGemm {
     const float* a_part2; int a_ns2;
     const float* a_gamma; const float* a_beta;
     int a_groups; float a_eps;
+    /* ---- BC_TILE_GW* only: LayerNorm in front of the projection, FOLDED (attention.py:447,491,517 norm1/2/3 -> to_q|k|v, ff.net.0):
+     *      W holds W * diag(gamma), bias holds bias + W beta, ln_colsum[n] = sum_k (fp16) W'[n][k]; A is the RAW residual stream, the
+     *      kernel accumulates the row statistics while it stages the rows and applies
+     *      rstd_m * (acc[m][n] - mean_m * ln_colsum[n]) + bias[n]  (eps = ln_eps).  NULL = plain projection. ---- */
+    const float* ln_colsum; float ln_eps;
+    /* ---- BC_TILE_GW* only: a second, TRANSPOSED output for the column tiles n >= n_t0 (q | k row-major into C, V^T for the attention
+     *      kernel in the same launch): C_t[(b * (N - n_t0) + n - n_t0) * ldc_t + (m % rows_per_batch)].  NULL = none. ---- */
+    void* C_t; int ldc_t, n_t0;
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);
@@ -125,7 +133,19 @@ enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_12
        BC_TILE_HALO = 8,
        /* the same convolution, tile, prologue and epilogue with the weights streamed straight into VGPRs (conv_wreg.hip): `W` is the
         * fragment stream bc_conv_wreg_pack wrote for this layer (not the row-major matrix), ldw is ignored.  Same eligibility. */
-       BC_TILE_WREG = 9 };
+       BC_TILE_WREG = 9,
+       /* small-M projections with the weights streamed straight into VGPRs (gemm_wreg.hip): dense A (one or two sources), M % 64 == 0,
+        * K % 320 == 0 (C1 % 320 == 0), workgroup = 64 rows x 128 / 256 / 320 columns (N a multiple of that); `W` is the fragment stream
+        * bc_gemm_wreg_pack wrote for the SAME configuration, ldw is ignored; fp16 row-major output, no split-K, no row vector; takes
+        * ln_colsum (folded LayerNorm) and C_t (transposed second output).  Never chosen by BC_TILE_AUTO (bc_gemm_wreg_eligible). */
+       BC_TILE_GW64x128 = 10, BC_TILE_GW64x256 = 11, BC_TILE_GW64x320 = 12 };
+/* Re-order a weight matrix w[N][ldw] into the per-wave fragment streams of a BC_TILE_GW* configuration (out of place;
+ * bc_gemm_wreg_stream_elems(N, K) elements incl. the tail the register ring reads past the end): [column tile][wave 4][k-step K / 32]
+ * [tile][64 lanes][8]; lane l holds w[n0 + 16 tile + (l & 15)][32 s + 8 (l >> 4) .. + 8]. */
+int bc_gemm_wreg_pack(const bc_half* w, int ldw, int N, int K, int tile_cfg, bc_half* out, bc_stream stream);
+long long bc_gemm_wreg_stream_elems(int N, int K);
+/* 1 when a dense projection (C1 > 0: two-source A split at C1) can run on the given BC_TILE_GW* configuration. */
+int bc_gemm_wreg_eligible(int M, int N, int K, int C1, int tile_cfg);
 /* Re-order a 3x3 weight matrix w[N][9 * Cin] (k = (ky * 3 + kx) * Cin + c; N % 160 == 0, Cin % 64 == 0) into the per-wave fragment
  * streams of BC_TILE_WREG (same size, out of place): per 160-column block, per (column group 3|2|2|3 tiles, K half of the 64-channel
  * chunk) one contiguous stream [chunk][kx][ky][tile][64 lanes][8]; lane l holds w[n0 + 16 tile + (l & 15)][k0 + 8 (l >> 4) .. + 8]. */

@@ -109,8 +109,23 @@ BLOCK_CASES = {
     "up_scale2": ("upsample", dict(C=320, B=1, H=4, W=8, size=None)),
     "up_explicit_size": ("upsample", dict(C=320, B=1, H=3, W=6, size=(5, 12))),
     "down": ("downsample", dict(C=320, B=1, H=8, W=16)),
+    # round 4: the block sizes rounds 3 / 4 built kernels for.  640 channels on a 32 x 64 map at B = 2 = 64 row blocks (the row-chain's
+    # default threshold, split block end); 1280 channels on the 16 x 32 map (gemm_wreg.hip path).  The fixture keeps every `sub`-th
+    # pixel of the reference output in both directions (the full maps would be 10 MB each).
+    "tfm_640_cross": ("transformer", dict(C=640, heads=8, ctx=768, B=2, H=32, W=64, sub=8)),
+    "tfm_640_self_only": ("transformer", dict(C=640, heads=8, ctx=None, B=2, H=32, W=64, sub=8)),
+    "tfm_1280_cross": ("transformer", dict(C=1280, heads=8, ctx=768, B=2, H=16, W=32, sub=4)),
+    "tfm_1280_self_only": ("transformer", dict(C=1280, heads=8, ctx=None, B=1, H=16, W=32, sub=4)),
 }
+# seed index of a case: the round-2 cases keep the index they had (their position in the sorted list of the original eight names)
+_BLOCK_ORDER = ["down", "res_2560_1280", "res_320_320", "res_320_640_shortcut", "tfm_320_cross", "tfm_320_self_only", "up_explicit_size",
+                "up_scale2", "tfm_640_cross", "tfm_640_self_only", "tfm_1280_cross", "tfm_1280_self_only"]
+assert sorted(_BLOCK_ORDER) == sorted(BLOCK_CASES)
 BLOCK_TIMESTEPS = (999, 981, 500, 1)
+
+
+def block_index(name):
+    return _BLOCK_ORDER.index(name)
 
 
 def block_param_shapes(kind, p):
@@ -156,14 +171,14 @@ def block_weights(name):
     from blobctrl_amd import synth
     kind, p = ("time", {}) if name == "time" else BLOCK_CASES[name]
     # (seed differs per case so that equally named parameters of two cases are not the same numbers)
-    seed = BLOCK_SEED + (sorted(BLOCK_CASES).index(name) if name != "time" else 99)
+    seed = BLOCK_SEED + (block_index(name) if name != "time" else 99)
     return synth.synth_state_dict(block_param_shapes(kind, p), seed)
 
 
 def block_inputs(name):
     """(x NCHW, temb [B,1280] or None, context [B,7,ctx] or None) of a block case."""
     kind, p = BLOCK_CASES[name]
-    i = sorted(BLOCK_CASES).index(name)
+    i = block_index(name)
     C = p.get("cin", p.get("C"))
     x = g(500 + i, p["B"], C, p["H"], p["W"])
     temb = g(600 + i, p["B"], 1280) if kind == "resnet" else None

@@ -44,7 +44,8 @@ def _nchw(a, B):
     return a.t.float().cpu().view(B, a.H, a.W, a.C).permute(0, 3, 1, 2).numpy()
 
 
-def _check(name, got, ref):
+def _check(name, got, ref, sub=1):
+    got = got[:, :, ::sub, ::sub]                      # (the fixture keeps every sub-th pixel of the large maps)
     err = float(np.abs(got - ref).max() / np.abs(ref).max())
     print(f"block {name}: max-abs/scale {err:.3e}, PSNR {psnr(got, ref):.1f} dB")
     assert got.shape == ref.shape
@@ -93,6 +94,36 @@ def test_transformer_block(z, name, fused, monkeypatch):
     assert ("rowchain" in kinds) == fused, kinds
     _run(seg)
     _check(name + (" (row-chain)" if fused else " (unfused)"), _nchw(out, p["B"]), z[name])
+
+
+@pytest.mark.parametrize("name,mode", [("tfm_640_cross", "rowchain"), ("tfm_640_cross", "rowchain_nsplit1"), ("tfm_640_cross", "unfused"),
+                                       ("tfm_640_self_only", "rowchain"), ("tfm_640_self_only", "unfused"),
+                                       ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "unfused"), ("tfm_1280_self_only", "gw")])
+def test_transformer_block_640_1280(z, name, mode, monkeypatch):
+    """The block sizes rounds 3 / 4 built kernels for, against the reference's Transformer2DModel: 640 channels
+    on a 32 x 64 map at B = 2 (64 row blocks: the row-chain with the block end as OUT_FF + OUT_TAIL over two workgroups per row
+    block, its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
+    in one launch; and the unfused list)."""
+    if mode == "unfused":
+        monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
+        monkeypatch.setenv("BC_NO_GW", "1")
+    if mode == "rowchain_nsplit1":
+        monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", "1")
+    _, p = BLOCK_CASES[name]
+    x, _, ctx = block_inputs(name)
+    rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"], heads=p["heads"], cross=p["ctx"])
+    if ctx is not None:
+        plan.record_context(ctx.reshape(-1, p["ctx"]).half().cuda(), ctx.shape[1])
+    out, _ = plan.transformer("blk.", _act(x))
+    kinds, variants = rec.seg.kinds, [m.get("variant", "") for m in rec.seg.meta]
+    assert ("rowchain" in kinds) == mode.startswith("rowchain"), kinds
+    assert any("gemm_wreg_kernel" in v for v in variants) == (mode == "gw"), variants
+    if mode == "rowchain":
+        assert any("out_ff/2" in v for v in variants), variants
+    if mode == "gw":
+        assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
+    _run(seg)
+    _check(f"{name} ({mode})", _nchw(out, p["B"]), z[name], p["sub"])
 
 
 @pytest.mark.parametrize("name", ["up_scale2", "up_explicit_size", "down"])

@@ -251,7 +251,7 @@ def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
     assert seq == ["step_active"] * 4 + ["step_inactive"] * 2
     raw = open(path, "rb").read()
     magic, version, gsz, nbuf = struct.unpack("<IIII", raw[:16])
-    assert magic == 0x4E4C5042 and version == 1 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
+    assert magic == 0x4E4C5042 and version == 2 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
     for name in (b"latents", b"ctx", b"fg_lat", b"bg_lat", b"fg_score", b"bg_score", b"feat16", b"step_idx", b"coef", b"hist"):
         assert name in raw
     P = eng.plan_for(1, 8, 8, 7, TINY["ctx"], 6)
@@ -399,3 +399,33 @@ def test_rowchain_split_block_end_streams():
     w_t, v_t = weights.pack_rowchain(pw, p, 4, "blobnet_down_blocks.1")
     assert tuple(w_t.shape) == (nw, 2 * g + weights.RC_RPAD, 64, 8) and torch.equal(v_t, v_one)
     assert torch.equal(w_t[:, :2 * g], w_one[:, g + nch * per_chunk:g + nch * per_chunk + 2 * g])      # proj_out, zero-conv
+
+
+def test_layernorm_fold_and_gemm_wreg_packing_on_the_host():
+    """weights.fold_layernorm states Linear(LayerNorm(x)) = rstd (x W'^T - mean colsum) + bias' exactly (fp64), and pack_gemm_wreg is
+    the permutation csrc/gemm_wreg.hip documents: lane l of fragment (column tile j, wave w, k-step s, tile t) holds
+    W[64 nt j + 16 nt w + 16 t + (l & 15)][32 s + 8 (l >> 4) : + 8]."""
+    from blobctrl_amd.weights import fold_layernorm, pack_gemm_wreg
+    torch.manual_seed(0)
+    K, N = 64, 48
+    x = torch.randn(5, K, dtype=torch.float64) * 2 + 0.7
+    w, b = torch.randn(N, K), torch.randn(N)
+    gamma, beta = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+    w2, cs, b2 = fold_layernorm(w, b, gamma, beta)
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    got = rstd * (x @ w2.double().t() - mean * cs.double()[None, :]) + b2.double()
+    ref = torch.nn.functional.layer_norm(x, (K,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    assert float((got - ref).abs().max()) < 2e-2 * float(ref.abs().max())        # (W' is rounded to fp16: that is the only difference)
+    got64 = rstd * (x @ (w.double() * gamma.double()).t() - mean * (w.double() * gamma.double()).sum(1)[None, :]) + b2.double()
+    assert float((got64 - ref).abs().max()) < 1e-5
+    for nt in (2, 4, 5):
+        Nn, Kk = 64 * nt * 2, 96
+        W = torch.arange(Nn * Kk, dtype=torch.float32).reshape(Nn, Kk)
+        s = pack_gemm_wreg(W, nt)
+        assert s.numel() == Nn * Kk + 32 * 512 and float(s[Nn * Kk:].abs().max()) == 0.0
+        f = s[:Nn * Kk].reshape(2, 4, Kk // 32, nt, 64, 8)
+        for (j, wv, ks, t, l) in ((0, 0, 0, 0, 0), (1, 3, 2, nt - 1, 63), (1, 2, 1, 1, 37)):
+            n = 64 * nt * j + 16 * nt * wv + 16 * t + (l & 15)
+            k = 32 * ks + 8 * (l >> 4)
+            assert torch.equal(f[j, wv, ks, t, l], W[n, k:k + 8])

@@ -610,3 +610,120 @@ def test_run_timed_kernels_divides_a_splitk_gemm(rec):
     (_, main0, red0), (_, main1, red1) = rows
     assert main0 > 0 and red0 > 0 and main1 > 0 and red1 == 0.0
     assert abs((main0 + red0) - whole[0][1]) < 0.5 * whole[0][1] + 0.05      # same launches, separately timed replays
+
+
+# ---------------------------------------------------------------------------------------------------- gemm_wreg.hip (BC_TILE_GW*)
+def _gw_cfgs():
+    from blobctrl_amd import _lib
+    return [_lib.TILE_GW64x128, _lib.TILE_GW64x256, _lib.TILE_GW64x320]
+
+
+@pytest.mark.parametrize("cfg_i", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["plain", "ln", "ln_geglu", "res_r2_gn", "concat", "alpha"])
+def test_gemm_wreg_modes(rec, cfg_i, mode):
+    """Small-M projections with the weights streamed into VGPRs against fp32 torch on the fp16-rounded operands: folded LayerNorm
+    (raw rows in, statistics accumulated while staging), GEGLU, residual + BlobNet right-half residual + GroupNorm partials of the
+    output, two-source A, per-image scale; every workgroup shape."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import fold_layernorm, pack_gemm_wreg
+    cfg = _gw_cfgs()[cfg_i]
+    nt = _lib.GW_TILES[cfg]
+    B, rows = 2, 128
+    M, K = B * rows, 640
+    N = 64 * nt * (2 if mode != "ln_geglu" else 2)
+    A = g(1, M, K) * 1.5 + 0.4
+    W = g(2, N, K) / math.sqrt(K)
+    b = g(3, N)
+    x = A.half().float()
+    kw, cs = {}, None
+    wq, bq = W.half(), b
+    if mode.startswith("ln"):
+        gamma, beta = torch.rand(K, generator=torch.Generator().manual_seed(5)) + 0.5, g(6, K) * 0.1
+        wq, cs, bq = fold_layernorm(W.half(), b, gamma, beta)
+        x = F.layer_norm(x, (K,), gamma, beta, 1e-5)
+        kw.update(ln_colsum=cs.cuda(), ln_eps=1e-5)
+    ref = x @ W.half().float().t() + b
+    n_out = N
+    if mode == "ln_geglu":
+        r4 = ref.view(M, N // 64, 2, 32)
+        ref = (r4[:, :, 0] * F.gelu(r4[:, :, 1])).reshape(M, N // 2)
+        n_out = N // 2
+        kw.update(act=_lib.ACT_GEGLU)
+    part = None
+    if mode == "res_r2_gn":
+        R, R2 = g(7, M, N), g(8, 1, rows, N)
+        Wd, xmin = 16, 8                                            # canvas 8 x 16, residual added on the right half
+        ref = ref + R.half().float()
+        msk = (torch.arange(rows) % Wd >= xmin).float()[None, :, None]
+        ref = (ref.view(B, rows, N) + R2.half().float() * msk).view(M, N)
+        kw.update(R=h(R), ldr=N, R2=h(R2), ldr2=N, r2_xmin=xmin, r2_bmod=1, out_w=Wd, rows_per_batch=rows, want_gn=True)
+    if mode == "alpha":
+        tab = torch.tensor([9.0, 9.0, 0.7, 1.3]).cuda()
+        idx = torch.tensor([1], dtype=torch.int32).cuda()
+        ref = ref * 2.0 * torch.tensor([0.7, 1.3]).repeat_interleave(rows)[:, None]
+        kw.update(alpha=2.0, alpha_dev=tab, alpha_idx=idx, alpha_bstride=B, rows_per_batch=rows)
+    Ad = h(A)
+    if mode == "concat":
+        kw.update(A2=h(A[:, 320:].contiguous()), C1=320, lda=320, lda2=320)
+        Ad = h(A[:, :320].contiguous())
+    ws = pack_gemm_wreg(wq.cuda(), nt)
+    out = run(rec, lambda: rec.gemm(A=Ad, W=ws, M=M, N=N, K=K, out=rec.empty(M, n_out), bias=bq.cuda(), tile_cfg=cfg, **kw))
+    close(out, ref, what=f"gemm_wreg {mode} nt={nt}")
+    if mode == "res_r2_gn":
+        part, nslab = rec.parts[out.data_ptr()]
+        assert nslab == rows // 64
+        o = out.float().cpu().view(B, nslab, 64, N)
+        want = torch.stack([o.sum(2), (o * o).sum(2)], -1)
+        close(part, want, rtol=1e-4, atol=1e-2, what="gemm_wreg GroupNorm partials")
+
+
+@pytest.mark.parametrize("cfg_i", [0, 1])
+def test_gemm_wreg_qkv_one_launch(rec, cfg_i):
+    """LayerNorm -> to_q | to_k (row-major) and to_v (written transposed [B][C][ldvt] for the attention kernel) as ONE launch."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import fold_layernorm, pack_gemm_wreg
+    cfg = _gw_cfgs()[cfg_i]
+    nt = _lib.GW_TILES[cfg]
+    B, rows, Cc = 2, 128, 512
+    M = B * rows
+    A, W = g(1, M, Cc) * 2 - 0.3, g(2, 3 * Cc, Cc) / math.sqrt(Cc)
+    gamma, beta = torch.rand(Cc, generator=torch.Generator().manual_seed(5)) + 0.5, g(6, Cc) * 0.1
+    Kp = 640                                                        # K must be a multiple of 320: pad the channels with zeros
+    Ap = torch.zeros(M, Kp); Ap[:, :Cc] = A
+    Wp = torch.zeros(3 * Cc, Kp); Wp[:, :Cc] = W
+    gp, bp_ = torch.ones(Kp), torch.zeros(Kp); gp[:Cc], bp_[:Cc] = gamma, beta
+    # (the padded LayerNorm is over 640 channels: the reference below is stated on the padded operands)
+    x = F.layer_norm(Ap.half().float(), (Kp,), gp, bp_, 1e-5)
+    ref = x @ Wp.half().float().t()
+    wq, cs, bq = fold_layernorm(Wp.half(), None, gp, bp_)
+    ldvt = 192
+    qk, vt = None, None
+
+    def go():
+        nonlocal qk, vt
+        qk, vt = rec.empty(M, 2 * Cc), rec.zeros(B, Cc, ldvt)
+        rec.gemm(A=h(Ap), W=pack_gemm_wreg(wq.cuda(), nt), M=M, N=3 * Cc, K=Kp, out=qk, bias=bq.cuda(), tile_cfg=cfg, ln_colsum=cs.cuda(),
+                 C_t=vt, ldc_t=ldvt, n_t0=2 * Cc, rows_per_batch=rows)
+    run(rec, go)
+    close(qk, ref[:, :2 * Cc], what="q | k")
+    v = ref[:, 2 * Cc:].view(B, rows, Cc).permute(0, 2, 1)
+    close(vt[:, :, :rows], v, what="V^T")
+    assert float(vt[:, :, rows:].abs().max()) == 0.0               # the padding of the token axis is left alone
+
+
+def test_gemm_wreg_pack_matches_host_packing(rec):
+    """bc_gemm_wreg_pack (device) writes the same bytes as weights.pack_gemm_wreg (torch), for every configuration."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_gemm_wreg
+    lib = _lib.load()
+    for cfg, nt in _lib.GW_TILES.items():
+        N, K = 64 * nt * 3, 320
+        w = h(g(9, N, K))
+        out = torch.zeros(lib.bc_gemm_wreg_stream_elems(N, K), dtype=torch.float16, device="cuda:0")
+        _lib.check(lib.bc_gemm_wreg_pack(w.data_ptr(), K, N, K, cfg, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "pack")
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), pack_gemm_wreg(w, nt).cpu())
+    assert lib.bc_gemm_wreg_eligible(1024, 1280, 1280, 0, _lib.TILE_GW64x128) == 1
+    assert lib.bc_gemm_wreg_eligible(1000, 1280, 1280, 0, _lib.TILE_GW64x128) == 0      # M % 64
+    assert lib.bc_gemm_wreg_eligible(1024, 1280, 1024, 0, _lib.TILE_GW64x128) == 0      # K % 320
+    assert lib.bc_gemm_wreg_eligible(1024, 1280, 2560, 1280, _lib.TILE_GW64x320) == 1

@@ -164,13 +164,16 @@ def oracle_block(name):
 
 
 @pytest.mark.parametrize("name", ["res_320_320", "res_320_640_shortcut", "res_2560_1280", "tfm_320_cross", "tfm_320_self_only",
-                                  "up_scale2", "up_explicit_size", "down"])
+                                  "up_scale2", "up_explicit_size", "down", "tfm_640_self_only", "tfm_1280_cross"])
 def test_blocks_vs_reference_fixture(golden_dir, name):
-    """SURVEY 8c.2 block-level goldens (diffusers' own ResnetBlock2D / Transformer2DModel / Upsample2D / Downsample2D at SD-1.5 widths)."""
+    """SURVEY 8c.2 block-level goldens (diffusers' own ResnetBlock2D / Transformer2DModel / Upsample2D / Downsample2D at SD-1.5 widths;
+    the 640- / 1280-channel transformer cases keep every `sub`-th pixel of the reference output)."""
+    from tests.common import BLOCK_CASES
     z = load(golden_dir, "blocks.npz")
-    y = oracle_block(name).numpy()
+    sub = BLOCK_CASES[name][1].get("sub", 1)
+    y = oracle_block(name).numpy()[:, :, ::sub, ::sub]
     assert y.shape == z[name].shape
-    np.testing.assert_allclose(y, z[name], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y, z[name], rtol=1e-4, atol=2e-4 if sub > 1 else 1e-4)
 
 
 def test_time_embedding_vs_reference_fixture(golden_dir):

@@ -52,6 +52,15 @@ def main():
         torch.cuda.synchronize()
     n = len(seg.meta)
     dur = [sorted(r[i][1] + r[i][2] for r in reps)[1] for i in range(n)]
+    if os.environ.get("CP_DUMP"):
+        # per-launch table (index, stream, kind, variant, shape, main-kernel us, reducer us) for offline analysis
+        import json
+        rows = [dict(i=i, sid=m["sid"], kind=m["kind"], variant=m.get("variant", ""), shape=m.get("shape"), flops=m.get("flops", 0),
+                     us=round(sorted(r[i][1] for r in reps)[1] * 1e3, 2), red_us=round(sorted(r[i][2] for r in reps)[1] * 1e3, 2))
+                for i, m in enumerate(seg.meta)]
+        os.makedirs(os.path.dirname(os.environ["CP_DUMP"]) or ".", exist_ok=True)
+        with open(os.environ["CP_DUMP"], "w") as f:
+            json.dump(dict(measured_ms=measured, launches=rows), f)
 
     ev_of = {i: m["ev"] for i, m in enumerate(seg.meta) if "ev" in m}
     clock = {0: 0.0, 1: 0.0, 2: 0.0}

@@ -703,8 +703,9 @@ def golden_blocks():
             y = m(x, output_size=p["size"])
         else:
             y = m(x)
-        out[name] = y.numpy().astype(np.float32)
-        print(f"block {name}: out {tuple(y.shape)} std {float(y.std()):.4f}")
+        sub = p.get("sub", 1)
+        out[name] = y.numpy().astype(np.float32)[:, :, ::sub, ::sub]
+        print(f"block {name}: out {tuple(y.shape)} std {float(y.std()):.4f} stored {out[name].shape}")
     proj, emb = Timesteps(320, True, 0), TimestepEmbedding(320, 1280).eval()
     emb.load_state_dict(block_weights("time"), strict=True)
     t = torch.tensor(BLOCK_TIMESTEPS)
