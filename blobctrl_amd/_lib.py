@@ -37,9 +37,9 @@ class BcGemm(C.Structure):
         ("R", C.c_void_p), ("ldr", C.c_int),
         ("R2", C.c_void_p), ("ldr2", C.c_int), ("r2_xmin", C.c_int), ("r2_bmod", C.c_int), ("out_w", C.c_int),
         ("out_mode", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
-        ("splitk", C.c_int), ("slab", C.c_void_p), ("gn_part", C.c_void_p), ("tile_cfg", C.c_int),
+        ("splitk", C.c_int), ("slab", C.c_void_p), ("gn_tot", C.c_void_p), ("tile_cfg", C.c_int),
         ("a_affine", C.c_void_p), ("a_act", C.c_int),
-        ("a_part1", C.c_void_p), ("a_ns1", C.c_int), ("a_part2", C.c_void_p), ("a_ns2", C.c_int),
+        ("a_tot1", C.c_void_p), ("a_tot2", C.c_void_p),
         ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("a_groups", C.c_int), ("a_eps", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("C_t", C.c_void_p), ("ldc_t", C.c_int), ("n_t0", C.c_int),
@@ -60,12 +60,13 @@ _SIGNATURES = {
     "bc_gemm_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gemm_wreg_stream_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "bc_gemm_wreg_eligible": (C.c_int, [C.c_int] * 5),
-    "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
-    "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "bc_gn_apply_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "bc_gn_apply_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p]),
+    "bc_memset_zero": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "bc_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p]),
     "bc_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -96,7 +97,8 @@ _SIGNATURES = {
     "bc_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_rowchain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bc_rowchain_stream_frags": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "bc_rowchain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "bc_rowchain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                               C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     # ---- plan runtime (plan.hip)
@@ -139,9 +141,10 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_attention": 6, "bc_attention_causal": 7, "bc_assemble_input": 8, "bc_timestep_embedding": 9,
        "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
-       "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23}
+       "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23, "bc_memset_zero": 24}
 OP_SIGNAL, OP_WAIT = 20, 21
 CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL = 0, 1, 2, 3, 4
+GN_TOT_WORDS = 6                      # 64-bit words per (image, channel) of a GroupNorm statistics table (include/blobctrl_hip.h)
 _KIND = {C.c_void_p: "p", C.c_int: "i", C.c_float: "f", C.c_longlong: "l", C.c_char_p: "p"}
 
 

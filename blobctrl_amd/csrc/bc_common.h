@@ -68,6 +68,46 @@ __device__ __forceinline__ float bc_gelu_f(float x) {
 // CLIP's "quick_gelu": x * sigmoid(1.702 x)  (transformers activations.QuickGELUActivation)
 __device__ __forceinline__ float bc_quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+// ---- GroupNorm statistics as ORDER-INDEPENDENT totals (round 4) -------------------------------------------------------------------
+// Per (image, channel) BC_GN_TOT_WORDS 64-bit integer accumulators: the sum and the sum of squares of the fp16 activation, each as three
+// signed 40-bit slices of a fixed-point number (units 2^-60, 2^-20, 2^20).  Every producer workgroup reduces its rows in fp32 as
+// before and then ADDS that partial with integer atomics: integer addition commutes, so the totals - and everything downstream - are
+// bit-reproducible whatever the arrival order (an fp32 partial of up to 2^58 in magnitude converts exactly; the slices cannot
+// overflow below 2^23 addends).  Consumers read six words per channel instead of re-reducing `nslab` partials, and no finalize launch
+// sits between a producer and a fused consumer.  The tables are zeroed once per replay (bc_memset_zero at the head of a segment).
+__device__ __forceinline__ void bc_gn_slices(float v, long long (&sl)[3]) {
+    if (!(fabsf(v) < 2.8e17f)) {                       // inf / NaN / absurd: poison the total (consumers turn it into NaN)
+        sl[0] = 0; sl[1] = 0; sl[2] = 1ll << 60;
+        return;
+    }
+    const double d = (double)v;
+    const double h = floor(d * 9.5367431640625e-07);   // 2^-20
+    const double r = d - h * 1048576.0;                // in [0, 2^20)
+    const double m = floor(r * 1048576.0);
+    const double r2 = r - m * 9.5367431640625e-07;     // in [0, 2^-20)
+    sl[2] = (long long)h;
+    sl[1] = (long long)m;
+    sl[0] = (long long)floor(r2 * 1152921504606846976.0);   // 2^60
+}
+__device__ __forceinline__ void bc_gn_tot_add(unsigned long long* t, float s, float q) {
+    long long a[3], b[3];
+    bc_gn_slices(s, a);
+    bc_gn_slices(q, b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (a[i]) __hip_atomic_fetch_add(t + i, (unsigned long long)a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b[i]) __hip_atomic_fetch_add(t + 3 + i, (unsigned long long)b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// (sum, sum of squares) of one channel; a poisoned total reads as NaN
+__device__ __forceinline__ void bc_gn_tot_read(const unsigned long long* t, double& s, double& q) {
+    const long long a0 = (long long)t[0], a1 = (long long)t[1], a2 = (long long)t[2];
+    const long long b0 = (long long)t[3], b1 = (long long)t[4], b2 = (long long)t[5];
+    s = (double)a0 * 8.673617379884035e-19 + (double)a1 * 9.5367431640625e-07 + (double)a2 * 1048576.0;
+    q = (double)b0 * 8.673617379884035e-19 + (double)b1 * 9.5367431640625e-07 + (double)b2 * 1048576.0;
+    if (a2 >= (1ll << 50) || b2 >= (1ll << 50) || a2 <= -(1ll << 50)) { s = __builtin_nan(""); q = s; }
+}
+
 __device__ __forceinline__ uint4 bc_ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void bc_st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 

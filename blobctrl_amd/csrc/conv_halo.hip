@@ -248,30 +248,24 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
         const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
         const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
         const int c_lo = g_lo * cpg, nc = g_hi * cpg - c_lo;
-        float* scr = reinterpret_cast<float*>(smem + OFF_HALO);          // [8 waves][nc][2]
-        for (int cc = lane; cc < nc; cc += 64) {
+        double* scr = reinterpret_cast<double*>(smem + OFF_HALO);           // [nc][2] = (sum, sum of squares) per channel
+        for (int cc = tid; cc < nc; cc += 512) {
             const int c = c_lo + cc;
             const bool second = p.A2 != nullptr && c >= p.C1;
-            const int ns = second ? p.a_ns2 : p.a_ns1;
             const int Cs = second ? p.Cin - p.C1 : (p.A2 ? p.C1 : p.Cin);
-            const float* base = (second ? p.a_part2 : p.a_part1) + ((size_t)b * ns * Cs + (second ? c - p.C1 : c)) * 2;
-            double s = 0.0, q = 0.0;
-            for (int sl = wave; sl < ns; sl += 8) {
-                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)sl * Cs * 2);
-                s += v.x;
-                q += v.y;
-            }
-            scr[(wave * nc + cc) * 2] = (float)s;
-            scr[(wave * nc + cc) * 2 + 1] = (float)q;
+            const unsigned long long* t = (second ? p.a_tot2 : p.a_tot1) + ((size_t)b * Cs + (second ? c - p.C1 : c)) * BC_GN_TOT_WORDS;
+            double s, q;
+            bc_gn_tot_read(t, s, q);
+            scr[cc * 2] = s;
+            scr[cc * 2 + 1] = q;
         }
         __syncthreads();
-        float* stat = scr + 8 * nc * 2;                                   // [groups][2] = (mean, rstd)
+        float* stat = reinterpret_cast<float*>(scr + nc * 2);             // [groups][2] = (mean, rstd)
         for (int gi = g_lo + wave; gi < g_hi; gi += 8) {
             double s = 0.0, q = 0.0;
-            for (int it = lane; it < cpg * 8; it += 64) {
-                const int w8 = it / cpg, cj = it - w8 * cpg;
-                s += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2];
-                q += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2 + 1];
+            for (int cj = lane; cj < cpg; cj += 64) {
+                s += scr[((gi - g_lo) * cpg + cj) * 2];
+                q += scr[((gi - g_lo) * cpg + cj) * 2 + 1];
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -456,7 +450,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             epi8_store(g, cols, v, gt, m, gs, gq);
         }
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
         if (act) {
 #pragma unroll
@@ -473,9 +467,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
                 s += scr[(r * HBN + tid) * 2];
                 q += scr[(r * HBN + tid) * 2 + 1];
             }
-            float* dst = p.gn_part + (((size_t)b * g.halo_tpi + tin) * g.n_out + n0 + tid) * 2;
-            dst[0] = s;
-            dst[1] = q;
+            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n0 + tid) * BC_GN_TOT_WORDS, s, q);
         }
     }
     stamp(6);
@@ -489,7 +481,7 @@ int bc_conv_halo_max_chunks_impl() { return MAX_CH; }
 int bc_conv_halo_ok(const BcGemm& p) {
     if (p.a_mode != BC_A_CONV3X3 || p.stride != 1 || p.conv_nopad_lo) return 0;
     // BC_TILE_WREG also takes the exact 2x nearest upsample in front of a plain convolution (no GroupNorm prologue, single source)
-    const bool ups2 = p.tile_cfg == BC_TILE_WREG && p.Hv == 2 * p.Hin && p.Wv == 2 * p.Win && !p.A2 && !p.a_affine && !p.a_part1;
+    const bool ups2 = p.tile_cfg == BC_TILE_WREG && p.Hv == 2 * p.Hin && p.Wv == 2 * p.Win && !p.A2 && !p.a_affine && !p.a_tot1;
     if (!ups2 && (p.Hv != p.Hin || p.Wv != p.Win)) return 0;
     if (p.Hout != p.Hv || p.Wout != p.Wv) return 0;
     if (p.Cin % 64 != 0 || p.N % HBN != 0 || p.Wout % TW != 0 || p.Hout % TH != 0) return 0;
@@ -546,8 +538,8 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
         }
     } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
     static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
-    if (p.a_part1) {
-        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && p.a_ns1 > 0 && (!p.A2 || (p.a_part2 && p.a_ns2 > 0)),
+    if (p.a_tot1) {
+        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && (!p.A2 || p.a_tot2),
                      "bc_gemm(halo conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
         const int cpg = p.Cin / p.a_groups;
         BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && (8 * (g.halo_cps * 64 + 2 * cpg) + p.a_groups + 8) * 8 <= 2 * HALO_BYTES,

@@ -58,9 +58,9 @@ constexpr int LDS_EPI = OFF_SCR + 24 * HBN * 2 * 4;
 constexpr int OFF_EPI = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;   // bias[160] | time-embedding row[160] (floats), staged in the prologue
 constexpr int LDS_TOTAL = OFF_EPI + 2 * HBN * 4;
 static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES, "LDS budget");
-constexpr int FIN_MAX_CH = 720;                 // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
-constexpr int OFF_FIN = LDS_LOOP;               // its scratch: [8 waves][span][2] floats + [groups][2], behind the loop's LDS
-constexpr int LDS_TOTAL_FIN = OFF_FIN + 8 * FIN_MAX_CH * 8 + 1024 > LDS_TOTAL ? OFF_FIN + 8 * FIN_MAX_CH * 8 + 1024 : LDS_TOTAL;
+constexpr int FIN_MAX_CH = 2752;                // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
+constexpr int OFF_FIN = LDS_LOOP;               // its scratch: [span][2] doubles + [groups][2] floats, behind the loop's LDS
+constexpr int LDS_TOTAL_FIN = OFF_FIN + FIN_MAX_CH * 16 + 1024 > LDS_TOTAL ? OFF_FIN + FIN_MAX_CH * 16 + 1024 : LDS_TOTAL;
 static_assert(LDS_TOTAL_FIN <= 160 * 1024, "LDS budget (in-kernel finalize)");
 
 template <int N>
@@ -242,67 +242,71 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         }
         BC_WREG_LOAD_GROUP(0, wb)
         if (AFFINE == 2) {
-            // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the producers' per-channel
-            // partials (fixed summation order: bit-reproducible), while the first halo rows and weight fragments are in flight.
-            // Scratch behind the loop's LDS (the halo images are already being written).  Eight partial loads per channel in flight.
+            // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the statistics totals (six
+            // words per channel, order-independent integer sums: bc_common.h), while the first halo rows and weight fragments are in
+            // flight.  Scratch behind the loop's LDS (the halo images are already being written).
             const int cpg = p.Cin / p.a_groups;
             const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
             const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
             const int c_lo = g_lo * cpg, nc = g_hi * cpg - c_lo;
-            float* scr = reinterpret_cast<float*>(smem + OFF_FIN);           // [8 waves][nc][2]
-            for (int cc = lane; cc < nc; cc += 64) {
+            // gamma / beta of this thread's first two channels are requested FIRST: fetched behind the second barrier they were a
+            // third exposed memory round trip of the prologue
+            float gpre[2] = {0.f, 0.f}, bpre[2] = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + 512 * j < nch * 64) {
+                    gpre[j] = p.a_gamma[k_lo + tid + 512 * j];
+                    bpre[j] = p.a_beta[k_lo + tid + 512 * j];
+                }
+            double* scr = reinterpret_cast<double*>(smem + OFF_FIN);           // [nc][2] = (sum, sum of squares) per channel
+            for (int cc = tid; cc < nc; cc += 512) {
                 const int c = c_lo + cc;
                 const bool second = p.A2 != nullptr && c >= p.C1;
-                const int ns = second ? p.a_ns2 : p.a_ns1;
                 const int Cs = second ? p.Cin - p.C1 : (p.A2 ? p.C1 : p.Cin);
-                const float* base = (second ? p.a_part2 : p.a_part1) + ((size_t)b * ns * Cs + (second ? c - p.C1 : c)) * 2;
-                double s = 0.0, q = 0.0;
-                for (int sl0 = wave; sl0 < ns; sl0 += 64) {               // slabs wave, wave + 8, ...: eight at a time, summed in order
-                    float2 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        // unconditional load from a clamped slab, scaled by 1 or 0: hipcc turns `cond ? load : 0` - even written as a
-                        // select after the load - into a branch around the load with a vmcnt(0) behind each one (560 cycles per slab)
-                        const int sl = sl0 + 8 * u;
-                        const float2 ld = *reinterpret_cast<const float2*>(base + (size_t)min(sl, ns - 1) * Cs * 2);
-                        const float keep = sl < ns ? 1.0f : 0.0f;
-                        v[u] = make_float2(ld.x * keep, ld.y * keep);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        s += v[u].x;
-                        q += v[u].y;
-                    }
-                }
-                scr[(wave * nc + cc) * 2] = (float)s;
-                scr[(wave * nc + cc) * 2 + 1] = (float)q;
+                const unsigned long long* t = (second ? p.a_tot2 : p.a_tot1) + ((size_t)b * Cs + (second ? c - p.C1 : c)) * BC_GN_TOT_WORDS;
+                double s, q;
+                bc_gn_tot_read(t, s, q);
+                scr[cc * 2] = s;
+                scr[cc * 2 + 1] = q;
             }
             __syncthreads();
-            float* stat = scr + 8 * nc * 2;                                   // [groups][2] = (mean, rstd)
-            for (int gi = g_lo + wave; gi < g_hi; gi += 8) {
-                double s = 0.0, q = 0.0;
-                for (int it = lane; it < cpg * 8; it += 64) {
-                    const int w8 = it / cpg, cj = it - w8 * cpg;
-                    s += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2];
-                    q += scr[(w8 * nc + (gi - g_lo) * cpg + cj) * 2 + 1];
-                }
+            float* stat = reinterpret_cast<float*>(scr + nc * 2);             // [groups][2] = (mean, rstd)
+            {   // eight lanes per group: 64 groups per pass of the workgroup, fixed summation order
+                const int sub = tid & 7;
+                for (int gi = g_lo + (tid >> 3); gi < g_hi; gi += 64) {
+                    double s = 0.0, q = 0.0;
+                    for (int cj = sub; cj < cpg; cj += 8) {
+                        s += scr[((gi - g_lo) * cpg + cj) * 2];
+                        q += scr[((gi - g_lo) * cpg + cj) * 2 + 1];
+                    }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    s += __shfl_xor(s, o);
-                    q += __shfl_xor(q, o);
-                }
-                const double n = (double)g.div_rpb.d * cpg;
-                const double mean = s / n;
-                double var = q / n - mean * mean;
-                if (var < 0.0) var = 0.0;
-                if (lane == 0) {
-                    stat[(gi - g_lo) * 2] = (float)mean;
-                    stat[(gi - g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+                    for (int o = 4; o > 0; o >>= 1) {
+                        s += __shfl_xor(s, o);
+                        q += __shfl_xor(q, o);
+                    }
+                    const double n = (double)g.div_rpb.d * cpg;
+                    const double mean = s / n;
+                    double var = q / n - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    if (sub == 0) {
+                        stat[(gi - g_lo) * 2] = (float)mean;
+                        stat[(gi - g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+                    }
                 }
             }
             __syncthreads();
             float* abt = reinterpret_cast<float*>(smem + OFF_AB);
-            for (int i = tid; i < nch * 64; i += 512) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 512 * j;
+                if (i < nch * 64) {
+                    const int gi = (k_lo + i) / cpg - g_lo;
+                    const float a = stat[gi * 2 + 1] * gpre[j];
+                    abt[i * 2] = a;
+                    abt[i * 2 + 1] = bpre[j] - stat[gi * 2] * a;
+                }
+            }
+            for (int i = tid + 1024; i < nch * 64; i += 512) {
                 const int c = k_lo + i;
                 const int gi = c / cpg - g_lo;
                 const float a = stat[gi * 2 + 1] * p.a_gamma[c];
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[k] * p.ldc + n_first, outraw);
         }
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
         if (act) {
 #pragma unroll
@@ -603,9 +607,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 s += scr[(r * HBN + tid) * 2];
                 q += scr[(r * HBN + tid) * 2 + 1];
             }
-            float* dst = p.gn_part + (((size_t)b * g.halo_tpi + tin) * g.n_out + n0 + tid) * 2;
-            dst[0] = s;
-            dst[1] = q;
+            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n0 + tid) * BC_GN_TOT_WORDS, s, q);
         }
     }
     stamp(5);
@@ -714,15 +716,16 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
         }
     } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
     static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
-    if (p.a_part1) {
-        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && p.a_ns1 > 0 && (!p.A2 || (p.a_part2 && p.a_ns2 > 0)),
+    if (p.a_tot1) {
+        BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && (!p.A2 || p.a_tot2),
                      "bc_gemm(wreg conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
         const int cpg = p.Cin / p.a_groups;
         BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && p.a_groups * 8 <= 1024,
                      "bc_gemm(wreg conv): channel span %d per workgroup too wide for the in-kernel GroupNorm finalize (max %d): use "
                      "bc_gn_finalize + a_affine or raise splitk", g.halo_cps * 64 + 2 * cpg, FIN_MAX_CH);
         BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_wreg_kernel<2>), LDS_TOTAL_FIN));
-        hipLaunchKernelGGL((conv_wreg_kernel<2>), grid, dim3(512), LDS_TOTAL_FIN, stream, g);
+        const int lds_fin = std::max(LDS_TOTAL, OFF_FIN + (g.halo_cps * 64 + 2 * cpg) * 16 + 1024);    // (scratch for this span only)
+        hipLaunchKernelGGL((conv_wreg_kernel<2>), grid, dim3(512), lds_fin, stream, g);
     } else if (p.a_affine) {
         BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_wreg_kernel<1>), LDS_TOTAL));
         hipLaunchKernelGGL((conv_wreg_kernel<1>), grid, dim3(512), LDS_TOTAL, stream, g);

@@ -232,8 +232,8 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
 }
 
 // Vectorised reducer: a workgroup owns SK_ROWS rows x 64 output columns (8 columns per thread), sums the slabs with
-// 16-byte loads, applies the shared 8-wide epilogue and (optionally) emits GroupNorm partials for its row block:
-// gn_part[B][rows_per_batch / SK_ROWS][n_out][2].
+// 16-byte loads, applies the shared 8-wide epilogue and (optionally) adds the GroupNorm statistics of its row block to the
+// totals gn_tot[B][n_out][BC_GN_TOT_WORDS].
 constexpr int SK_ROWS = 32;
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g) {
     __shared__ float scr[4 * 64 * 2];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g
         }
         epi8_store(g, cols, v, gt, m, gs, gq);
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         for (int o = 8; o < 64; o <<= 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -307,13 +307,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g
                     s += scr[(w * 64 + tid) * 2];
                     q += scr[(w * 64 + tid) * 2 + 1];
                 }
-                const int mb = blockIdx.y * SK_ROWS;
-                const int b = (int)fdiv((unsigned)mb, g.div_rpb);
-                const int slab = (mb - b * (int)g.div_rpb.d) / SK_ROWS;
-                const int nslab = (int)g.div_rpb.d / SK_ROWS;
-                float* dst = p.gn_part + (((size_t)b * nslab + slab) * g.n_out + n) * 2;
-                dst[0] = s;
-                dst[1] = q;
+                const int b = (int)fdiv((unsigned)(blockIdx.y * SK_ROWS), g.div_rpb);
+                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n) * BC_GN_TOT_WORDS, s, q);
             }
         }
     }
@@ -518,7 +513,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
                                          "Wout%%16==0, Hout%%8==0 (Cin=%d N=%d %dx%d)", p.Cin, p.N, p.Hout, p.Wout);
         BC_CHECK_ARG(!p.a_affine || p.a_act == BC_ACT_NONE || p.a_act == BC_ACT_SILU, "bc_gemm: a_act must be NONE or SILU");
     } else {
-        BC_CHECK_ARG(p.a_affine == nullptr && p.a_part1 == nullptr, "bc_gemm: the fused GroupNorm prologue is only available on BC_TILE_HALO");
+        BC_CHECK_ARG(p.a_affine == nullptr && p.a_tot1 == nullptr, "bc_gemm: the fused GroupNorm prologue is only available on BC_TILE_HALO");
     }
     g.nk = bc_ceil_div(p.K, BK);
     if (halo) g.nk = p.Cin / BK;                    // split-K counts 64-channel chunks (each covers the nine taps)
@@ -556,16 +551,17 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     static const bool no_vec_t = getenv("BC_NO_VEC_T") != nullptr;
     g.vec_transposed = !no_vec_t && p.out_mode == BC_OUT_F16_T && p.rows_per_batch % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                        p.act == BC_ACT_NONE && !p.rowvec && !p.colscale && !p.R && !p.R2;
-    if (p.gn_part) {
+    if (p.gn_tot) {
+        // (a workgroup's rows must belong to one image: its statistics go to that image's totals)
         const int slab_rows = p.splitk > 1 ? SK_ROWS : g.bm;
         BC_CHECK_ARG((fast_ok || halo || p.splitk > 1) && g.vec_epilogue && p.N % 4 == 0 && p.rows_per_batch % slab_rows == 0 &&
                          p.M % p.rows_per_batch == 0,
-                     "bc_gemm: fused GroupNorm partials need the fast path or split-K, fp16 row-major output and rows_per_batch%%%d==0", slab_rows);
+                     "bc_gemm: fused GroupNorm statistics need the fast path or split-K, fp16 row-major output and rows_per_batch%%%d==0", slab_rows);
     }
     int rc = wreg ? bc_conv_wreg_launch(g, stream) : halo ? bc_conv_halo_launch(g, stream) : fast_ok ? bc_gemm_fast_try(g, stream) : -1;
     if (rc > 0) return rc;
     if (rc < 0) {
-        BC_CHECK_ARG(!p.gn_part || p.splitk > 1, "bc_gemm: fused GroupNorm partials are only produced by the fast path or the split-K reducer");
+        BC_CHECK_ARG(!p.gn_tot || p.splitk > 1, "bc_gemm: fused GroupNorm statistics are only produced by the fast path or the split-K reducer");
         rc = (g.bn == 64) ? launch_gemm<256, 64, 4, 1>(g, stream) : launch_gemm<128, 128, 2, 2>(g, stream);
         if (rc) return rc;
     }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
             epi8_store(g, cols, v, gt, m, gs, gq);
         }
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         // reduce the per-thread column partials over the rows of this block: lanes with equal col8 inside a wave, then waves
         for (int o = CPR; o < 64; o <<= 1) {
 #pragma unroll
@@ -293,11 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
                     q += scr[(w * TSO + tid) * 2 + 1];
                 }
                 const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-                const int slab = (m0 - b * (int)g.div_rpb.d) / BM;
-                const int nslab = (int)g.div_rpb.d / BM;
-                float* dst = p.gn_part + (((size_t)b * nslab + slab) * g.n_out + n) * 2;
-                dst[0] = s;
-                dst[1] = q;
+                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n) * BC_GN_TOT_WORDS, s, q);
             }
         }
     }

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
             epi8_store(g, cols, v, gt, m0 + row, gs, gq);
         }
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         // per-channel (sum, sum of squares) of the fp16 output over the block's 64 rows: threads of equal col8 combine through LDS
         __syncthreads();                            // tile fully consumed; reuse its head as scratch [RG][TSO][2]
         float* scr = reinterpret_cast<float*>(smem);
@@ -296,11 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
                 qq += scr[(r * TSO + c) * 2 + 1];
             }
             const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-            const int slab = (m0 - b * (int)g.div_rpb.d) / GW_BM;
-            const int nslab = (int)g.div_rpb.d / GW_BM;
-            float* dst = p.gn_part + (((size_t)b * nslab + slab) * g.n_out + (geglu ? n0 / 2 : n0) + c) * 2;
-            dst[0] = s;
-            dst[1] = qq;
+            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + c) * BC_GN_TOT_WORDS, s, qq);
         }
     }
 }
@@ -347,16 +343,16 @@ int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg) {
     if (!nt || p.a_mode != BC_A_DENSE) return 0;
     if (p.M <= 0 || p.M % GW_BM || p.N % (64 * nt) || p.K % (32 * GW_KC)) return 0;
     if (p.A2 && (p.C1 % (32 * GW_KC) || p.C1 <= 0 || p.C1 >= p.K)) return 0;
-    if (p.out_mode != BC_OUT_F16 || p.splitk > 1 || p.rowvec || p.a_affine || p.a_part1) return 0;
+    if (p.out_mode != BC_OUT_F16 || p.splitk > 1 || p.rowvec || p.a_affine || p.a_tot1) return 0;
     if (p.act != BC_ACT_NONE && p.act != BC_ACT_GEGLU && p.act != BC_ACT_GELU && p.act != BC_ACT_SILU && p.act != BC_ACT_QUICK_GELU) return 0;
     if (p.ln_colsum && p.A2) return 0;               // (the statistics cover one source)
     if (p.C_t) {
         const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
         if (p.n_t0 <= 0 || p.n_t0 % (64 * nt) || p.n_t0 >= p.N || rpb % GW_BM || p.M % rpb || p.ldc_t < rpb || p.ldc_t % 8 ||
-            p.act != BC_ACT_NONE || p.R || p.R2 || p.colscale || p.gn_part || p.alpha_dev || p.alpha != 1.0f)
+            p.act != BC_ACT_NONE || p.R || p.R2 || p.colscale || p.gn_tot || p.alpha_dev || p.alpha != 1.0f)
             return 0;
     }
-    if (p.gn_part) {
+    if (p.gn_tot) {
         const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
         if (rpb % GW_BM || p.M % rpb) return 0;
     }

@@ -17,13 +17,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// part[b][slab][c][2] = per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab.  No atomics: every partial is
-// produced in a fixed order, so GroupNorm (and everything downstream) is bit-reproducible.  Four waves split the slab's
-// pixels; lane l of a wave owns 8-channel chunk(s) l, l + 64, ... (adjacent lanes read adjacent 16-byte chunks: coalesced
-// rows); the four wave partials are combined through LDS in wave order.
-// (Only used for tensors whose producer could not emit the partials itself - see BcGemm.gn_part.)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x, int C, int HW, float* __restrict__ part,
-                                                         int nslab) {
+// Per-CHANNEL (sum, sumsq) over the GN_PIX_PER_SLAB pixels of a slab, ADDED to the totals tot[b][c][BC_GN_TOT_WORDS] (integer atomics:
+// order-independent, so GroupNorm - and everything downstream - stays bit-reproducible; bc_common.h).  Four waves split the slab's
+// pixels; lane l of a wave owns 8-channel chunk(s) l, l + 64, ... (adjacent lanes read adjacent 16-byte chunks: coalesced rows); the
+// four wave partials are combined through LDS in wave order.
+// (Only used for tensors whose producer could not emit the statistics itself - see BcGemm.gn_tot.)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x, int C, int HW, unsigned long long* __restrict__ tot) {
     __shared__ float red[4][64][16];
     const int b = blockIdx.y, slab = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -32,7 +31,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x
     const int np = min(GN_PIX_PER_SLAB, HW - p0);
     const int per_wave = (np + 3) / 4;
     const int pw0 = min(np, wave * per_wave), pw1 = min(np, pw0 + per_wave);
-    float* dst = part + ((size_t)b * nslab + slab) * C * 2;
+    unsigned long long* dst = tot + (size_t)b * C * BC_GN_TOT_WORDS;
     for (int ch0 = 0; ch0 < nchunk; ch0 += 64) {
         const int ch = ch0 + lane;
         float s[8], q[8];
@@ -61,78 +60,50 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const h16* __restrict__ x
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { ss += red[w][lane][2 * j]; qq += red[w][lane][2 * j + 1]; }
-                dst[(ch * 8 + j) * 2] = ss;
-                dst[(ch * 8 + j) * 2 + 1] = qq;
+                bc_gn_tot_add(dst + (size_t)(ch * 8 + j) * BC_GN_TOT_WORDS, ss, qq);
             }
         }
         __syncthreads();
     }
 }
 
-// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]) for the channel-concat of two sources, each with its own
-// per-channel partial buffer part_i[B][nslab_i][C_i][2].  grid (G, B), one 256-thread workgroup per group: its threads sweep the
-// flattened (channel-in-group, slab) items of both sources (all loads independent -> one memory latency; 640 ... 1920 items per
-// group at the 64 x 128 level, which one wave per group - the first version - walked in 10 ... 30 dependent rounds: 8 us per
-// launch, 88 launches per step), fp64 accumulation in a fixed order (thread-strided, wave butterfly, four wave sums in order)
-// => deterministic.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part1, int nslab1, int C1,
-                                                            const float* __restrict__ part2, int nslab2, int C2, int HW,
-                                                            int G, float eps, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ ab) {
-    __shared__ double red[4][2];
+// ab[b][c] = (rstd*gamma[c], beta[c] - mean*rstd*gamma[c]) for the channel-concat of two sources, each with its own totals
+// tot_i[B][C_i][BC_GN_TOT_WORDS].  grid (G, B), one wave per group: every lane reads the totals of its channels of the group (48 bytes
+// each), fp64 butterfly => deterministic.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const unsigned long long* __restrict__ tot1, int C1,
+                                                           const unsigned long long* __restrict__ tot2, int C2, int HW,
+                                                           int G, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ ab) {
     const int b = blockIdx.y;
     const int C = C1 + C2;
     const int cpg = C / G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x;
-    const int c_lo = g * cpg, c_hi = c_lo + cpg;
-    const int n1 = max(0, min(c_hi, C1) - c_lo);               // channels of this group living in source 1
-    const int n2 = cpg - n1;
+    const int lane = threadIdx.x;
+    const int c_lo = blockIdx.x * cpg, c_hi = c_lo + cpg;
     double s = 0.0, q = 0.0;
-    {
-        const float* base = part1 + ((size_t)b * nslab1 * C1 + c_lo) * 2;
-        const int items = n1 * nslab1;
-        for (int it = tid; it < items; it += 256) {
-            const int sl = it / n1, cj = it - sl * n1;
-            const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C1 + cj) * 2);
-            s += v.x;
-            q += v.y;
-        }
-    }
-    if (n2 > 0) {
-        const int c2_lo = max(c_lo, C1) - C1;
-        const float* base = part2 + ((size_t)b * nslab2 * C2 + c2_lo) * 2;
-        const int items = n2 * nslab2;
-        for (int it = tid; it < items; it += 256) {
-            const int sl = it / n2, cj = it - sl * n2;
-            const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)sl * C2 + cj) * 2);
-            s += v.x;
-            q += v.y;
-        }
+    for (int c = c_lo + lane; c < c_hi; c += 64) {
+        const unsigned long long* t = c < C1 ? tot1 + ((size_t)b * C1 + c) * BC_GN_TOT_WORDS : tot2 + ((size_t)b * C2 + (c - C1)) * BC_GN_TOT_WORDS;
+        double cs, cq;
+        bc_gn_tot_read(t, cs, cq);
+        s += cs;
+        q += cq;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o);
         q += __shfl_xor(q, o);
     }
-    if (lane == 0) {
-        red[wave][0] = s;
-        red[wave][1] = q;
-    }
-    __syncthreads();
-    s = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-    q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     const double n = (double)HW * cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int c = c_lo + tid; c < c_hi; c += 256) {
+    for (int c = c_lo + lane; c < c_hi; c += 64) {
         const float a = rstd * gamma[c];
         ab[((size_t)b * C + c) * 2] = a;
         ab[((size_t)b * C + c) * 2 + 1] = beta[c] - meanf * a;
     }
 }
+
 
 // y = silu?(x * a + b) over the concat of two sources; grid (chunks of one image, batch), 32-bit index maths only.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x1, int C1, const h16* __restrict__ x2,
@@ -164,12 +135,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const h16* __restrict__ x
 }
 
 // Fused finalize + apply: one launch per GroupNorm.  A workgroup owns a 64-channel range x a pixel range of one image; its
-// prologue re-reduces the per-channel partials of just the groups that overlap its channel range into LDS (a, b) pairs, then
-// streams its pixels: y = silu?(a*x + b), 16-byte accesses.  The prologue is the critical path of this (latency-bound) kernel, so
-// it is ONE round of independent loads: thread (channel cc, row r) sums slabs r, r+R, ... of its own channel (coalesced across
-// channels, fixed order, fp64), the R rows and the channels of a group are then combined through LDS by one thread per group.
-__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __restrict__ part1, int nslab1, int C1,
-                                                               const float* __restrict__ part2, int nslab2, int C2,
+// prologue reads the statistics totals (bc_common.h: six words per channel) of the groups that overlap its channel range, one thread
+// per channel, combines the channels of a group through LDS (one thread per group, fixed order, fp64) into (a, b) pairs, then
+// streams its pixels: y = silu?(a*x + b), 16-byte accesses.
+__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const unsigned long long* __restrict__ tot1, int C1,
+                                                               const unsigned long long* __restrict__ tot2, int C2,
                                                                const h16* __restrict__ x1, const h16* __restrict__ x2, int HW,
                                                                int G, float eps, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int silu, int pix_per_block,
@@ -181,33 +151,12 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __rest
     const int cpg = C / G;
     const int c0 = blockIdx.x * 64, c1 = min(c0 + 64, C);
     const int g_lo = c0 / cpg, g_hi = (c1 - 1) / cpg;
-    const int cA = g_lo * cpg, nch = (g_hi + 1) * cpg - cA;          // channels whose partials this workgroup needs (<= 256)
-    int nchp = 1;
-    while (nchp < nch) nchp <<= 1;
-    const int R = 256 / nchp;                                         // slab rows summed in parallel
-    {
-        const int cc = threadIdx.x & (nchp - 1), r = threadIdx.x / nchp;
-        double s = 0.0, q = 0.0;
-        if (cc < nch) {
-            const int c = cA + cc;
-            const bool first = c < C1;
-            const int ns = first ? nslab1 : nslab2, Cs = first ? C1 : C2;
-            const float* base = (first ? part1 : part2) + ((size_t)b * ns * Cs + (first ? c : c - C1)) * 2;
-            const size_t step = (size_t)Cs * 2;
-            int sl = r;
-            for (; sl + 7 * R < ns; sl += 8 * R) {                    // 8 independent loads in flight
-                float2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(base + (size_t)(sl + u * R) * step);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
-            }
-            for (; sl < ns; sl += R) {
-                const float2 v = *reinterpret_cast<const float2*>(base + (size_t)sl * step);
-                s += v.x;
-                q += v.y;
-            }
-        }
+    const int cA = g_lo * cpg, nch = (g_hi + 1) * cpg - cA;          // channels whose statistics this workgroup needs (<= 256)
+    if ((int)threadIdx.x < nch) {
+        const int c = cA + threadIdx.x;
+        const unsigned long long* t = c < C1 ? tot1 + ((size_t)b * C1 + c) * BC_GN_TOT_WORDS : tot2 + ((size_t)b * C2 + (c - C1)) * BC_GN_TOT_WORDS;
+        double s, q;
+        bc_gn_tot_read(t, s, q);
         sq_s[threadIdx.x * 2] = s;
         sq_s[threadIdx.x * 2 + 1] = q;
     }
@@ -216,11 +165,10 @@ __global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __rest
         const int g = g_lo + threadIdx.x;
         const int cl = g * cpg - cA;
         double s = 0.0, q = 0.0;
-        for (int r = 0; r < R; ++r)
-            for (int j = 0; j < cpg; ++j) {
-                s += sq_s[(r * nchp + cl + j) * 2];
-                q += sq_s[(r * nchp + cl + j) * 2 + 1];
-            }
+        for (int j = 0; j < cpg; ++j) {
+            s += sq_s[(cl + j) * 2];
+            q += sq_s[(cl + j) * 2 + 1];
+        }
         const double n = (double)HW * cpg;
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -358,26 +306,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(h16* __restrict__ x, 
 
 }  // namespace
 
-extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, int nslab, bc_stream stream_) {
+extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, unsigned long long* tot, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    BC_CHECK_ARG(x && part && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "bc_gn_stats: bad args (C %% 8 == 0)");
-    BC_CHECK_ARG(nslab == bc_ceil_div(HW, GN_PIX_PER_SLAB), "bc_gn_stats: nslab must be ceil(HW/%d)", GN_PIX_PER_SLAB);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nslab, B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x), C, HW, part,
-                       nslab);
+    BC_CHECK_ARG(x && tot && B > 0 && HW > 0 && C > 0 && C % 8 == 0, "bc_gn_stats: bad args (C %% 8 == 0)");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(bc_ceil_div(HW, GN_PIX_PER_SLAB), B), dim3(256), 0, stream, reinterpret_cast<const h16*>(x), C, HW, tot);
     BC_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bc_gn_finalize(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2, int B, int HW,
+extern "C" int bc_gn_finalize(const unsigned long long* tot1, int C1, const unsigned long long* tot2, int C2, int B, int HW,
                               int G, float eps, const float* gamma, const float* beta, float* ab, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!part2) { C2 = 0; nslab2 = 0; }
+    if (!tot2) C2 = 0;
     int C = C1 + C2;
-    BC_CHECK_ARG(part1 && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0 && nslab1 > 0,
+    BC_CHECK_ARG(tot1 && gamma && beta && ab && G > 0 && G <= GN_MAX_GROUPS && C % G == 0,
                  "bc_gn_finalize: bad args (groups <= %d, C %% G == 0)", GN_MAX_GROUPS);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2, C2, HW, G, eps,
-                       gamma, beta, ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(64), 0, stream, tot1, C1, tot2, C2, HW, G, eps, gamma, beta, ab);
     BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_memset_zero(void* ptr, long long bytes, bc_stream stream_) {
+    BC_CHECK_ARG(ptr && bytes > 0, "bc_memset_zero: bad args");
+    BC_CHECK_HIP(hipMemsetAsync(ptr, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream_)));
     return 0;
 }
 
@@ -400,22 +351,21 @@ extern "C" int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2,
     return 0;
 }
 
-extern "C" int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2,
+extern "C" int bc_gn_apply_fused(const unsigned long long* tot1, int C1, const unsigned long long* tot2, int C2,
                                  const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
                                  const float* beta, int silu, bc_half* y, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!part2 || !x2) { C2 = 0; nslab2 = 0; part2 = nullptr; x2 = nullptr; }
+    if (!tot2 || !x2) { C2 = 0; tot2 = nullptr; x2 = nullptr; }
     const int C = C1 + C2;
-    BC_CHECK_ARG(part1 && x1 && y && gamma && beta && G > 0 && C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && nslab1 > 0,
-                 "bc_gn_apply_fused: bad args");
+    BC_CHECK_ARG(tot1 && x1 && y && gamma && beta && G > 0 && C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0, "bc_gn_apply_fused: bad args");
     BC_CHECK_ARG(C / G <= 96, "bc_gn_apply_fused: %d channels per group (> 96): use bc_gn_finalize + bc_gn_apply", C / G);
     const int cblocks = bc_ceil_div(C, 64);
-    // ~512 workgroups in total, at least 32 pixels each (the prologue's partial re-reduction is amortised over the pixels)
+    // ~512 workgroups in total, at least 32 pixels each
     int pblocks = std::max(1, std::min(bc_ceil_div(HW, 32), bc_ceil_div(512, cblocks * B)));
     int ppb = bc_ceil_div(bc_ceil_div(HW, pblocks), 32) * 32;
     pblocks = bc_ceil_div(HW, ppb);
-    hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(cblocks, pblocks, B), dim3(256), 0, stream, part1, nslab1, C1, part2, nslab2,
-                       C2, reinterpret_cast<const h16*>(x1), reinterpret_cast<const h16*>(x2), HW, G, eps, gamma, beta, silu,
+    hipLaunchKernelGGL(gn_apply_fused_kernel, dim3(cblocks, pblocks, B), dim3(256), 0, stream, tot1, C1, tot2, C2,
+                       reinterpret_cast<const h16*>(x1), reinterpret_cast<const h16*>(x2), HW, G, eps, gamma, beta, silu,
                        ppb, reinterpret_cast<h16*>(y));
     BC_CHECK_LAUNCH();
     return 0;

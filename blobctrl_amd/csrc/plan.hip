@@ -28,9 +28,9 @@ namespace {
 // argument kinds of the recordable entry points (stream argument excluded): p = device pointer, i = int, f = float, l = long long
 const char* op_signature(int op) {
     switch (op) {
-        case BC_OP_GN_STATS: return "piiipi";
-        case BC_OP_GN_FINALIZE: return "piipiiiiifppp";
-        case BC_OP_GN_APPLY_FUSED: return "piipiippiiifppip";
+        case BC_OP_GN_STATS: return "piiip";
+        case BC_OP_GN_FINALIZE: return "pipiiiifppp";
+        case BC_OP_GN_APPLY_FUSED: return "pipippiiifppip";
         case BC_OP_GN_APPLY: return "pipiiipip";
         case BC_OP_LAYERNORM: return "piiippfpi";
         case BC_OP_ATTENTION:
@@ -49,8 +49,9 @@ const char* op_signature(int op) {
         case BC_OP_GAUSSIAN_SAMPLE: return "ppiiifp";
         case BC_OP_SIGNAL:
         case BC_OP_WAIT: return "i";
-        case BC_OP_ROWCHAIN: return "iiiipppppiiipppppipffppipi";
+        case BC_OP_ROWCHAIN: return "iiiipppppifpppiiipppppipffppipi";
         case BC_OP_ASSEMBLE_IM2COL: return "pippiiiiip";
+        case BC_OP_MEMSET_ZERO: return "pl";
         default: return nullptr;
     }
 }
@@ -59,8 +60,8 @@ const char* op_signature(int op) {
 const size_t kGemmPtrFields[] = {
     offsetof(BcGemm, A), offsetof(BcGemm, A2), offsetof(BcGemm, W), offsetof(BcGemm, bias), offsetof(BcGemm, rowvec),
     offsetof(BcGemm, rowvec_idx), offsetof(BcGemm, colscale), offsetof(BcGemm, alpha_dev), offsetof(BcGemm, alpha_idx),
-    offsetof(BcGemm, R), offsetof(BcGemm, R2), offsetof(BcGemm, C), offsetof(BcGemm, gn_part), offsetof(BcGemm, a_affine),
-    offsetof(BcGemm, a_part1), offsetof(BcGemm, a_part2), offsetof(BcGemm, a_gamma), offsetof(BcGemm, a_beta),
+    offsetof(BcGemm, R), offsetof(BcGemm, R2), offsetof(BcGemm, C), offsetof(BcGemm, gn_tot), offsetof(BcGemm, a_affine),
+    offsetof(BcGemm, a_tot1), offsetof(BcGemm, a_tot2), offsetof(BcGemm, a_gamma), offsetof(BcGemm, a_beta),
     offsetof(BcGemm, ln_colsum), offsetof(BcGemm, C_t)};
 
 struct Rec {
@@ -127,13 +128,14 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
         case BC_OP_GEMM:
             if (r.g.splitk > 1) r.g.slab = pl->slab[r.sid];
             return bc_gemm(&r.g, s);
-        case BC_OP_GN_STATS: return bc_gn_stats(CP(bc_half, 0), I(1), I(2), I(3), MP(float, 4), I(5), s);
+        case BC_OP_GN_STATS: return bc_gn_stats(CP(bc_half, 0), I(1), I(2), I(3), MP(unsigned long long, 4), s);
         case BC_OP_GN_FINALIZE:
-            return bc_gn_finalize(CP(float, 0), I(1), I(2), CP(float, 3), I(4), I(5), I(6), I(7), I(8), F(9), CP(float, 10), CP(float, 11),
-                                  MP(float, 12), s);
+            return bc_gn_finalize(CP(unsigned long long, 0), I(1), CP(unsigned long long, 2), I(3), I(4), I(5), I(6), F(7), CP(float, 8),
+                                  CP(float, 9), MP(float, 10), s);
         case BC_OP_GN_APPLY_FUSED:
-            return bc_gn_apply_fused(CP(float, 0), I(1), I(2), CP(float, 3), I(4), I(5), CP(bc_half, 6), CP(bc_half, 7), I(8), I(9), I(10),
-                                     F(11), CP(float, 12), CP(float, 13), I(14), MP(bc_half, 15), s);
+            return bc_gn_apply_fused(CP(unsigned long long, 0), I(1), CP(unsigned long long, 2), I(3), CP(bc_half, 4), CP(bc_half, 5), I(6),
+                                     I(7), I(8), F(9), CP(float, 10), CP(float, 11), I(12), MP(bc_half, 13), s);
+        case BC_OP_MEMSET_ZERO: return bc_memset_zero(P(0), L(1), s);
         case BC_OP_GN_APPLY:
             return bc_gn_apply(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), CP(float, 6), I(7), MP(bc_half, 8), s);
         case BC_OP_LAYERNORM:
@@ -164,9 +166,10 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
         case BC_OP_ASSEMBLE_IM2COL:
             return bc_assemble_input_im2col(CP(float, 0), I(1), CP(float, 2), CP(float, 3), I(4), I(5), I(6), I(7), I(8), MP(bc_half, 9), s);
         case BC_OP_ROWCHAIN:
-            return bc_rowchain(I(0), I(1), I(2), I(3), CP(bc_half, 4), CP(float, 5), CP(bc_half, 6), CP(bc_half, 7), CP(bc_half, 8), I(9), I(10),
-                               I(11), CP(bc_half, 12), CP(float, 13), MP(bc_half, 14), MP(bc_half, 15), MP(bc_half, 16), I(17), MP(float, 18),
-                               F(19), F(20), CP(float, 21), CP(int, 22), I(23), MP(float, 24), I(25), s);
+            return bc_rowchain(I(0), I(1), I(2), I(3), CP(bc_half, 4), CP(float, 5), CP(unsigned long long, 6), CP(float, 7), CP(float, 8), I(9),
+                               F(10), CP(bc_half, 11), CP(bc_half, 12), CP(bc_half, 13), I(14), I(15), I(16), CP(bc_half, 17), CP(float, 18),
+                               MP(bc_half, 19), MP(bc_half, 20), MP(bc_half, 21), I(22), MP(unsigned long long, 23), F(24), F(25),
+                               CP(float, 26), CP(int, 27), I(28), MP(float, 29), I(30), s);
         case BC_OP_SIGNAL: {
             hipEvent_t ev;
             int rc = plan_event(pl, I(0), &ev);

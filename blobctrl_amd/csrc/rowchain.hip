@@ -33,7 +33,8 @@ constexpr int RC_BM = 64;              // rows per workgroup
 constexpr int RC_NT = 5;               // 16-channel tiles per wave of an N = C GEMM: a wave owns 80 output channels
 constexpr int RC_HC = 128;             // feed-forward hidden chunk
 constexpr int RC_RPAD = 20;            // padding fragments at the end of every wave's stream (>= the deepest ring)
-// Ring depth R (fragments of 1 KiB per wave in flight ahead of the MFMAs): 14 for IN, 16 for MID, 15 for OUT (a feed-forward chunk
+// Ring depth R (fragments of 1 KiB per wave in flight ahead of the MFMAs): 13 for IN (12 at 640 channels; 14 spills three registers
+// since the GroupNorm finalize moved into its prologue), 16 for MID, 15 for OUT (a feed-forward chunk
 // must consume a whole number of rings): 56-64 KiB per 4 waves in flight, what ~70 GB/s per CU needs at ~1 us of L2 / HBM latency.
 
 // Channel count C in {320, 640}: C / 80 waves (4 / 8), 64 rows per workgroup either way.
@@ -58,6 +59,11 @@ struct RowChainArgs {
     int kind, M, rows_per_batch;
     const h16* x;            // IN: block input rows [M][C]; MID / OUT: attention output rows
     const float* affine;     // IN: GroupNorm affine [B][C][2] or null
+    const unsigned long long* gn_in;   // IN: ... or the statistics totals of x [B][C][BC_GN_TOT_WORDS]: the finalize runs in the prologue
+    const float* gn_gamma;   //     (gamma, beta, groups, eps of that GroupNorm)
+    const float* gn_beta;
+    int gn_groups;
+    float gn_eps;
     const h16* res;          // MID / OUT: residual stream before this attention [M][C]
     const h16* res2;         // OUT: the block's input x (added after proj_out)
     const h16* r2;           // OUT: BlobNet residual [bmod][rows_per_batch][C] added where pixel x >= r2_xmin, or null
@@ -69,7 +75,7 @@ struct RowChainArgs {
     h16* out1;               // IN: q|k [M][2C]; MID: q [M][C]; OUT (BlobNet): zero-conv residual [M][C]
     h16* out2;               // IN: V^T [B][C][ldvt]
     int ldvt;
-    float* gn_part;          // OUT: per-channel (sum, sum of squares) of the block output per 64-row slab [B][rpb/64][C][2], or null
+    unsigned long long* gn_tot;   // OUT: statistics totals of the block output [B][C][BC_GN_TOT_WORDS] (added to with integer atomics), or null
     float ln_eps;
     float alpha;             // OUT (BlobNet): zero-conv scale
     const float* alpha_dev;
@@ -213,16 +219,16 @@ __device__ __forceinline__ void S_to_rows(h16* __restrict__ dst, int ld, const c
         }
 }
 
-// global rows -> X operand image, optionally through the per-(image, channel) GroupNorm affine y = a x + b
+// global rows -> X operand image, optionally through the per-(image, channel) GroupNorm affine y = a x + b (table [C][2] in LDS at `abl`)
 template <int RC_C>
-__device__ __forceinline__ void rows_to_X(const h16* __restrict__ src, char* X, const CopyMap& c, const float* __restrict__ ab) {
+__device__ __forceinline__ void rows_to_X(const h16* __restrict__ src, char* X, const CopyMap& c, const char* abl, bool ab) {
     const h16* g = src + (size_t)c.row * RC_C + c.v8 * 8;
 #pragma unroll
     for (int k = 0; k < RCfg<RC_C>::NKC; ++k) {
         float4 a4[4];
         if (ab) {
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) a4[j4] = reinterpret_cast<const float4*>(ab + (c.v8 + 8 * k) * 16)[j4];   // (a, b) of 8 channels
+            for (int j4 = 0; j4 < 4; ++j4) a4[j4] = reinterpret_cast<const float4*>(abl + (c.v8 + 8 * k) * 64)[j4];   // (a, b) of 8 channels
         }
 #pragma unroll
         for (int j = 0; j < RCfg<RC_C>::NPASS; ++j) {
@@ -363,9 +369,9 @@ __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], co
     }
 }
 
-// per-channel (sum, sum of squares) of the fp16 rows in S over the 64 rows: the consumer's GroupNorm statistics
+// per-channel (sum, sum of squares) of the fp16 rows in S over the 64 rows, added to the consumer's GroupNorm statistics totals
 template <int RC_C>
-__device__ __forceinline__ void gn_partials_from_S(const char* S, float* __restrict__ dst, int tid) {
+__device__ __forceinline__ void gn_partials_from_S(const char* S, unsigned long long* __restrict__ dst, int tid) {
     if (tid < RC_C / 2) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
         const int unit = tid >> 1, half = tid & 1;
@@ -376,7 +382,8 @@ __device__ __forceinline__ void gn_partials_from_S(const char* S, float* __restr
             s0 += a; q0 = fmaf(a, a, q0);
             s1 += b; q1 = fmaf(b, b, q1);
         }
-        *reinterpret_cast<float4*>(dst + 4 * tid) = make_float4(s0, q0, s1, q1);
+        bc_gn_tot_add(dst + (size_t)(2 * tid) * BC_GN_TOT_WORDS, s0, q0);
+        bc_gn_tot_add(dst + (size_t)(2 * tid + 1) * BC_GN_TOT_WORDS, s1, q1);
     }
 }
 
@@ -408,9 +415,74 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     };
     stamp(0);
 
+    if (KIND == BC_CHAIN_IN && a.gn_in) {
+        // (before the weight ring is filled: its registers stay out of this prologue)
+        // GroupNorm finalize of this image from the statistics totals (bc_common.h) into S, which is free here: no bc_gn_finalize
+        // launch in front of the block.  gamma / beta first (they are needed last), one thread per channel, eight lanes per group.
+        constexpr int NTH = CF::NTH, PER = (RC_C + NTH - 1) / NTH;
+        float* abl = reinterpret_cast<float*>(S);                       // [C][2]
+        double* scr = reinterpret_cast<double*>(S + RC_C * 8);          // [C][2]
+        float* stat = reinterpret_cast<float*>(S + RC_C * 24);          // [groups][2]
+        float gp[PER], bp_[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int c = tid + NTH * j;
+            gp[j] = c < RC_C ? a.gn_gamma[c] : 0.f;
+            bp_[j] = c < RC_C ? a.gn_beta[c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int c = tid + NTH * j;
+            if (c < RC_C) {
+                double s_, q_;
+                bc_gn_tot_read(a.gn_in + ((size_t)b * RC_C + c) * BC_GN_TOT_WORDS, s_, q_);
+                scr[c * 2] = s_;
+                scr[c * 2 + 1] = q_;
+            }
+        }
+        __syncthreads();
+        const int cpg = RC_C / a.gn_groups, sub = tid & 7;
+        for (int gi = tid >> 3; gi < a.gn_groups; gi += NTH / 8) {
+            double s_ = 0.0, q_ = 0.0;
+            for (int cj = sub; cj < cpg; cj += 8) {
+                s_ += scr[(gi * cpg + cj) * 2];
+                q_ += scr[(gi * cpg + cj) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                s_ += __shfl_xor(s_, o);
+                q_ += __shfl_xor(q_, o);
+            }
+            const double n = (double)a.rows_per_batch * cpg;
+            const double mean = s_ / n;
+            double var = q_ / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (sub == 0) {
+                stat[gi * 2] = (float)mean;
+                stat[gi * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int c = tid + NTH * j;
+            if (c < RC_C) {
+                const int gi = c / cpg;
+                const float av = stat[gi * 2 + 1] * gp[j];
+                abl[c * 2] = av;
+                abl[c * 2 + 1] = bp_[j] - stat[gi * 2] * av;
+            }
+        }
+        __syncthreads();
+    } else if (KIND == BC_CHAIN_IN && a.affine) {
+        // the table bc_gn_finalize wrote, staged in S like the in-kernel one (one way for rows_to_X to read it)
+        const float4* src4 = reinterpret_cast<const float4*>(a.affine + (size_t)b * RC_C * 2);
+        for (int i = tid; i < RC_C / 2; i += CF::NTH) reinterpret_cast<float4*>(S)[i] = src4[i];
+        __syncthreads();
+    }
     constexpr bool FFLOOP = KIND == BC_CHAIN_OUT || FF;      // kinds that run the feed-forward loop
-    constexpr int RC_R = RC_C == 320 ? (FFLOOP ? 15 : (KIND == BC_CHAIN_IN ? 14 : 16))
-                                     : (FFLOOP ? 10 : (KIND == BC_CHAIN_IN ? 14 : 12));   // (8 waves: two per SIMD hide more latency)
+    constexpr int RC_R = RC_C == 320 ? (FFLOOP ? 15 : (KIND == BC_CHAIN_IN ? 13 : 16))
+                                     : (FFLOOP ? 10 : (KIND == BC_CHAIN_IN ? 12 : 12));   // (8 waves: two per SIMD hide more latency)
     static_assert(RC_R <= RC_RPAD, "stream padding");
     WRing<RC_R> ring;
     ring.p = a.wstream + ((size_t)z * CF::NW + wave) * a.wave_frags * 64 + lane;
@@ -420,7 +492,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     zero_acc(acc);
 
     if (KIND == BC_CHAIN_IN) {
-        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, a.affine ? a.affine + (size_t)b * RC_C * 2 : nullptr);
+        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, S, a.gn_in != nullptr || a.affine != nullptr);
         lds_barrier();
         stamp(1);
         // proj_in -> h0
@@ -476,7 +548,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
 
     // MID / OUT / OUT_FF: X = attention output rows, S = the residual stream
     if (!TAIL) {
-        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, nullptr);
+        rows_to_X<RC_C>(a.x + (size_t)m0 * RC_C, X, cm, S, false);
         rows_to_S<RC_C>(a.res + (size_t)m0 * RC_C, S, cm);
         lds_barrier();
         stamp(1);
@@ -608,8 +680,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     acc_to_S<RC_C>(acc, S, wave, m, q);
     lds_barrier();
     S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
-    if (a.gn_part)
-        gn_partials_from_S<RC_C>(S, a.gn_part + ((size_t)b * (a.rows_per_batch / RC_BM) + pix0 / RC_BM) * RC_C * 2, tid);
+    if (a.gn_tot) gn_partials_from_S<RC_C>(S, a.gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid);
     stamp(7);
     if (BLOB) {
         // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
@@ -718,9 +789,10 @@ extern "C" long long bc_rowchain_stream_frags(int channels, int kind, int blobne
     return -1;
 }
 
-extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine,
+                           const unsigned long long* gn_in, const float* gn_gamma, const float* gn_beta, int gn_groups, float gn_eps, const bc_half* res,
                            const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
-                           const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
+                           const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, unsigned long long* gn_tot, float ln_eps,
                            float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit,
                            bc_stream stream) {
     BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
@@ -734,6 +806,10 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
     RowChainArgs a;
     a.kind = kind; a.M = M; a.rows_per_batch = rows_per_batch;
     a.x = reinterpret_cast<const h16*>(x); a.affine = affine;
+    a.gn_in = kind == BC_CHAIN_IN ? gn_in : nullptr; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.gn_groups = gn_groups; a.gn_eps = gn_eps;
+    if (a.gn_in)
+        BC_CHECK_ARG(gn_gamma && gn_beta && gn_groups > 0 && channels % gn_groups == 0 && channels / gn_groups >= 1 && !affine,
+                     "bc_rowchain(IN): the in-kernel GroupNorm finalize needs gamma, beta, groups | channels (and no affine table)");
     a.res = reinterpret_cast<const h16*>(res); a.res2 = reinterpret_cast<const h16*>(res2);
     a.r2 = reinterpret_cast<const h16*>(r2); a.r2_xmin = r2_xmin; a.r2_bmod = r2_bmod > 0 ? r2_bmod : 1; a.out_w = out_w > 0 ? out_w : 1;
     a.wstream = reinterpret_cast<const uint4*>(wstream);
@@ -741,7 +817,7 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
     a.part = part; a.nsplit = nsplit > 0 ? nsplit : 1;
     a.vec = vec;
     a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1); a.out2 = reinterpret_cast<h16*>(out2);
-    a.ldvt = ldvt; a.gn_part = gn_part; a.ln_eps = ln_eps;
+    a.ldvt = ldvt; a.gn_tot = gn_tot; a.ln_eps = ln_eps;
     a.alpha = alpha; a.alpha_dev = alpha_dev; a.alpha_idx = alpha_idx; a.alpha_bstride = alpha_bstride;
     a.stamps = nullptr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

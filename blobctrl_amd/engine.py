@@ -221,12 +221,15 @@ class TrunkPlan:
             if key not in cache:
                 cache[key] = pack_rowchain(pw, p, kind, zname, nsplit)
             return cache[key]
-        ab = rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"])
+        if os.environ.get("BC_GN_FINALIZE_LAUNCH"):
+            gnkw = dict(affine=rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"]))
+        else:                                              # the GroupNorm finalize runs in the IN launch's prologue, from the statistics totals
+            gnkw = dict(gn_in=(rec.gn_sources(x.t, Cc, None, 0, B, HW)[0], pw.f[p + "norm.weight"], pw.f[p + "norm.bias"], self.G, 1e-6))
         h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
         w, v = packed(_lib.CHAIN_IN)
-        rec.rowchain(_lib.CHAIN_IN, Cc, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, affine=ab)
+        rec.rowchain(_lib.CHAIN_IN, Cc, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, **gnkw)
         a = rec.empty(M, Cc)
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
                       scale, q_off=0, k_off=Cc)
@@ -240,8 +243,7 @@ class TrunkPlan:
             rec.attention(q2, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
             h = h1
         out = rec.empty(M, Cc)
-        nslab = HW // 64
-        part = rec.empty(B, nslab, Cc, 2, dtype=torch.float32)
+        part = rec.new_tot(B, Cc)                            # GroupNorm statistics of the block output (the next ResBlock's norm1)
         kw = {}
         r2kw = self._r2(r2, x.H, x.W)                      # (records the wait for the BlobNet branch's residual)
         if r2kw:
@@ -260,11 +262,11 @@ class TrunkPlan:
             w, v = packed(_lib.CHAIN_OUT_FF, zname, nsplit)
             rec.rowchain(_lib.CHAIN_OUT_FF, Cc, M, HW, a, w, v, None, res=h, part=ffp, nsplit=nsplit)
             w, v = packed(_lib.CHAIN_OUT_TAIL, zname)
-            rec.rowchain(_lib.CHAIN_OUT_TAIL, Cc, M, HW, None, w, v, out, res2=x.t, gn_part=part, part=ffp, nsplit=nsplit, **kw)
+            rec.rowchain(_lib.CHAIN_OUT_TAIL, Cc, M, HW, None, w, v, out, res2=x.t, gn_tot=part, part=ffp, nsplit=nsplit, **kw)
         else:
             w, v = packed(_lib.CHAIN_OUT, zname)
-            rec.rowchain(_lib.CHAIN_OUT, Cc, M, HW, a, w, v, out, res=h, res2=x.t, gn_part=part, **kw)
-        rec.parts[out.data_ptr()] = (part, nslab)
+            rec.rowchain(_lib.CHAIN_OUT, Cc, M, HW, a, w, v, out, res=h, res2=x.t, gn_tot=part, **kw)
+        rec.tots[out.data_ptr()] = part
         return Act(out, Cc, x.H, x.W), res_out
 
     def gw_tile(self, M, N, K, C1=0, prefer=None):
@@ -272,7 +274,7 @@ class TrunkPlan:
         Measured per shape on an MI355X (tools/gw_probe.py, cold weights, graph replay): at M <= 1024 every projection is latency-bound
         (~11 us whatever the kernel), so the choice only matters where a launch disappears with it (LayerNorm folded, q | k | V^T in one
         launch) or the grid fills the chip (N >= 2560)."""
-        if os.environ.get("BC_NO_GW") or M > 1024:
+        if os.environ.get("BC_NO_GW") or M > int(os.environ.get("BC_GW_MAXM", "1024")):
             return 0
         order = prefer or (_lib.TILE_GW64x128,)
         for cfg in order:
@@ -292,6 +294,11 @@ class TrunkPlan:
         G128, G256, G320 = _lib.TILE_GW64x128, _lib.TILE_GW64x256, _lib.TILE_GW64x320
 
         def proj(a_t, wname, N, K, cfg, ln=None, bias=True, extra=(), **kw):
+            for c in (cfg, G128, G320, G256):                 # (the preferred workgroup shape, else one that divides N and the split point)
+                bn = 64 * _lib.GW_TILES[c]
+                if N % bn == 0 and kw.get("n_t0", 0) % bn == 0 and rec.lib.bc_gemm_wreg_eligible(M, N, K, 0, c):
+                    cfg = c
+                    break
             w, cs, b = pw.gw(wname + ".weight", cfg, ln=ln, bias=(wname + ".bias") if bias else None, extra=extra)
             n_out = N // 2 if kw.get("act") == _lib.ACT_GEGLU else N
             out = kw.pop("out", None)

@@ -34,6 +34,25 @@ def tuning_table():
     return _TUNING
 
 
+def decode_gn_tot(tot: torch.Tensor) -> torch.Tensor:
+    """GroupNorm statistics totals [..., GN_TOT_WORDS] int64 (include/blobctrl_hip.h) -> (sum, sum of squares) [..., 2] float64."""
+    t = tot.to(torch.float64).cpu()
+    w = torch.tensor([2.0 ** -60, 2.0 ** -20, 2.0 ** 20], dtype=torch.float64)
+    return torch.stack([(t[..., 0:3] * w).sum(-1), (t[..., 3:6] * w).sum(-1)], -1)
+
+
+def encode_gn_tot(sums: torch.Tensor) -> torch.Tensor:
+    """(sum, sum of squares) [..., 2] -> totals [..., GN_TOT_WORDS] int64, sliced the way the kernels do it (csrc/bc_common.h
+    bc_gn_slices): tools and tests that stand in for a producer."""
+    d = sums.to(torch.float64)
+    h = torch.floor(d * 2.0 ** -20)
+    r = d - h * 2.0 ** 20
+    m = torch.floor(r * 2.0 ** 20)
+    r2 = r - m * 2.0 ** -20
+    sl = torch.stack([torch.floor(r2 * 2.0 ** 60), m, h], -1).to(torch.int64)          # [..., 2, 3]
+    return sl.reshape(*sums.shape[:-1], 6).contiguous()
+
+
 def ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -151,7 +170,8 @@ class Recorder:
             _lib.check(self.lib.bc_device_info(info), "bc_device_info")
             self.num_cu = info[0]
         self.bytes_allocated = 0
-        self.parts = {}                     # data_ptr of a GEMM output -> (per-channel GroupNorm partials, nslab)
+        self.tots = {}                      # data_ptr of an activation -> its GroupNorm statistics totals [B][C][GN_TOT_WORDS] (int64)
+        self._tot_chunk = None              # (segment id, stream id, chunk tensor, used words): the arena new tables are carved from
         self.sid = 0                        # stream id new launches are recorded for (0 main, 1 side)
         self.events = []
         self.loop_graphs = []
@@ -285,6 +305,24 @@ class Recorder:
             self._slab_elems[sid] = elems
             _lib.check(self.lib.bc_plan_set_slab(self.plan, sid, self._slab[sid].data_ptr()), "bc_plan_set_slab")
 
+    # ------------------------------------------------------------------ GroupNorm statistics totals
+    TOT_CHUNK_WORDS = 1 << 20               # 8 MiB of int64 per (segment, stream): > all statistics tables of one trunk forward at batch 8
+
+    def new_tot(self, B, Cc):
+        """A statistics table [B][C][GN_TOT_WORDS] (int64 words, include/blobctrl_hip.h) for the producer(s) of one activation,
+        carved from the current (segment, stream) chunk.  A chunk is zeroed by ONE bc_memset_zero recorded where it is first used -
+        before every producer that adds to it - so a replay starts from zero totals with one extra launch per segment and stream."""
+        n = B * Cc * _lib.GN_TOT_WORDS
+        ch = self._tot_chunk
+        if ch is None or ch[0] != self.seg.id or ch[1] != self.sid or ch[3] + n > ch[2].numel():
+            t = self.zeros(max(self.TOT_CHUNK_WORDS, n), dtype=torch.int64)
+            self.keep.append(t)
+            self._op("bc_memset_zero", (t, t.numel() * 8), "memset", variant="memset_zero", shape=("memset", t.numel() * 8))
+            ch = self._tot_chunk = [self.seg.id, self.sid, t, 0]
+        view = ch[2][ch[3]:ch[3] + n].view(B, Cc, _lib.GN_TOT_WORDS)
+        ch[3] += (n + 31) // 32 * 32        # (256-byte aligned tables)
+        return view
+
     # ------------------------------------------------------------------ GEMM family
     def plan_gemm(self, M, N, K, fast, mode, tile_cfg=0, splitk=None):
         """(tile_cfg, splitk, bm, bn) for a GEMM: tuning table first, then the library's cost model (bc_gemm_plan)."""
@@ -380,21 +418,17 @@ class Recorder:
             fast, mode = True, "halo"
             if a_gn is not None:
                 # GroupNorm in front of the convolution: a_gn = dict(x1, C1, x2, C2, B, HW, G, eps, gamma, beta).  The finalize runs
-                # inside the convolution's prologue when the workgroup's channel span fits its scratch, else as its own launch.
+                # inside the convolution's prologue - every workgroup reads the statistics totals (six words per channel) of the groups
+                # overlapping its channel span - whenever that span fits the kernel's scratch, else as its own launch.
                 G_ = a_gn["G"]
                 span = cps * 64 + 2 * (conv["Cin"] // G_)
-                (pa1, ns1), (pa2, ns2) = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"])
-                # Every workgroup re-reduces span x nslab partials: measured a LOSS against one bc_gn_finalize launch when that is
-                # 170 KB per workgroup (64 x 128 level: 63.9 vs 55.5 us per conv), a gain when it is a few KB (low-resolution levels)
-                vol = span * max(ns1, ns2) * 8
-                # in the kernel's prologue where every workgroup re-reduces at most 30 KB (the 16 x 32 and 8 x 16 levels: 9.81 -> 9.74 ms
-                # per step, round 3); above that the redundant reduction costs more than the launch it saves (60 KB: +0.05 ms, all: +0.4)
-                limit = int(os.environ.get("BC_GN_FINALIZE_IN_KERNEL_BYTES", "30000"))
-                if span <= 712 and vol <= limit:
-                    g.a_part1, g.a_ns1, g.a_part2, g.a_ns2 = ptr(pa1), ns1, ptr(pa2), ns2
+                t1, t2 = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"])
+                fin_max = 2752 if tile_cfg == _lib.TILE_WREG else 712          # (FIN_MAX_CH of conv_wreg.hip / conv_halo.hip)
+                if span <= fin_max and not os.environ.get("BC_GN_FINALIZE_LAUNCH"):
+                    g.a_tot1, g.a_tot2 = ptr(t1), ptr(t2)
                     g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), G_, a_gn["eps"]
-                    self.keep.append((pa1, pa2, a_gn["gamma"], a_gn["beta"]))
-                    for t in (pa1, pa2, a_gn["gamma"], a_gn["beta"]):
+                    self.keep.append((t1, t2, a_gn["gamma"], a_gn["beta"]))
+                    for t in (t1, t2, a_gn["gamma"], a_gn["beta"]):
                         self.register(t)
                     mode = "halo_gnfin"
                 else:
@@ -413,19 +447,17 @@ class Recorder:
         g.tile_cfg = cfg
         if sk > 1:
             self.reserve_slab(sk * M * N)
-        rec = self
         part = None
         if want_gn:
             rpb = rows_per_batch if rows_per_batch > 0 else (conv["Hout"] * conv["Wout"] if conv else M)
             vec = out_mode == _lib.OUT_F16 and n_out % 8 == 0 and g.ldc % 8 == 0 and (R is None or ldr % 8 == 0) and \
                 (R2 is None or ldr2 % 8 == 0)
-            slab_rows = bm if sk == 1 else 32
+            slab_rows = bm if sk == 1 else 32            # (a workgroup's rows must lie inside one image)
             if vec and (fast or sk > 1) and N % 4 == 0 and rpb % slab_rows == 0 and M % rpb == 0 and \
                     not os.environ.get("BC_GEMM_TILE"):
-                nslab = rpb // slab_rows
-                part = self.empty(M // rpb, nslab, n_out, 2, dtype=torch.float32)
-                g.gn_part = part.data_ptr()
-                self.parts[g.C] = (part, nslab)
+                part = self.new_tot(M // rpb, n_out)
+                g.gn_tot = part.data_ptr()
+                self.tots[g.C] = part
 
         idx = self.lib.bc_plan_add_gemm(self.plan, self.seg.id, self.sid, C.byref(g))
         if idx < 0 or idx != len(self.seg.meta):
@@ -445,46 +477,45 @@ class Recorder:
         self._add_op(_lib.OPS[name], _lib.op_signature(name), args, kind, **meta)
 
     def gn_sources(self, x1, C1, x2, C2, B, HW):
-        """Per-channel partial statistics of (x1 | x2): the producers' epilogue partials when they exist, else a recorded
-        bc_gn_stats pass.  Returns ((part1, nslab1), (part2, nslab2))."""
+        """GroupNorm statistics totals of (x1 | x2): the tables the producers' epilogues added to when they exist, else a recorded
+        bc_gn_stats pass.  Returns (tot1, tot2 or None)."""
         srcs = []
         for x, c in ((x1, C1), (x2, C2 if x2 is not None else 0)):
             if x is None:
-                srcs.append((None, 0))
+                srcs.append(None)
                 continue
-            hit = self.parts.get(x.data_ptr())
-            if hit is not None and hit[0].shape[2] == c:
-                srcs.append((hit[0], hit[1]))
+            hit = self.tots.get(x.data_ptr())
+            if hit is not None and hit.shape[1] == c:
+                srcs.append(hit)
             else:
-                nslab = (HW + 127) // 128
-                part = self.empty(B, nslab, c, 2, dtype=torch.float32)
-                self.keep.append((x, part))
-                self._op("bc_gn_stats", (x, c, B, HW, part, nslab), "gn_stats", variant="gn_stats_kernel",
+                tot = self.new_tot(B, c)
+                self.keep.append((x, tot))
+                self._op("bc_gn_stats", (x, c, B, HW, tot), "gn_stats", variant="gn_stats_kernel",
                          shape=("gn_stats", B, HW, c), bytes_=B * HW * c * 2)
-                self.parts[x.data_ptr()] = (part, nslab)
-                srcs.append((part, nslab))
+                self.tots[x.data_ptr()] = tot
+                srcs.append(tot)
         return tuple(srcs)
 
     def groupnorm(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta, silu, out=None):
-        """GroupNorm(+SiLU) of the channel-concat (x1 | x2) as its own pass.  Per-channel partial statistics are taken from the
-        producing GEMM's epilogue when it emitted them (self.parts), otherwise a standalone bc_gn_stats pass is recorded."""
+        """GroupNorm(+SiLU) of the channel-concat (x1 | x2) as its own pass.  The statistics come from the producing GEMM's epilogue
+        when it emitted them (self.tots), otherwise a standalone bc_gn_stats pass is recorded."""
         c2 = C2 if x2 is not None else 0
         Cc = C1 + c2
         if out is None:
             out = self.empty(B, HW, Cc)
-        n_before = len(self.seg.meta)
-        (pa1, ns1), (pa2, ns2) = self.gn_sources(x1, C1, x2, c2, B, HW)
-        own_stats = len(self.seg.meta) > n_before
+        n_before = self.seg.kinds.get("gn_stats", 0)
+        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW)
+        own_stats = self.seg.kinds.get("gn_stats", 0) > n_before
         fused = not os.environ.get("BC_GN_UNFUSED") and Cc // G <= 96          # (the fused kernel's LDS staging holds <= 256 channels)
-        self.keep.append((x1, x2, pa1, pa2, gamma, beta, out))
+        self.keep.append((x1, x2, t1, t2, gamma, beta, out))
         kind = "groupnorm" + ("" if own_stats else "_fused_stats")
         if fused:
-            self._op("bc_gn_apply_fused", (pa1, ns1, C1, pa2, ns2, c2, x1, x2, B, HW, G, eps, gamma, beta, 1 if silu else 0, out), kind,
+            self._op("bc_gn_apply_fused", (t1, C1, t2, c2, x1, x2, B, HW, G, eps, gamma, beta, 1 if silu else 0, out), kind,
                      variant="gn_apply_fused_kernel", shape=("gn", B, HW, Cc), bytes_=2 * B * HW * Cc * 2)
         else:
             ab = self.empty(B, Cc, 2, dtype=torch.float32)
             self.keep.append(ab)
-            self._op("bc_gn_finalize", (pa1, ns1, C1, pa2, ns2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
+            self._op("bc_gn_finalize", (t1, C1, t2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
                      variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc))
             self._op("bc_gn_apply", (x1, C1, x2, c2, B, HW, ab, 1 if silu else 0, out), kind, variant="gn_apply_kernel",
                      shape=("gn", B, HW, Cc), bytes_=2 * B * HW * Cc * 2)
@@ -492,14 +523,14 @@ class Recorder:
 
     def gn_affine(self, x1, C1, x2, C2, B, HW, G, eps, gamma, beta):
         """Per-(image, channel) affine (rstd*gamma, beta - mean*rstd*gamma) of GroupNorm over the channel-concat (x1 | x2), from the
-        producers' per-channel partial statistics: ab [B][C1+C2][2] fp32.  The consumer convolution applies it (and SiLU) while it
-        stages its input halo (BcGemm.a_affine), so the normalised activation never goes through HBM."""
+        statistics totals: ab [B][C1+C2][2] fp32.  The consumer (row-chain, or a convolution whose channel span is too wide for the
+        in-kernel finalize) applies it while it stages its input, so the normalised activation never goes through HBM."""
         c2 = C2 if x2 is not None else 0
         Cc = C1 + c2
         ab = self.empty(B, Cc, 2, dtype=torch.float32)
-        (pa1, ns1), (pa2, ns2) = self.gn_sources(x1, C1, x2, c2, B, HW)
-        self.keep.append((x1, x2, pa1, pa2, ab, gamma, beta))
-        self._op("bc_gn_finalize", (pa1, ns1, C1, pa2, ns2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
+        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW)
+        self.keep.append((x1, x2, t1, t2, ab, gamma, beta))
+        self._op("bc_gn_finalize", (t1, C1, t2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
                  variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc))
         return ab
 
@@ -522,20 +553,22 @@ class Recorder:
         return out
 
     # ------------------------------------------------------------------ row-chain (fused transformer-block glue, csrc/rowchain.hip)
-    def rowchain(self, kind, Cc, M, rows_per_batch, x, wstream, vec, out0, out1=None, out2=None, ldvt=0, affine=None, res=None, res2=None,
-                 r2=None, r2_xmin=0, r2_bmod=1, out_w=0, gn_part=None, ln_eps=1e-5, alpha=1.0, alpha_dev=None, alpha_idx=None,
+    def rowchain(self, kind, Cc, M, rows_per_batch, x, wstream, vec, out0, out1=None, out2=None, ldvt=0, affine=None, gn_in=None, res=None, res2=None,
+                 r2=None, r2_xmin=0, r2_bmod=1, out_w=0, gn_tot=None, ln_eps=1e-5, alpha=1.0, alpha_dev=None, alpha_idx=None,
                  alpha_bstride=0, part=None, nsplit=1):
         """`part` / `nsplit`: the split form of the block end (CHAIN_OUT_FF writes, CHAIN_OUT_TAIL reads the fp32 partial sums
         [nsplit][M][C] of the feed-forward: include/blobctrl_hip.h)."""
         mult = {_lib.CHAIN_IN: 4, _lib.CHAIN_MID: 2, _lib.CHAIN_OUT: 14 + (1 if out1 is not None else 0), _lib.CHAIN_OUT_FF: 13,
                 _lib.CHAIN_OUT_TAIL: 1 + (1 if out1 is not None else 0)}[kind]
-        refs = (x, wstream, vec, out0, out1, out2, affine, res, res2, r2, gn_part, alpha_dev, alpha_idx, part)
+        # gn_in = (totals of x, gamma, beta, groups, eps): CHAIN_IN finalizes the GroupNorm in front of proj_in in its own prologue
+        g_tot, g_gamma, g_beta, g_groups, g_eps = gn_in if gn_in is not None else (None, None, None, 0, 0.0)
+        refs = (x, wstream, vec, out0, out1, out2, affine, res, res2, r2, gn_tot, alpha_dev, alpha_idx, part, g_tot, g_gamma, g_beta)
         self.keep.append(refs)
         for t in refs:
             self.register(t)
         name = {_lib.CHAIN_IN: "in", _lib.CHAIN_MID: "mid", _lib.CHAIN_OUT: "out", _lib.CHAIN_OUT_FF: f"out_ff/{nsplit}", _lib.CHAIN_OUT_TAIL: "out_tail"}[kind]
-        self._op("bc_rowchain", (kind, Cc, M, rows_per_batch, x, affine, res, res2, r2, r2_xmin, r2_bmod, out_w, wstream, vec, out0, out1, out2,
-                                 ldvt, gn_part, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride, part, nsplit), "rowchain",
+        self._op("bc_rowchain", (kind, Cc, M, rows_per_batch, x, affine, g_tot, g_gamma, g_beta, g_groups, g_eps, res, res2, r2, r2_xmin, r2_bmod, out_w, wstream, vec, out0, out1, out2,
+                                 ldvt, gn_tot, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride, part, nsplit), "rowchain",
                  flops=2 * M * Cc * Cc * mult,
                  variant=f"rowchain_kernel<{name}{',zero' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else ''}>",
                  shape=("rowchain_" + name, M, Cc, mult * Cc))

@@ -89,11 +89,11 @@ typedef struct BcGemm {
     /* ---- split-K ---- */
     int splitk;              /* >=1 ; >1 needs `slab` of splitk*M*N floats */
     float* slab;
-    /* ---- optional fused GroupNorm statistics of the (fp16-rounded) OUTPUT: per-channel (sum, sumsq) partials
-     *      gn_part[B][rows_per_batch / slab_rows][n_out][2], slab_rows = bm of bc_gemm_plan when splitk == 1 (fast path only)
-     *      or 32 when splitk > 1 (emitted by the split-K reducer).  Needs BC_OUT_F16, widths % 8 == 0 and
-     *      rows_per_batch % slab_rows == 0.  Consumed by bc_gn_finalize (replaces the bc_gn_stats pass). ---- */
-    float* gn_part;
+    /* ---- optional fused GroupNorm statistics of the (fp16-rounded) OUTPUT: every workgroup ADDS the per-channel (sum, sumsq) of its
+     *      rows to the totals gn_tot[B][n_out][BC_GN_TOT_WORDS] (see "GroupNorm statistics totals" below; the table must be zero before
+     *      the launch).  Fast path or split-K reducer only; needs BC_OUT_F16, widths % 8 == 0 and rows_per_batch % slab_rows == 0
+     *      (slab_rows = bm of bc_gemm_plan, or 32 with split-K: a workgroup's rows lie in one image).  Replaces the bc_gn_stats pass. ---- */
+    unsigned long long* gn_tot;
     /* ---- tile configuration: 0 = library heuristic, else one of BC_TILE_* (see bc_gemm_plan) ---- */
     int tile_cfg;
     /* ---- A-operand prologue (BC_TILE_HALO only): the GroupNorm(+SiLU) in front of a ResBlock convolution
@@ -103,12 +103,12 @@ typedef struct BcGemm {
     const float* a_affine;
     int a_act;               /* BC_ACT_NONE or BC_ACT_SILU */
     /* ---- ... or the same prologue with the GroupNorm FINALIZE done inside the convolution (no bc_gn_finalize launch): every
-     *      workgroup re-reduces the producers' per-channel partial statistics of the groups overlapping its channel range
-     *      (a_part1 [B][a_ns1][C1][2] for the channels of A, a_part2 [B][a_ns2][Cin - C1][2] for A2; same layout as gn_part),
-     *      then applies (x - mean) * rstd * a_gamma[k] + a_beta[k] and a_act.  Used when a_part1 != NULL (a_affine is then ignored);
-     *      needs the workgroup's channel span (+ group straddle) <= 720 channels, else call bc_gn_finalize and pass a_affine. ---- */
-    const float* a_part1; int a_ns1;
-    const float* a_part2; int a_ns2;
+     *      workgroup reads the statistics totals of the groups overlapping its channel range (a_tot1 [B][C1][BC_GN_TOT_WORDS] for the
+     *      channels of A, a_tot2 [B][Cin - C1][..] for A2; same layout as gn_tot), then applies (x - mean) * rstd * a_gamma[k] +
+     *      a_beta[k] and a_act.  Used when a_tot1 != NULL (a_affine is then ignored); needs the workgroup's channel span (+ group
+     *      straddle) <= 2752 channels (BC_TILE_HALO: 720), else call bc_gn_finalize and pass a_affine. ---- */
+    const unsigned long long* a_tot1;
+    const unsigned long long* a_tot2;
     const float* a_gamma; const float* a_beta;
     int a_groups; float a_eps;
     /* ---- BC_TILE_GW* only: LayerNorm in front of the projection, FOLDED (attention.py:447,491,517 norm1/2/3 -> to_q|k|v, ff.net.0):
@@ -155,7 +155,7 @@ int bc_conv_halo_eligible(int Cin, int C1, int N, int Hin, int Win, int Hout, in
 /* most 64-channel chunks one workgroup of BC_TILE_HALO may take: callers keep ceil(Cin / 64 / splitk) <= this */
 int bc_conv_halo_max_chunks(void);
 /* Resolve the plan for a GEMM: in/out *tile_cfg (AUTO -> heuristic choice), in/out *splitk (<= 0 -> heuristic), out *bm,
- * *bn = tile shape (bm is the slab height of gn_part).  `fast` = 1 when the problem meets the fast-path conditions
+ * *bn = tile shape.  `fast` = 1 when the problem meets the fast-path conditions
  * (K % 64 == 0, conv Cin % 64 == 0, concat split % 64 == 0); otherwise only 128x128 / 256x64 generic tiles exist. */
 int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int* bm, int* bn);
 
@@ -163,22 +163,30 @@ int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int*
  * GroupNorm (+SiLU) over NHWC, optionally over a channel-concat of two tensors.
  * Replaces F.group_norm + F.silu (resnet.py:327-328,351-363; transformer_2d.py:481; unet_2d_condition.py:1341-1343)
  * and torch.cat([h, skip], 1) (unet_2d_blocks.py:2559,2719) feeding it.
- *   bc_gn_stats    : per-channel partial sums of ONE tensor, part[B][ceil(HW/128)][C][2] (no atomics: bit-reproducible).
- *                    Only needed when the producing GEMM did not emit them itself (BcGemm.gn_part).
+ * GroupNorm statistics totals (round 4): tot[B][C][BC_GN_TOT_WORDS] 64-bit words per (image, channel) = the sum and the sum of
+ * squares of the fp16 activation over the image, each as three signed 40-bit slices of a fixed-point number (units 2^-60, 2^-20,
+ * 2^20).  Producers (the GEMM / convolution epilogues: BcGemm.gn_tot, bc_rowchain, or bc_gn_stats) reduce their rows in fp32 and ADD
+ * the result with integer atomics - integer sums do not depend on the arrival order, so results stay bit-reproducible - and a
+ * consumer reads six words per channel.  A table must be zero before its producers run: bc_memset_zero (one per plan segment for
+ * all tables of that segment).
+ *   bc_gn_stats    : statistics of ONE tensor added to tot[B][C][..].  Only needed when the producing GEMM did not emit them itself.
  *   bc_gn_finalize : per-channel affine of the concat (x1 | x2): ab[B][C1+C2][2] = (rstd*gamma, beta - mean*rstd*gamma),
- *                    from part_i[B][nslab_i][C_i][2] (part2 may be NULL)
+ *                    from tot_i[B][C_i][..] (tot2 may be NULL)
  *   bc_gn_apply    : y[B][HW][C1+C2] = silu?( x*ab.x + ab.y )   (x = concat(x1, x2))
  * --------------------------------------------------------------------------------------------------------------- */
-int bc_gn_stats(const bc_half* x, int C, int B, int HW, float* part, int nslab, bc_stream stream);
-int bc_gn_finalize(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2, int B, int HW, int G,
+enum { BC_GN_TOT_WORDS = 6 };
+int bc_gn_stats(const bc_half* x, int C, int B, int HW, unsigned long long* tot, bc_stream stream);
+int bc_gn_finalize(const unsigned long long* tot1, int C1, const unsigned long long* tot2, int C2, int B, int HW, int G,
                    float eps, const float* gamma, const float* beta, float* ab, bc_stream stream);
 int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int HW,
                 const float* ab, int silu, bc_half* y, bc_stream stream);
-/* finalize + apply in ONE launch (what the engine uses): every workgroup re-reduces the partials of the groups overlapping
+/* finalize + apply in ONE launch (what the engine uses): every workgroup reads the totals of the groups overlapping
  * its 64-channel range, then normalises its pixels. */
-int bc_gn_apply_fused(const float* part1, int nslab1, int C1, const float* part2, int nslab2, int C2,
+int bc_gn_apply_fused(const unsigned long long* tot1, int C1, const unsigned long long* tot2, int C2,
                       const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
                       const float* beta, int silu, bc_half* y, bc_stream stream);
+/* hipMemsetAsync(ptr, 0, bytes) on the caller's stream (graph-capturable): zeroes the statistics totals at the head of a segment. */
+int bc_memset_zero(void* ptr, long long bytes, bc_stream stream);
 
 /* Row softmax in place on fp16 [rows][cols] (fp32 maths): the single-head, head_dim-512 attention of the VAE mid block is run
  * as GEMM (QK^T) -> softmax -> GEMM (PV)  (attention_processor.py:2216 with heads = 1). */
@@ -275,19 +283,20 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  *   diffusers/src/diffusers/models/transformers/transformer_2d.py:479-527 (norm -> proj_in ... proj_out + residual),
  *   attention.py:421-541 (norm1/2/3, attn to_q / to_k / to_v / to_out, residual adds), activations.py:113-123 and
  *   attention.py:1161-1167 (GEGLU feed-forward), blobctrl/models/blobnet.py:860-864,921-924,936-938 (zero-conv x scale):
- *   BC_CHAIN_IN   x [M][C] --(GroupNorm affine [B][C][2] or NULL)--> proj_in -> out0 = h0 [M][C]; LayerNorm ->
+ *   BC_CHAIN_IN   x [M][C] --(GroupNorm affine [B][C][2], or the statistics totals gn_in [B][C][BC_GN_TOT_WORDS] of x with gn_gamma /
+ *                 gn_beta / gn_groups / gn_eps: the finalize then runs in the kernel's prologue; or neither)--> proj_in -> out0 = h0 [M][C]; LayerNorm ->
  *                 out1 = q|k [M][2C] (row-major), out2 = V^T [B][C][ldvt]
  *   BC_CHAIN_MID  x = attention output, res = h0: to_out + res -> out0 = h1; LayerNorm -> out1 = attn2.to_q [M][C]
  *   BC_CHAIN_OUT  x = attention output, res = residual stream, res2 = the block's input: to_out + res -> LayerNorm ->
  *                 GEGLU feed-forward + residual -> proj_out + res2 (+ r2: BlobNet residual [r2_bmod][rows_per_batch][C] where
- *                 pixel x = (row % out_w) >= r2_xmin) -> out0 [M][C] and gn_part [B][rows_per_batch/64][C][2] (per-channel sum,
- *                 sum of squares of the fp16 output per 64-row slab; NULL: none).  With out1 != NULL (BlobNet) the block
+ *                 pixel x = (row % out_w) >= r2_xmin) -> out0 [M][C]; gn_tot [B][C][BC_GN_TOT_WORDS]: the statistics totals the
+ *                 per-channel (sum, sum of squares) of the fp16 output rows are added to (NULL: none).  With out1 != NULL (BlobNet) the block
  *                 output also goes through the zero-conv: out1 = (W out0 + b) * alpha * alpha_dev[*alpha_idx (* bstride + image)].
  *   BC_CHAIN_OUT_FF + BC_CHAIN_OUT_TAIL  the same block end as two launches with the feed-forward's hidden chunks split over `nsplit`
  *                 workgroups per row block (a 64-row workgroup of the one-launch form does the whole feed-forward on one CU: at 640
  *                 channels that is 120 us of MFMA work; with few row blocks most of the chip idles meanwhile).  OUT_FF (x, res as for
  *                 OUT; grid = row blocks x nsplit): to_out + res -> LayerNorm -> its NCH / nsplit hidden chunks -> part[z][M][C] fp32
- *                 (slice 0 on top of the residual stream).  OUT_TAIL (res2, r2, out0, out1, gn_part as for OUT): sum of the nsplit
+ *                 (slice 0 on top of the residual stream).  OUT_TAIL (res2, r2, out0, out1, gn_tot as for OUT): sum of the nsplit
  *                 slices + ff.net.2 bias -> proj_out + res2 (+ r2) [-> zero-conv].  nsplit divides 4C / 128.
  * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
  * consumption order, for OUT_FF one set per slice; bc_rowchain_stream_frags(channels, kind, blobnet, nsplit) gives the length).  M % rows_per_batch == 0,
@@ -297,9 +306,10 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
 enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
 long long bc_rowchain_stream_frags(int channels, int kind, int blobnet, int nsplit);
-int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine, const bc_half* res,
+int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine,
+                const unsigned long long* gn_in, const float* gn_gamma, const float* gn_beta, int gn_groups, float gn_eps, const bc_half* res,
                 const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
-                const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, float* gn_part, float ln_eps,
+                const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, unsigned long long* gn_tot, float ln_eps,
                 float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit, bc_stream stream);
 
 /* Layout helpers at the nn.Module boundary (NCHW <-> token-major NHWC, fp32/fp16). */
@@ -352,7 +362,7 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
        BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
-       BC_OP_COUNT = 24 };
+       BC_OP_MEMSET_ZERO = 24, BC_OP_COUNT = 25 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

@@ -62,7 +62,6 @@ def test_halo_conv_plain(rec, tile, B, H, W, Cin, Cout, sk):
                                                        (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False),
                                                        (1, 8, 16, 640, 320, 160, 3, True)])
 def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, Cout, sk, silu, finalize, monkeypatch):
-    monkeypatch.setenv("BC_GN_FINALIZE_IN_KERNEL_BYTES", "1000000")          # (the in-kernel finalize is opt-in)
     """GroupNorm statistics from a standalone pass -> bc_gn_finalize -> affine applied in the halo staging (zero padding AFTER the
     activation), two channel-concatenated sources, and the whole ResBlock epilogue: bias + time-embedding row vector + residual +
     BlobNet right-half residual + GroupNorm partials of the output."""
@@ -92,8 +91,8 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
                        **kw)
         if finalize == "in_kernel":
             assert "gnfin" in rec.seg.meta[-1]["variant"], rec.seg.meta[-1]["variant"]
-        return out, rec.parts[out.data_ptr()]
-    out, (part, nslab) = run(rec, fn)
+        return out, rec.tots[out.data_ptr()]
+    out, part = run(rec, fn)
     xh = xcat.half().float()
     y = F.group_norm(xh, G, gamma, beta, 1e-5)
     y = F.silu(y) if silu else y
@@ -102,8 +101,9 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
     ref[..., xmin:] += R2.half().float()[..., xmin:]
     got = from_nhwc(out, B, H, W)
     close(got, ref, rtol=4e-3, what=f"fused GN conv {C1}+{C2}->{Cout}@{H}x{W} sk={sk}")
-    # GroupNorm partials of the fp16-rounded output: per-channel sums over all slabs
-    s = part.float().cpu().sum(1)                                             # [B][Cout][2]
+    # GroupNorm statistics of the fp16-rounded output: the totals every workgroup added its rows to
+    from blobctrl_amd.launch import decode_gn_tot
+    s = decode_gn_tot(part).float()                                           # [B][Cout][2]
     o = out.float().cpu().view(B, HW, Cout)
     assert torch.allclose(s[..., 0], o.sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
     assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)

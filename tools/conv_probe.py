@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
 from blobctrl_amd import _lib  # noqa: E402
-from blobctrl_amd.launch import Recorder  # noqa: E402
+from blobctrl_amd.launch import Recorder, encode_gn_tot  # noqa: E402
 from blobctrl_amd.weights import pack_conv_wreg  # noqa: E402
 from tools.tune_gemm import time_launch, time_launch_cold  # noqa: E402
 
@@ -43,7 +43,7 @@ for (B, H, W, C1, C2, Co) in SHAPES:
         if t is not None:
             ns = HW // 128
             f = t.float().view(B, ns, 128, c)
-            rec.parts[t.data_ptr()] = (torch.stack([f.sum(2), (f * f).sum(2)], -1).contiguous(), ns)
+            rec.tots[t.data_ptr()] = encode_gn_tot(torch.stack([f.sum((1, 2)), (f * f).sum((1, 2))], -1)).to(dev)
     res = {}
     seg = rec.begin("old")
     y = rec.groupnorm(x1, C1, x2, C2, B, HW, 32, 1e-5, gamma, beta, True)

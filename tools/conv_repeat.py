@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
 from blobctrl_amd import _lib  # noqa: E402
-from blobctrl_amd.launch import Recorder  # noqa: E402
+from blobctrl_amd.launch import Recorder, encode_gn_tot  # noqa: E402
 from blobctrl_amd.weights import pack_conv_wreg  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -33,7 +33,7 @@ for name, cfg in (("wreg", _lib.TILE_WREG), ("halo", _lib.TILE_HALO)):
             if t is not None:
                 ns = HW // 128
                 f = t.float().view(B, ns, 128, c)
-                rec.parts[t.data_ptr()] = (torch.stack([f.sum(2), (f * f).sum(2)], -1).contiguous(), ns)
+                rec.tots[t.data_ptr()] = encode_gn_tot(torch.stack([f.sum((1, 2)), (f * f).sum((1, 2))], -1)).to(t.device)
         seg = rec.begin(f"{name}{B}{H}{C1}{C2}")
         kw = dict(A2=x2, C1=C1, lda2=C2) if C2 else {}
         out = rec.gemm(A=x1, lda=C1, W=wm, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW,

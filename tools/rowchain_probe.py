@@ -15,7 +15,7 @@ from tools.tune_gemm import time_launch, time_launch_cold  # noqa: E402
 def build(fused, cross, B, H, W, zero, C=320):
     from blobctrl_amd import synth
     from blobctrl_amd.engine import Act, TrunkConfig, TrunkPlan
-    from blobctrl_amd.launch import Recorder
+    from blobctrl_amd.launch import Recorder, encode_gn_tot
     from blobctrl_amd.weights import PackedTrunk
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from tests.common import block_param_shapes
@@ -38,7 +38,7 @@ def build(fused, cross, B, H, W, zero, C=320):
     x = torch.randn(B, H * W, C, device=dev, dtype=torch.float16)
     ns = H * W // 128
     f = x.float().view(B, ns, 128, C)
-    rec.parts[x.data_ptr()] = (torch.stack([f.sum(2), (f * f).sum(2)], -1).contiguous(), ns)      # producer statistics, as in the step
+    rec.tots[x.data_ptr()] = encode_gn_tot(torch.stack([f.sum((1, 2)), (f * f).sum((1, 2))], -1)).to(x.device)      # producer statistics, as in the step
     if cross:
         plan.record_context(torch.randn(B * 77, 768, device=dev, dtype=torch.float16), 77)
     r2 = (torch.randn(1, H * W, C, device=dev) * 0.5).half() if cross else None
