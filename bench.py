@@ -51,20 +51,31 @@ def synth_inputs(h, w, T=77, ctx=768, feat=1024, batch=1):
                 blob=blob_dict_from_ellipse(ell, 8 * w, 8 * h))
 
 
-def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
-    """The CPU oracle (oracle/, kind 'port') timed on the host cores: FULL denoise steps of the same workload as the reference
-    executes them (BlobNet AND UNet at CFG batch 2, fp32, pipe:1043-1090).  The thread count is chosen on the measured step itself
-    (one step per candidate), it is recorded in `cores` next to the physical core count.  The 50-step edit and the C1 (20-step)
-    edit are extrapolations of the measured step time and are labelled as such."""
-    import statistics
+def cpu_baseline_worker(h, w, steps):
+    """`bench.py --cpu-baseline-worker`: the CPU oracle (oracle/, kind 'port') timed on the host cores in a process of its own, which
+    never touches the GPU.  FULL denoise steps of the same workload as the reference executes them (BlobNet AND UNet at CFG batch 2,
+    fp32, pipe:1043-1090).  The process pins itself to the cores of ONE socket before the first torch operation (the OpenMP pool
+    inherits the mask; on the two-socket hosts an unpinned 32-thread run measured 28 s per step, the real reference does 18.7 s on
+    8 cores), then takes one warm-up step and one step at each candidate thread count {8, 16, 32, 64} that the socket can hold; the
+    reported step time is the best candidate's.  The 50-step edit is an extrapolation of that step and is labelled as such."""
+    sock = socket0_cpus()
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    cpus = [c for c in sock if c in avail] or avail
+    pinned = False
+    try:
+        os.sched_setaffinity(0, cpus)
+        pinned = True
+    except (AttributeError, OSError):
+        pass
     from oracle import blob_splat
     from oracle.nets import NetConfig
     from oracle.pipeline import noise_pred_step
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    physical = physical_cores() or avail
+    usd, bsd = synth_weights()
+    inp = synth_inputs(h, w)
+    physical = physical_cores() or len(avail)
     ucfg = NetConfig(in_channels=5, cross_attention_dim=768)
     bcfg = NetConfig(in_channels=1029, cross_attention_dim=None)
     b = inp["blob"]
@@ -79,40 +90,86 @@ def cpu_baseline(usd, bsd, inp, h, w, steps, scheduler, timed_steps=3):
         """pipe:1031-1098: BlobNet on the CFG batch, right-square slices of its residuals into the UNet, crop + CFG."""
         return noise_pred_step(usd, ucfg, bsd, bcfg, inp["latents"], t, inp["prompt"], fg, bg, fg_s, bg_s, feats, 1.0, 7.5)
 
-    # The thread count is chosen on the MEASURED quantity (VERDICT r2): one full step at each candidate (32 threads - the round-1/2
-    # optimum on the 2 x 64-core hosts - and one thread per physical core, capped by the CPUs this process may use), then two more
-    # (`timed_steps` - candidates, at least one) at the faster one; the reported step time is the median of the steps taken at the chosen
-    # count.  One untimed warm-up step comes first.
-    cands = sorted({min(avail, 32), min(avail, max(1, physical))})
-    per_thread, all_times = {}, []
+    cands = sorted({min(len(cpus), n) for n in (8, 16, 32, 64)})
+    budget_s = float(os.environ.get("BC_CPU_BASELINE_BUDGET_S", "150"))
+    t_begin = time.perf_counter()
+    table = []
     with torch.no_grad():
-        torch.set_num_threads(cands[0])
+        torch.set_num_threads(cands[min(1, len(cands) - 1)])
         t0 = time.perf_counter()
         one_step(torch.tensor(999))                      # warm-up step (primitive creation, first touch): not used
-        all_times.append(("warm-up", time.perf_counter() - t0))
+        table.append(["warm-up", round(time.perf_counter() - t0, 3)])
+        per = {}
         for k, nt in enumerate(cands):
+            if per and time.perf_counter() - t_begin + min(per.values()) > budget_s:
+                break                                    # (the bench must finish in minutes: remaining candidates are skipped, and listed)
             torch.set_num_threads(nt)
             t0 = time.perf_counter()
-            one_step(torch.tensor(999 - 20 * k))
-            per_thread[nt] = [time.perf_counter() - t0]
-            all_times.append((nt, per_thread[nt][0]))
-        cores = min(per_thread, key=lambda n_: per_thread[n_][0])
-        torch.set_num_threads(cores)
-        for i in range(max(1, timed_steps - len(cands))):
-            t0 = time.perf_counter()
-            one_step(torch.tensor(959 - 20 * i))
-            per_thread[cores].append(time.perf_counter() - t0)
-            all_times.append((cores, per_thread[cores][-1]))
-    t_step = statistics.median(per_thread[cores])
-    sample = (f"{len(per_thread[cores])} full denoise steps (BlobNet + UNet at CFG batch 2 as the reference executes them, fp32, "
-              f"{8*h}x{8*w}) at the chosen thread count: median {t_step:.2f} s/step on {cores} threads; thread count chosen on the step "
-              f"itself, one step per candidate {{{', '.join(f'{k}: {v[0]:.1f} s' for k, v in sorted(per_thread.items()))}}} "
-              f"({physical} physical cores, {avail} CPUs visible); value = 1 / (s/step x {steps}) "
-              "is an EXTRAPOLATION of the measured step time to the whole edit (the scheduler update is negligible)")
-    return dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
-                host_cpus_visible=avail, physical_cores=physical, s_per_step=round(t_step, 3),
-                step_times_s=[[n_, round(x, 3)] for n_, x in all_times],
-                c1_20step_edit_s_extrapolated=round(t_step * 20, 1), edit_s_extrapolated=round(t_step * steps, 1)), None
+            one_step(torch.tensor(979 - 20 * k))
+            per[nt] = time.perf_counter() - t0
+            table.append([nt, round(per[nt], 3)])
+    cores = min(per, key=per.get)
+    t_step = per[cores]
+    skipped = [n for n in cands if n not in per]
+    sample = (f"one full denoise step (BlobNet + UNet at CFG batch 2 as the reference executes them, fp32, {8*h}x{8*w}) per candidate "
+              f"thread count after one warm-up step, in a separate process {'pinned to the ' + str(len(cpus)) + ' CPUs of socket 0' if pinned else 'not pinned'}: "
+              f"{{{', '.join(f'{k}: {v:.1f} s' for k, v in sorted(per.items()))}}}"
+              f"{' (skipped for the time budget: ' + str(skipped) + ')' if skipped else ''}; best {t_step:.2f} s/step on {cores} threads "
+              f"({physical} physical cores on the host); value = 1 / (s/step x {steps}) is an EXTRAPOLATION of the measured step time "
+              "to the whole edit (the scheduler update is negligible)")
+    print(json.dumps(dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
+                          host_cpus_visible=len(avail), physical_cores=physical, pinned_cpus=len(cpus) if pinned else None,
+                          s_per_step=round(t_step, 3), step_times_s=table,
+                          c1_20step_edit_s_extrapolated=round(t_step * 20, 1), edit_s_extrapolated=round(t_step * steps, 1))), flush=True)
+
+
+def socket0_cpus():
+    """Logical CPUs of physical package 0 (/proc/cpuinfo), hyper-thread siblings included; [] when unknown."""
+    try:
+        cpus, cur, phys = [], None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("processor"):
+                    cur = int(ln.split(":")[1])
+                elif ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if cur is not None and phys in (None, "0"):
+                        cpus.append(cur)
+                    cur = phys = None
+        return cpus
+    except OSError:
+        return []
+
+
+def start_cpu_baseline(h, w, steps):
+    """Start the CPU-baseline worker as a child of THIS process, which has made no GPU call yet (a GPU-initialised process must not be
+    the parent of an exec on this pool).  It runs beside the GPU benchmark on its own socket's cores; `collect_cpu_baseline` waits."""
+    import subprocess
+    import tempfile
+    out = tempfile.NamedTemporaryFile("w+", suffix=".json", delete=False)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")       # (the worker never sees a GPU)
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--res", str(8 * h), "--denoise-steps", str(steps)],
+                         stdout=out, stderr=subprocess.DEVNULL, env=env)
+    return p, out
+
+
+def collect_cpu_baseline(handle, timeout_s=600):
+    p, out = handle
+    try:
+        p.wait(timeout=timeout_s)
+    except Exception:
+        p.kill()
+        return dict(error=f"cpu-baseline worker did not finish within {timeout_s} s")
+    out.seek(0)
+    lines = [ln for ln in out.read().splitlines() if ln.startswith("{")]
+    try:
+        os.unlink(out.name)
+    except OSError:
+        pass
+    if p.returncode or not lines:
+        return dict(error=f"cpu-baseline worker failed (exit code {p.returncode})")
+    return json.loads(lines[-1])
 
 
 def physical_cores():
@@ -187,6 +244,8 @@ def other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, denoise_steps, scheduler):
                             latents=rb["latents"], blobnet_conditioning_scale=rb["strength"]))
     out["c3_batch8_mixed_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
     out["c3_batch8_mixed_images_per_s"] = round(8 / dt, 4)
+    fl3 = pipe.plan_for(8, 64, 64, 77, 768, denoise_steps, per_request=True).step_active.flops
+    out["c3_frac_of_peak"] = round(fl3 * denoise_steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)
     h5 = 96
     i5 = synth_inputs(h5, h5, batch=4)
     d5 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in i5.items()}
@@ -195,6 +254,8 @@ def other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, denoise_steps, scheduler):
                             latents=d5["latents"], blobnet_conditioning_scale=1.0))
     out["c5_768_batch4_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
     out["c5_768_batch4_images_per_s"] = round(4 / dt, 4)
+    fl5 = pipe.plan_for(4, h5, h5, 77, 768, denoise_steps).step_active.flops
+    out["c5_frac_of_peak"] = round(fl5 * denoise_steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)
     other = "unipc" if scheduler == "ddim" else "ddim"
     eng = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=other)
     i1 = synth_inputs(64, 64)
@@ -242,16 +303,12 @@ def csrc_sha():
     return hsh.hexdigest()[:12]
 
 
-def pmc_traffic(kernel_label, res, batch):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the timed process: the figure comes
-    from the committed rocprofv3 summary of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE passes, gfx950 correction 2*FETCH + WRITE).  It is reported ONLY when that summary was taken on exactly these
-    kernel sources (csrc hash) at the headline shape; otherwise `traffic` is null and `traffic_source` says why."""
+def _profile_doc(pattern, res, batch):
+    """The committed PMC summary (profiles/<round>_<pattern>) taken on exactly these kernel sources at the headline shape, or (None, why)."""
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_hbm_traffic.json")))      # by name (r1_, r2_, ...), never by mtime
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*" + pattern)))      # by name (r1_, r2_, ...), never by mtime
     if not files:
-        return None, "no profiles/*pmc_hbm_traffic.json"
+        return None, f"no profiles/*{pattern}"
     docs = []
     for fn in files:
         with open(fn) as f:
@@ -263,17 +320,42 @@ def pmc_traffic(kernel_label, res, batch):
         return None, f"{name} was measured at 512x512 batch 1, this run is {res}x{res} batch {batch}"
     if doc.get("csrc_sha") != csrc_sha():
         return None, f"{name} was measured on kernel sources {doc.get('csrc_sha', '(unrecorded)')}, this run is {csrc_sha()}"
-    m = re.match(r"(\w+)<([\d, ]+)", kernel_label)
-    key = kernel_label.split("<")[0]
-    hit = [r for r in doc["kernels"] if key in r["kernel"]]
-    if key == "attn_fwd_kernel" and m:
-        hit = [r for r in hit if f"attn_fwd_kernelILi{m.group(2).split(',')[0].strip()}E" in r["kernel"] or
-               f"attn_fwd_kernel<{m.group(2).split(',')[0].strip()}," in r["kernel"]]
-    n = sum(r["launches"] for r in hit)
+    return (name, doc), None
+
+
+def _rows_of(doc, rocprof_name):
+    """Rows of a PMC summary for ONE kernel instantiation, by the name rocprofv3 prints (e.g. `conv_wreg_kernel<2>`)."""
+    return [r for r in doc["kernels"] if rocprof_name + "(" in r["kernel"].replace("(anonymous namespace)::", "")]
+
+
+def pmc_traffic(rocprof_name, res, batch):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the timed process: the figure comes
+    from the committed rocprofv3 summary of this same command (tools/profile_round.sh: separate --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE passes, gfx950 correction 2*FETCH + WRITE).  It is reported ONLY when that summary was taken on exactly these
+    kernel sources (csrc hash) at the headline shape; otherwise `traffic` is null and `traffic_source` says why.  The average is over
+    exactly the launches of the instantiation the bench bucket holds (the bucket IS that instantiation)."""
+    hit, why = _profile_doc("pmc_hbm_traffic.json", res, batch)
+    if hit is None:
+        return None, why, None
+    name, doc = hit
+    rows = _rows_of(doc, rocprof_name)
+    n = sum(r["launches"] for r in rows)
     if not n:
-        return None, f"{name} has no row for {kernel_label}"
-    return int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in hit) / n), \
-        f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {doc['csrc_sha']}; 2*FETCH+WRITE)"
+        return None, f"{name} has no row for {rocprof_name}", None
+    steps_prof = doc.get("denoise_steps_profiled")
+    step_gb = round(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in doc["kernels"]) / steps_prof / 1e9, 2) if steps_prof else None
+    return int(sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / n), \
+        f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {doc['csrc_sha']}; 2*FETCH+WRITE)", step_gb
+
+
+def pmc_mfma_busy(rocprof_name, res, batch):
+    """MFMA-pipe busy fraction of the dominant kernel from the committed SQ-counter pass (same rules as pmc_traffic)."""
+    hit, why = _profile_doc("pmc_mfma_util_per_kernel.json", res, batch)
+    if hit is None:
+        return None
+    rows = _rows_of(hit[1], rocprof_name)
+    n = sum(r["launches"] for r in rows)
+    return round(sum(r["mfma_busy_frac"] * r["launches"] for r in rows) / n, 4) if n else None
 
 
 def roofline(pipe, plan, res=512, batch=1):
@@ -288,9 +370,10 @@ def roofline(pipe, plan, res=512, batch=1):
     # event between its main kernel and its reducer, so that every bucket below is ONE kernel, as rocprofv3 reports it
     timed = []
     for m, ms_main, ms_red in plan.step_active.run_timed_kernels(s):
-        timed.append((dict(m, variant=(m["variant"] or "").replace("+splitk_reduce", "")), ms_main))
+        # (a bucket = ONE kernel instantiation, named as rocprofv3 names it: the rows of profiles/*kernel_stats*.csv)
+        timed.append((dict(m, variant=m.get("rocprof") or (m["variant"] or "").replace("+splitk_reduce", "")), ms_main))
         if ms_red > 0:
-            timed.append((dict(kind="splitk_reduce", variant="splitk_reduce_kernel", flops=0, bytes=0, shape=m["shape"]), ms_red))
+            timed.append((dict(kind="splitk_reduce", variant="splitk_reduce_vec_kernel", flops=0, bytes=0, shape=m["shape"]), ms_red))
     pipe.stream.synchronize()
     by = {}
     for m, ms in timed:
@@ -339,13 +422,11 @@ def roofline(pipe, plan, res=512, batch=1):
     table = {k: dict(launches=v["n"], ms=round(v["ms"], 4), tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                      gbps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
              for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}
-    traffic, traffic_source = pmc_traffic(dom, res, batch)
-    # algorithmic HBM bytes per launch of the dominant kernel (operands once: activation + weights + fp16 result), to read `traffic` against
-    alg = []
-    for m, _ in timed:
-        if (m["variant"] or m["kind"]) == dom and m.get("shape") and len(m["shape"]) >= 4 and isinstance(m["shape"][1], int):
-            mode, M_, N_, K_ = m["shape"][:4]
-            alg.append(2 * (M_ * (K_ // 9 if mode in ("halo", "conv1", "conv2", "ups") else K_) + N_ * K_ + M_ * N_))
+    traffic, traffic_source, step_traffic_gb = pmc_traffic(dom, res, batch)
+    # algorithmic HBM bytes per launch of the dominant kernel (operands once: activation + weights + fp16 result), to read `traffic` against:
+    # over exactly the launches of the bucket (= the instantiation the PMC rows hold)
+    alg = [m["bytes"] for m, _ in timed if (m["variant"] or m["kind"]) == dom and m.get("bytes")]
+    step_alg_gb = round(sum(m.get("bytes", 0) for m, _ in timed) / 1e9, 2)
     # The same figure over the launches of that kernel whose grid fills the chip (>= one workgroup per CU).  The plan deliberately leaves
     # some passes half-filled (the other trunk's kernels run beside them: DESIGN 3.7); alone in this serial replay such a launch shows
     # half the throughput, which says nothing about the kernel.  `frac` above is over ALL its launches, as they are shipped.
@@ -353,7 +434,7 @@ def roofline(pipe, plan, res=512, batch=1):
     if dom.startswith("conv_wreg_kernel") or dom.startswith("conv_halo_kernel"):
         fl = fms = fn = 0
         for m, ms in timed:
-            if (m["variant"] or m["kind"]) == dom and m.get("shape") and len(m["shape"]) >= 5:
+            if (m["variant"] or m["kind"]).split("<")[0] == dom.split("<")[0] and m.get("shape") and len(m["shape"]) >= 5:
                 _, M_, N_, _, sk_ = m["shape"][:5]
                 if -(-M_ // 128) * (N_ // 160) * sk_ >= 256:
                     fl, fms, fn = fl + m["flops"], fms + ms, fn + 1
@@ -362,7 +443,8 @@ def roofline(pipe, plan, res=512, batch=1):
                              frac=round(fl / (fms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4))
     return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / MFMA_PEAK_TFLOPS, 4), full_grid_launches=full_grid, traffic=traffic, traffic_source=traffic_source,
-                algorithmic_bytes_per_launch=int(sum(alg) / len(alg)) if alg else None, launches_per_step=a["n"],
+                algorithmic_bytes_per_launch=int(sum(alg) / len(alg)) if alg else None, mfma_busy=pmc_mfma_busy(dom, res, batch),
+                step_traffic_gb=step_traffic_gb, step_algorithmic_gb=step_alg_gb, launches_per_step=a["n"],
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3), event_overhead_us=round(overhead_ms * 1e3, 2)), \
         dict(by_kernel=table, top_shapes=detail)
@@ -524,8 +606,11 @@ def main():
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE configs[3]: this many independent edit requests in total, sharded round-robin over the ranks "
                          "(dist.shard_requests) and run `--batch` at a time as per-request batches; 0 = `--steps` edits per rank")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_worker:                       # child of a bench run: CPU only (see start_cpu_baseline)
+        return cpu_baseline_worker(args.res // 8, args.res // 8, args.denoise_steps)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus, sys.argv[1:])          # never returns
     if os.environ.get("BC_BENCH_STUB"):
@@ -537,6 +622,9 @@ def main():
     from blobctrl_amd.weights import PackedTrunk
     import torch.distributed as tdist
 
+    cpu_handle = None
+    if "WORLD_SIZE" not in os.environ and args.gpus == 1 and not args.no_cpu_baseline and args.batch == 1 and not os.environ.get("BC_BENCH_STUB"):
+        cpu_handle = start_cpu_baseline(args.res // 8, args.res // 8, args.denoise_steps)      # (before the first GPU call of this process)
     rank, world, local = bdist.init_from_env(os.environ.get("BC_DIST_BACKEND"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
@@ -608,6 +696,11 @@ def main():
         ranks = [None] * world
         tdist.all_gather_object(ranks, ident)
     units = args.requests if args.requests else world * args.steps * args.batch
+    # every rank's copy of the broadcast weight arenas hashed on the device: rank r > 0 holds what rank 0 packed
+    wsha = [bdist.arena_hash(pw_u, pw_b)]
+    if world > 1:
+        wsha = [None] * world
+        tdist.all_gather_object(wsha, bdist.arena_hash(pw_u, pw_b))
 
     plan = pipe.plan_for(args.batch, h, w, 77, 768, args.denoise_steps, per_request=bool(args.requests))
     line = {
@@ -624,23 +717,36 @@ def main():
                    "denoise_step_ms": dt / (len(batches) if args.requests else args.steps) / args.denoise_steps * 1e3,
                    "algorithmic_tflop_per_edit": plan.step_active.flops * args.denoise_steps / 1e12 / args.batch,
                    "dist_backend": (tdist.get_backend() if world > 1 else None),
+                   "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and tdist.get_backend() == "nccl" else None),
+                   "nranks_seen": len(ranks), "weights_sha16": wsha,
                    "ranks": ranks, "distinct_devices": len({(r["local_device"], r["pci_bdf"]) for r in ranks}),
                    "weights_s": weights_s},
     }
+    # The headline numbers above are complete.  Everything below is optional detail: a failure there is recorded in the line, it must
+    # not lose the line.
+    def guarded(key, fn):
+        try:
+            return fn()
+        except Exception as e:                                              # noqa: BLE001
+            line.setdefault("errors", {})[key] = f"{type(e).__name__}: {e}"[:300]
+            return None
     if rank == 0 and not args.no_roofline:
-        rl, table = roofline(pipe, plan, args.res, args.batch)
-        line["roofline"] = rl
-        if args.table:
-            print(json.dumps(table, indent=1), file=sys.stderr)
+        r = guarded("roofline", lambda: roofline(pipe, plan, args.res, args.batch))
+        if r is not None:
+            line["roofline"] = r[0]
+            if args.table:
+                print(json.dumps(r[1], indent=1), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_configs and args.batch == 1 and not args.requests and args.res == 512:
-        line["configs"] = other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, args.denoise_steps, args.scheduler)
+        c = guarded("configs", lambda: other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, args.denoise_steps, args.scheduler))
+        if c is not None:
+            line["configs"] = c
     if rank == 0 and world == 1 and not args.no_e2e and args.batch == 1 and not args.requests:
-        e2e = end_to_end(pw_u, pw_b, ucfg, bcfg, dev, args.res, args.denoise_steps)
-        line["edit_ms_end_to_end"] = e2e["edit_ms_end_to_end"]
-        line["end_to_end"] = e2e
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == 1:
-        cb, _ = cpu_baseline(state["usd"], state["bsd"], inp, h, w, args.denoise_steps, args.scheduler)
-        line["cpu_baseline"] = cb
+        e2e = guarded("end_to_end", lambda: end_to_end(pw_u, pw_b, ucfg, bcfg, dev, args.res, args.denoise_steps))
+        if e2e is not None:
+            line["edit_ms_end_to_end"] = e2e["edit_ms_end_to_end"]
+            line["end_to_end"] = e2e
+    if cpu_handle is not None:
+        line["cpu_baseline"] = collect_cpu_baseline(cpu_handle)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

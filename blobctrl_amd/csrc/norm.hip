@@ -304,6 +304,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(h16* __restrict__ x, 
     }
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, long long n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = z;
+}
+
 }  // namespace
 
 extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, unsigned long long* tot, bc_stream stream_) {
@@ -327,8 +332,12 @@ extern "C" int bc_gn_finalize(const unsigned long long* tot1, int C1, const unsi
 }
 
 extern "C" int bc_memset_zero(void* ptr, long long bytes, bc_stream stream_) {
-    BC_CHECK_ARG(ptr && bytes > 0, "bc_memset_zero: bad args");
-    BC_CHECK_HIP(hipMemsetAsync(ptr, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream_)));
+    // an ordinary kernel (a kernel node when captured), 16-byte stores: the statistics tables are 16-byte aligned multiples of 16 bytes
+    BC_CHECK_ARG(ptr && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)ptr % 16) == 0, "bc_memset_zero: needs a 16-byte aligned pointer and size");
+    const long long n16 = bytes / 16;
+    const int blocks = (int)std::min<long long>((n16 + 255) / 256, 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), reinterpret_cast<uint4*>(ptr), n16);
+    BC_CHECK_LAUNCH();
     return 0;
 }
 

@@ -19,56 +19,14 @@
 #include <string>
 #include <vector>
 #include "bc_common.h"
+#include "plan_format.h"
 
 void bc_gemm_set_probe(hipEvent_t e);      // gemm.hip (timing probe between a split-K GEMM's main kernel and its reducer)
 bool bc_gemm_probe_hit();
 
+using namespace bcplan;                    // the record / buffer structures and the file parser: plan_format.h (HIP-free)
+
 namespace {
-
-// argument kinds of the recordable entry points (stream argument excluded): p = device pointer, i = int, f = float, l = long long
-const char* op_signature(int op) {
-    switch (op) {
-        case BC_OP_GN_STATS: return "piiip";
-        case BC_OP_GN_FINALIZE: return "pipiiiifppp";
-        case BC_OP_GN_APPLY_FUSED: return "pipippiiifppip";
-        case BC_OP_GN_APPLY: return "pipiiipip";
-        case BC_OP_LAYERNORM: return "piiippfpi";
-        case BC_OP_ATTENTION:
-        case BC_OP_ATTENTION_CAUSAL: return "ppppiiiiiiiiillllf";
-        case BC_OP_ASSEMBLE_INPUT: return "pipppiiiiiiip";
-        case BC_OP_TIMESTEP_EMBEDDING: return "ppfiip";
-        case BC_OP_TIMESTEP_EMBEDDING_TABLE: return "piiip";
-        case BC_OP_CFG_SCHEDULER_STEP: return "pppppfiiipi";
-        case BC_OP_EMBED_TOKENS: return "pppiiiip";
-        case BC_OP_SOFTMAX_ROWS: return "piii";
-        case BC_OP_PATCHIFY: return "piiiiip";
-        case BC_OP_ADD_CLS_POS: return "pppiiip";
-        case BC_OP_SILU: return "ppl";
-        case BC_OP_NCHW_TO_NHWC_F16: return "piiiiip";
-        case BC_OP_NHWC_TO_NCHW: return "piiiipi";
-        case BC_OP_GAUSSIAN_SAMPLE: return "ppiiifp";
-        case BC_OP_SIGNAL:
-        case BC_OP_WAIT: return "i";
-        case BC_OP_ROWCHAIN: return "iiiipppppifpppiiipppppipffppipi";
-        case BC_OP_ASSEMBLE_IM2COL: return "pippiiiiip";
-        case BC_OP_MEMSET_ZERO: return "pl";
-        default: return nullptr;
-    }
-}
-
-// byte offsets of the pointer fields of BcGemm (relocated on save / load)
-const size_t kGemmPtrFields[] = {
-    offsetof(BcGemm, A), offsetof(BcGemm, A2), offsetof(BcGemm, W), offsetof(BcGemm, bias), offsetof(BcGemm, rowvec),
-    offsetof(BcGemm, rowvec_idx), offsetof(BcGemm, colscale), offsetof(BcGemm, alpha_dev), offsetof(BcGemm, alpha_idx),
-    offsetof(BcGemm, R), offsetof(BcGemm, R2), offsetof(BcGemm, C), offsetof(BcGemm, gn_tot), offsetof(BcGemm, a_affine),
-    offsetof(BcGemm, a_tot1), offsetof(BcGemm, a_tot2), offsetof(BcGemm, a_gamma), offsetof(BcGemm, a_beta),
-    offsetof(BcGemm, ln_colsum), offsetof(BcGemm, C_t)};
-
-struct Rec {
-    int op = 0, sid = 0, enabled = 1;
-    std::vector<uint64_t> a;     // generic arguments (floats as their 32-bit pattern)
-    BcGemm g;                    // BC_OP_GEMM
-};
 
 struct EventSet {                // events of a timed replay: destroyed on every exit path
     std::vector<hipEvent_t> ev;
@@ -83,14 +41,6 @@ struct Seg {
     hipGraphExec_t graph = nullptr;
 };
 
-struct Buf {
-    std::string name;
-    uint64_t addr = 0;           // address the records were built against (device, or host when compiled without a GPU)
-    uint64_t bytes = 0;
-    uint64_t arena_off = 0;      // loader: offset inside the arena
-};
-
-constexpr int kMaxStreams = 8;
 
 }  // namespace
 
@@ -222,9 +172,6 @@ int get_streams(BcPlan* pl, const bc_stream* streams, int n, hipStream_t* out) {
     Seg& sg = (pl)->segs[(s)]
 
 // ---- file format helpers ----
-const uint32_t kMagic = 0x4E4C5042u;   // "BPLN"
-const uint32_t kVersion = 2;        // 2: BcGemm grew ln_colsum / C_t (round 4)
-
 struct Writer {
     FILE* f;
     bool ok = true;
@@ -233,15 +180,6 @@ struct Writer {
     void u64(uint64_t v) { raw(&v, 8); }
     void str(const std::string& s) { u32((uint32_t)s.size()); raw(s.data(), s.size()); }
 };
-struct Reader {
-    FILE* f;
-    bool ok = true;
-    void raw(void* p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
-    uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
-    uint64_t u64() { uint64_t v = 0; raw(&v, 8); return v; }
-    std::string str() { uint32_t n = u32(); std::string s(ok && n < (1u << 20) ? n : 0, '\0'); raw(&s[0], s.size()); return s; }
-};
-
 // pointer -> (buffer index, offset); null stays null (index -1)
 bool relocate_out(const std::vector<Buf>& bufs, uint64_t addr, int64_t& idx, uint64_t& off) {
     if (addr == 0) { idx = -1; off = 0; return true; }
@@ -514,98 +452,34 @@ extern "C" int bc_plan_load(const char* path, BcPlan** out) {
     BC_CHECK_ARG(path && out, "bc_plan_load: bad arguments");
     FILE* f = fopen(path, "rb");
     BC_CHECK_ARG(f != nullptr, "bc_plan_load: cannot open %s", path);
-    Reader rd{f};
-    if (fseek(f, 0, SEEK_END)) { fclose(f); bc_set_error("bc_plan_load(%s): seek failed", path); return 1; }
-    const uint64_t file_bytes = (uint64_t)ftell(f);
-    rewind(f);
-    constexpr uint64_t kMaxArena = 1ull << 40;       // 1 TiB: far above any real plan, far below overflow of the running sum
     BcPlan* pl = new BcPlan();
-    auto fail = [&](const char* why) { fclose(f); bc_plan_destroy(pl); bc_set_error("bc_plan_load(%s): %s", path, why); return 1; };
-    if (rd.u32() != kMagic) return fail("not a plan file");
-    if (rd.u32() != kVersion) return fail("unsupported plan version");
-    if (rd.u32() != sizeof(BcGemm)) return fail("BcGemm layout differs from this library build");
-    const uint32_t nb = rd.u32();
-    if (!rd.ok || nb > (1u << 20)) return fail("corrupt header");
-    // pass 1: sizes (data blobs are skipped), then one arena
-    std::vector<long> data_pos(nb, -1);
-    uint64_t total = 0;
-    pl->bufs.resize(nb);
-    for (uint32_t i = 0; i < nb; ++i) {
-        Buf& b = pl->bufs[i];
-        b.name = rd.str();
-        b.bytes = rd.u64();
-        if (!rd.ok || b.bytes > kMaxArena) return fail("corrupt buffer size");
-        b.arena_off = total;
-        total += (b.bytes + 255) & ~255ull;
-        if (total > kMaxArena) return fail("buffer table larger than any device");
-        if (rd.u32()) {
-            data_pos[i] = ftell(f);
-            if (data_pos[i] < 0 || (uint64_t)data_pos[i] + b.bytes > file_bytes) return fail("buffer data runs past the end of the file");
-            if (fseek(f, (long)b.bytes, SEEK_CUR)) return fail("truncated buffer data");
-        }
-        if (!rd.ok) return fail("truncated buffer table");
-    }
-    if (hipMalloc(&pl->arena, (size_t)std::max<uint64_t>(total, 256)) != hipSuccess) return fail("hipMalloc of the plan arena failed");
-    if (hipMemset(pl->arena, 0, (size_t)std::max<uint64_t>(total, 256)) != hipSuccess) return fail("hipMemset failed");
-    const long after_table = ftell(f);
-    std::vector<char> host;
-    for (uint32_t i = 0; i < nb; ++i) {
-        if (data_pos[i] < 0) continue;
-        host.resize((size_t)pl->bufs[i].bytes);
-        if (fseek(f, data_pos[i], SEEK_SET)) return fail("seek failed");
-        rd.raw(host.data(), host.size());
-        if (!rd.ok) return fail("truncated buffer data");
-        if (hipMemcpy(static_cast<char*>(pl->arena) + pl->bufs[i].arena_off, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess)
-            return fail("hipMemcpy failed");
-    }
-    if (fseek(f, after_table, SEEK_SET)) return fail("seek failed");
-    for (Buf& b : pl->bufs) b.addr = (uint64_t)(uintptr_t)(static_cast<char*>(pl->arena) + b.arena_off);
-    bool bad_ptr = false;
-    auto get_ptr = [&]() -> uint64_t {
-        const int64_t idx = (int64_t)rd.u64();
-        const uint64_t off = rd.u64();
-        if (idx < 0) return 0;
-        if ((uint64_t)idx >= pl->bufs.size() || off > pl->bufs[idx].bytes) { bad_ptr = true; return 0; }
-        return pl->bufs[idx].addr + off;
-    };
-    const uint32_t nev = rd.u32();
-    if (!rd.ok || nev > (1u << 20)) return fail("corrupt event count");
-    for (uint32_t i = 0; i < nev; ++i)
-        if (bc_plan_new_event(pl) < 0) return fail("event creation failed");
-    for (int s = 0; s < kMaxStreams; ++s) pl->slab[s] = reinterpret_cast<float*>(get_ptr());
-    const uint32_t nseg = rd.u32();
-    if (!rd.ok || nseg > (1u << 16)) return fail("corrupt segment count");
-    for (uint32_t si = 0; si < nseg; ++si) {
-        pl->segs.emplace_back();
-        Seg& sg = pl->segs.back();
-        sg.name = rd.str();
-        const uint32_t nr = rd.u32();
-        if (!rd.ok || nr > (1u << 22)) return fail("corrupt launch count");
-        sg.recs.resize(nr);
-        for (Rec& r : sg.recs) {
-            const uint32_t op = rd.u32(), sid = rd.u32(), enabled = rd.u32();
-            if (!rd.ok || sid >= (uint32_t)kMaxStreams) return fail("stream id out of range");
-            if (op != (uint32_t)BC_OP_GEMM && !op_signature((int)op)) return fail("unknown op code");
-            r.op = (int)op; r.sid = (int)sid; r.enabled = enabled ? 1 : 0;
-            if (r.op == BC_OP_GEMM) {
-                rd.raw(&r.g, sizeof(r.g));
-                for (size_t fo : kGemmPtrFields) {
-                    const uint64_t addr = get_ptr();
-                    memcpy(reinterpret_cast<char*>(&r.g) + fo, &addr, 8);
-                }
-                r.g.slab = nullptr;
-            } else {
-                const char* sig = op_signature(r.op);
-                const uint32_t na = rd.u32();
-                if (!sig || strlen(sig) != na) return fail("unknown op or argument count");
-                r.a.resize(na);
-                for (uint32_t k = 0; k < na; ++k) r.a[k] = sig[k] == 'p' ? get_ptr() : rd.u64();
-            }
-            if (!rd.ok) return fail("truncated launch record");
-        }
-    }
+    PlanImage img;
+    // the format and every check on it live in plan_format.h (also built as plain host C++ under the sanitizers)
+    const std::string why = parse_plan(
+        f, img,
+        [&](uint64_t bytes) -> uint64_t {
+            if (hipMalloc(&pl->arena, (size_t)bytes) != hipSuccess) { pl->arena = nullptr; return 0; }
+            if (hipMemset(pl->arena, 0, (size_t)bytes) != hipSuccess) return 0;
+            return (uint64_t)(uintptr_t)pl->arena;
+        },
+        [&](uint64_t off, const char* host, size_t n) {
+            return hipMemcpy(static_cast<char*>(pl->arena) + off, host, n, hipMemcpyHostToDevice) == hipSuccess;
+        });
     fclose(f);
-    if (bad_ptr) { bc_plan_destroy(pl); bc_set_error("bc_plan_load(%s): pointer outside its buffer", path); return 1; }
+    if (!why.empty()) {
+        bc_plan_destroy(pl);
+        bc_set_error("bc_plan_load(%s): %s", path, why.c_str());
+        return 1;
+    }
+    pl->bufs = std::move(img.bufs);
+    for (uint32_t i = 0; i < img.nevents; ++i)
+        if (bc_plan_new_event(pl) < 0) { bc_plan_destroy(pl); bc_set_error("bc_plan_load(%s): event creation failed", path); return 1; }
+    for (int s = 0; s < kMaxStreams; ++s) pl->slab[s] = reinterpret_cast<float*>(img.slab[s]);
+    for (SegImage& si : img.segs) {
+        pl->segs.emplace_back();
+        pl->segs.back().name = std::move(si.name);
+        pl->segs.back().recs = std::move(si.recs);
+    }
     *out = pl;
     return 0;
 }

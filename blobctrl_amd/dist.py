@@ -66,3 +66,20 @@ def barrier_max_seconds(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def arena_hash(*trunks: PackedTrunk) -> str:
+    """16 hex digits over the weight arenas of the given trunks as this rank holds them (two wrapping 64-bit sums - of the words and of
+    the words times their position modulo a prime - computed on the device in chunks): equal on every rank after `broadcast_packed`."""
+    s1 = s2 = 0
+    mask = (1 << 64) - 1
+    for pw in trunks:
+        for arena in (pw.h_arena, pw.f_arena):
+            raw = arena.view(torch.int16) if arena.dtype == torch.float16 else arena.view(torch.int32)
+            step = 1 << 24
+            for o in range(0, raw.numel(), step):
+                x = raw[o:o + step].to(torch.int64)
+                pos = (torch.arange(x.numel(), device=x.device, dtype=torch.int64) + o) % 65521 + 1
+                s1 = (s1 + int(x.sum().item())) & mask
+                s2 = (s2 + int((x * pos).sum().item())) & mask
+    return f"{s1 & 0xFFFFFFFF:08x}{s2 & 0xFFFFFFFF:08x}"

@@ -236,7 +236,7 @@ class Recorder:
         self._add_op(_lib.OP_WAIT, "i", (ev,), "event_wait")
         self.seg.meta[-1]["ev"] = ev
 
-    def _add_op(self, op, sig, args, kind, flops=0, variant="", shape=None, bytes_=0):
+    def _add_op(self, op, sig, args, kind, flops=0, variant="", shape=None, bytes_=0, rocprof=None):
         assert len(sig) == len(args), (op, sig, args)
         words = (C.c_uint64 * max(1, len(args)))()
         for k, (c, v) in enumerate(zip(sig, args)):
@@ -249,13 +249,14 @@ class Recorder:
         idx = self.lib.bc_plan_add_op(self.plan, self.seg.id, self.sid, op, words, len(args))
         if idx < 0 or idx != len(self.seg.meta):
             _lib.check(1, f"bc_plan_add_op({kind})")
-        self._push(kind, flops, variant, shape, bytes_)
+        self._push(kind, flops, variant, shape, bytes_, rocprof)
 
-    def _push(self, kind, flops=0, variant="", shape=None, bytes_=0):
+    def _push(self, kind, flops=0, variant="", shape=None, bytes_=0, rocprof=None):
         self.seg.flops += flops
         self.seg.kinds[kind] = self.seg.kinds.get(kind, 0) + 1
-        # bytes_ = algorithmic HBM bytes of an HBM-bound launch (each activation read once + written once, fp16)
-        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape, bytes=bytes_, sid=self.sid))
+        # bytes_ = algorithmic HBM bytes of the launch (operands once: each activation / weight read once + the result written once)
+        # rocprof = the kernel's name as rocprofv3 prints it (template instantiation): ties bench.py's buckets to profiles/*.csv
+        self.seg.meta.append(dict(kind=kind, flops=flops, variant=variant, shape=shape, bytes=bytes_, sid=self.sid, rocprof=rocprof or variant))
 
     def capture_loop(self, segments, stream, side=None, extra=()):
         """ONE hipGraph for a whole sequence of segments (e.g. prologue + the N denoise steps); returns the graph handle for
@@ -469,7 +470,22 @@ class Recorder:
         variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "conv_wreg_kernel<" if cfg == _lib.TILE_WREG else
                    "gemm_wreg_kernel<" if cfg in _lib.GW_TILES else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
-        self._push(kind, 2 * M * N * K, variant, (mode, M, N, K, sk))
+        # the instantiation rocprofv3 reports for this launch (csrc/*.hip launchers)
+        FAST = {1: "256, 128, 4, 2, 3", 2: "128, 128, 2, 2, 3", 3: "128, 128, 2, 2, 2", 4: "256, 64, 4, 1, 2", 5: "256, 64, 4, 1, 3",
+                6: "128, 64, 2, 2, 3", 7: "64, 64, 2, 2, 4"}
+        if cfg in (_lib.TILE_HALO, _lib.TILE_WREG):
+            rp = ("conv_wreg_kernel" if cfg == _lib.TILE_WREG else "conv_halo_kernel") + f"<{2 if g.a_tot1 else 1 if g.a_affine else 0}>"
+        elif cfg in _lib.GW_TILES:
+            rp = f"gemm_wreg_kernel<{_lib.GW_TILES[cfg]}, {10 if _lib.GW_TILES[cfg] == 5 else 20}>"
+        elif fast:
+            ups_ = bool(conv) and (conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])) != (conv["Hin"], conv["Win"])
+            rp = f"gemm_fast_kernel<{FAST[cfg]}, {'true' if conv else 'false'}, {'true' if ups_ else 'false'}>"
+        else:
+            rp = "gemm_kernel<" + ("256, 64, 4, 1" if bn == 64 else "128, 128, 2, 2") + ">"
+        # algorithmic HBM bytes: activation (a convolution reads each input pixel once), weights and the result once
+        a_elems = (M // (conv["Hout"] * conv["Wout"])) * conv["Hin"] * conv["Win"] * conv["Cin"] if conv else M * K
+        alg_bytes = 2 * (a_elems + N * K + M * n_out) + (2 * M * n_out if R is not None else 0)
+        self._push(kind, 2 * M * N * K, variant, (mode, M, N, K, sk), alg_bytes, rp)
         return out
 
     # ------------------------------------------------------------------ norms
@@ -549,7 +565,7 @@ class Recorder:
         self._op("bc_attention_causal" if causal else "bc_attention",
                  (Q.data_ptr() + q_off * 2, K.data_ptr() + k_off * 2, Vt, out, B, heads, d, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs,
                   obs, scale), "attention", flops=4 * B * heads * Nq * Nkv * d, variant=f"attn_fwd_kernel<{d}>",
-                 shape=(B, heads, d, Nq, Nkv))
+                 shape=(B, heads, d, Nq, Nkv), bytes_=2 * B * heads * d * (2 * Nq + 2 * Nkv))
         return out
 
     # ------------------------------------------------------------------ row-chain (fused transformer-block glue, csrc/rowchain.hip)
@@ -571,7 +587,8 @@ class Recorder:
                                  ldvt, gn_tot, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride, part, nsplit), "rowchain",
                  flops=2 * M * Cc * Cc * mult,
                  variant=f"rowchain_kernel<{name}{',zero' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else ''}>",
-                 shape=("rowchain_" + name, M, Cc, mult * Cc))
+                 shape=("rowchain_" + name, M, Cc, mult * Cc), bytes_=2 * (mult * Cc * Cc + 2 * M * Cc),
+                 rocprof=f"rowchain_kernel<{Cc}, {kind}, {'true' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else 'false'}>")
         return out0
 
     # ------------------------------------------------------------------ glue

@@ -154,7 +154,10 @@ class _TrunkModule(torch.nn.Module):
 
     @property
     def dtype(self):
-        return torch.float16
+        """fp32 while the module still holds its host state dict and has not been packed (a freshly loaded checkpoint: the script's
+        conv_in surgery `Conv2d(..., dtype=unet.dtype)` then stays in fp32 like the reference's, inf:233-249); fp16 - the compute
+        dtype of the packed layouts - once packed."""
+        return torch.float32 if (self._sd is not None and self._packed is None) else torch.float16
 
     def to(self, *a, **k):
         return self
@@ -219,6 +222,15 @@ class BlobNetModel(_TrunkModule):
         B, C, H, W = sample.shape
         if C != self.trunk_config.in_channels:
             raise ValueError(f"expected {self.trunk_config.in_channels} input channels, got {C}")
+        # through the dispatcher (torch.ops.blobctrl.blobnet_forward, ops.py): profilers and fake-tensor tracing see the call
+        from . import ops
+        outs = torch.ops.blobctrl.blobnet_forward(sample, float(timestep), conditioning_scale, ops.register(self))
+        nd = len(ops.blobnet_output_shapes(self.trunk_config, B, H, W)[0])
+        return list(outs[:nd]), outs[nd], list(outs[nd + 1:])
+
+    def _forward_impl(self, sample: torch.Tensor, timestep: float, conditioning_scale: float):
+        """Body of torch.ops.blobctrl.blobnet_forward: one graph replay of the recorded trunk."""
+        B, C, H, W = sample.shape
         P = self._plan(B, H, W)
         P.x_in.copy_(self._to_nhwc(P.rec, sample, P.x_in.shape[-1]))
         P.t.fill_(float(timestep))
@@ -264,13 +276,16 @@ class UNet2DConditionModel(_TrunkModule):
 
     def __setattr__(self, name, value):
         if name == "conv_in" and isinstance(value, torch.nn.Module):
+            if self._sd is None:
+                raise _lib.BlobCtrlHipError("this UNet was built from packed weights: conv_in is not editable")
             w = value.weight.detach().float().cpu()
             if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] != self._sd["conv_in.weight"].shape[0]:
                 raise ValueError(f"conv_in must be a 3x3 convolution with {self._sd['conv_in.weight'].shape[0]} output channels")
             self._sd["conv_in.weight"] = w.clone()
             if value.bias is not None:
                 self._sd["conv_in.bias"] = value.bias.detach().float().cpu().clone()
-            self.trunk_config.in_channels = w.shape[1]
+            import dataclasses
+            self.trunk_config = dataclasses.replace(self.trunk_config, in_channels=w.shape[1])     # (the caller's config object is not touched)
             self._make_config()
             self._invalidate()
             return
@@ -346,6 +361,21 @@ class UNet2DConditionModel(_TrunkModule):
             raise ValueError(f"expected {self.trunk_config.in_channels} input channels, got {C}")
         is_blobnet = (down_block_add_samples is not None and mid_block_add_sample is not None
                       and up_block_add_samples is not None)                        # unet_2d_condition.py:1200
+        # through the dispatcher (torch.ops.blobctrl.unet_forward, ops.py)
+        from . import ops
+        eps = torch.ops.blobctrl.unet_forward(sample, float(timestep), encoder_hidden_states,
+                                              list(down_block_add_samples) if is_blobnet else [], mid_block_add_sample if is_blobnet else None,
+                                              list(up_block_add_samples) if is_blobnet else [], ops.register(self))
+        if is_blobnet:                                   # the reference consumes the two lists with pop(0) (:1217, 1230, 1313)
+            del down_block_add_samples[:]
+            del up_block_add_samples[:]
+        dt = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
+        return (eps.to(dt),)
+
+    def _forward_impl(self, sample, timestep, encoder_hidden_states, down_block_add_samples, mid_block_add_sample, up_block_add_samples):
+        """Body of torch.ops.blobctrl.unet_forward: eps [B][4][H][W] fp32."""
+        B, C, H, W = sample.shape
+        is_blobnet = mid_block_add_sample is not None
         T, Dc = encoder_hidden_states.shape[1:]
         P = self._plan(B, H, W, T, Dc, is_blobnet)
         P.x_in.copy_(self._to_nhwc(P.rec, sample, P.x_in.shape[-1]))
@@ -361,8 +391,7 @@ class UNet2DConditionModel(_TrunkModule):
             for buf, s in zip(P.residuals.up, su):
                 self._fill_residual(P, buf, up_block_add_samples.pop(0), s)        # (:1313)
         run_graphed(P.seg, self.device)
-        dt = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float32
         out = torch.empty(B, self.trunk_config.out_channels, H, W, dtype=torch.float32, device=self.device)
         out.copy_(P.eps.view(B, H, W, self.trunk_config.out_channels).permute(0, 3, 1, 2))
-        return (out.to(dt),)
+        return out
 

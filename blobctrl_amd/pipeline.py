@@ -492,7 +492,22 @@ class BlobCtrlEngine:
             torch.cuda.synchronize(self.device)
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
-    __call__ = denoise
+    @torch.no_grad()
+    def __call__(self, prompt_embeds, fg_image_latents=None, bg_image_latents=None, gs_score=None, dino_feats=None, **kw):
+        """`denoise(...)`; a plain tensor-level edit (explicit start latents, latent output, no callbacks / traces / images) goes through
+        the dispatcher as torch.ops.blobctrl.denoise (ops.py), everything else calls `denoise` directly."""
+        plain = {"num_inference_steps", "guidance_scale", "latents", "blobnet_conditioning_scale", "blobnet_control_guidance_start",
+                 "blobnet_control_guidance_end"}
+        if (set(kw) <= plain and kw.get("latents") is not None and fg_image_latents is not None and bg_image_latents is not None
+                and gs_score is not None and dino_feats is not None and kw.get("guidance_scale", 7.5) > 1.0):
+            from . import ops
+            sc = kw.get("blobnet_conditioning_scale", 1.0)
+            return torch.ops.blobctrl.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, kw["latents"],
+                                              int(kw.get("num_inference_steps", 50)), float(kw.get("guidance_scale", 7.5)),
+                                              [float(v) for v in sc] if isinstance(sc, (list, tuple)) else [float(sc)],
+                                              float(kw.get("blobnet_control_guidance_start", 0.0)),
+                                              float(kw.get("blobnet_control_guidance_end", 1.0)), ops.register(self))
+        return self.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, **kw)
 
     def compile_plan(self, path, B, h, w, T, ctx_dim, num_inference_steps, guidance_scale=7.5, blobnet_conditioning_scale=1.0,
                      blobnet_control_guidance_start=0.0, blobnet_control_guidance_end=1.0):
@@ -610,8 +625,12 @@ class StableDiffusionBlobNetPipeline:
         """The captured-plan loop engine over the CURRENT packed weights of `unet` / `blobnet`: built on first use, re-pointed (plans
         dropped) whenever a module's host weights changed (LoRA loaded / unloaded, conv_in surgery)."""
         versions = (self.unet._version, self.blobnet._version)
+        if self._scheduler.kind is None:
+            # the PNDM configuration holder a checkpoint directory ships (inf:276 replaces it): no loop engine behind it
+            raise NotImplementedError(f"{type(self._scheduler).__name__} is a configuration holder here: assign a UniPCMultistepScheduler / "
+                                      "DDIMScheduler (e.g. UniPCMultistepScheduler.from_config(pipe.scheduler.config)) before running the loop")
         if self._engine is None:
-            kind = self._scheduler.kind or "unipc"
+            kind = self._scheduler.kind
             self._engine = BlobCtrlEngine(self.unet.weights, self.blobnet.weights, self.unet.trunk_config, self.blobnet.trunk_config,
                                           device=str(self.unet.device), scheduler=kind, use_graphs=self._use_graphs, vae=self.vae,
                                           text_encoder=self.text_encoder)

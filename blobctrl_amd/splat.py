@@ -58,13 +58,20 @@ def splat_features(xs, ys, covs, sizes, score_size=None, return_d_score=False, d
     dev = torch.device(device)
     if dev.type != "cuda":
         raise _lib.BlobCtrlHipError("splat_features runs on MI355X only; there is no CPU fallback")
+    prm = torch.zeros(n, 8, dtype=torch.float64)
+    prm[:, 0], prm[:, 1] = xs, ys
+    prm[:, 2:6] = covs.reshape(n, 4)
+    prm[:, 6] = sizes
+    from . import ops  # noqa: F401  (registers torch.ops.blobctrl.*)
+    return torch.ops.blobctrl.splat_scores(prm, h, w, dev.index if dev.index is not None else 0)
+
+
+def _splat_scores_impl(params: torch.Tensor, h: int, w: int, dev: torch.device) -> torch.Tensor:
+    """Body of torch.ops.blobctrl.splat_scores: one bc_splat_scores launch (fp64) on `dev`."""
     lib = _lib.load()
-    prm = (C.c_double * (8 * n))()
-    for i in range(n):
-        prm[8 * i + 0], prm[8 * i + 1] = float(xs[i]), float(ys[i])
-        prm[8 * i + 2], prm[8 * i + 3] = float(covs[i, 0, 0]), float(covs[i, 0, 1])
-        prm[8 * i + 4], prm[8 * i + 5] = float(covs[i, 1, 0]), float(covs[i, 1, 1])
-        prm[8 * i + 6] = float(sizes[i])
+    p = params.detach().to("cpu", torch.float64).contiguous()
+    n = p.shape[0]
+    prm = (C.c_double * (8 * n))(*p.reshape(-1).tolist())
     out = torch.empty(n, 2, h, w, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.bc_splat_scores(prm, n, h, w, out.data_ptr(), torch.cuda.current_stream().cuda_stream),

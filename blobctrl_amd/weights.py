@@ -258,8 +258,19 @@ class PackedTrunk:
         self._view()
         return self
 
+    def derived_nbytes(self):
+        """Bytes of the fragment streams made on first use BESIDE the arenas (conv_wreg / gemm_wreg / row-chain streams: re-ordered
+        copies of matrices the arenas also hold in row-major form for the kernels that take that form - other batch sizes, canvases
+        the halo kernels do not cover, the diagnostic switches).  Not broadcast: every rank derives its own."""
+        n = sum(t.numel() * t.element_size() for k, t in self.h.items() if k.endswith("_wreg"))
+        for cache in (self.__dict__.get("_gw", {}), self.__dict__.get("_rowchain", {})):
+            for v in cache.values():
+                n += sum(t.numel() * t.element_size() for t in v if torch.is_tensor(t))
+        return n
+
     def nbytes(self):
-        return self.h_arena.numel() * 2 + self.f_arena.numel() * 4
+        """Device bytes of this trunk: the two arenas plus the derived fragment streams made so far."""
+        return self.h_arena.numel() * 2 + self.f_arena.numel() * 4 + self.derived_nbytes()
 
 
 # ---------------------------------------------------------------------------------------------------------------- row-chain streams

@@ -185,7 +185,8 @@ int bc_gn_apply(const bc_half* x1, int C1, const bc_half* x2, int C2, int B, int
 int bc_gn_apply_fused(const unsigned long long* tot1, int C1, const unsigned long long* tot2, int C2,
                       const bc_half* x1, const bc_half* x2, int B, int HW, int G, float eps, const float* gamma,
                       const float* beta, int silu, bc_half* y, bc_stream stream);
-/* hipMemsetAsync(ptr, 0, bytes) on the caller's stream (graph-capturable): zeroes the statistics totals at the head of a segment. */
+/* Zero `bytes` bytes at `ptr` (both multiples of 16) with a kernel on the caller's stream (a kernel node when captured): zeroes the
+ * statistics totals at the head of a segment. */
 int bc_memset_zero(void* ptr, long long bytes, bc_stream stream);
 
 /* Row softmax in place on fp16 [rows][cols] (fp32 maths): the single-head, head_dim-512 attention of the VAE mid block is run

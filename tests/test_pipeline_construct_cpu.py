@@ -23,7 +23,8 @@ def construct_pipeline(paths, device, weight_dtype=torch.float16):
     with torch.no_grad():
         initial_input_channels = unet.config.in_channels
         new_conv_in = torch.nn.Conv2d(initial_input_channels + 1, unet.conv_in.out_channels, kernel_size=3, stride=1, padding=1,
-                                      bias=unet.conv_in.bias is not None)
+                                      bias=unet.conv_in.bias is not None, dtype=unet.dtype, device=unet.device)
+        assert new_conv_in.weight.dtype == torch.float32        # (the surgery happens in the checkpoint's fp32, as in the reference)
         new_conv_in.weight.zero_()
         new_conv_in.weight[:, :initial_input_channels].copy_(unet.conv_in.weight)
         if unet.conv_in.bias is not None:
