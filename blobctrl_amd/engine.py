@@ -225,9 +225,11 @@ class TrunkPlan:
             gnkw = dict(affine=rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"]))
         else:                                              # the GroupNorm finalize runs in the IN launch's prologue, from the statistics totals
             gnkw = dict(gn_in=(rec.gn_sources(x.t, Cc, None, 0, B, HW)[0], pw.f[p + "norm.weight"], pw.f[p + "norm.bias"], self.G, 1e-6))
-        h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
+        # (the block's head on the column-tiled gemm_wreg projections - all CUs - instead of one 64-row workgroup per row block was
+        #  measured at the UNet's 640-channel level: 9.25 vs 9.13 ms per step, slower - the 64-CU launch leaves the chip to BlobNet)
+        h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
         w, v = packed(_lib.CHAIN_IN)
         rec.rowchain(_lib.CHAIN_IN, Cc, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, **gnkw)
         a = rec.empty(M, Cc)

@@ -498,10 +498,11 @@ class BlobCtrlEngine:
         the dispatcher as torch.ops.blobctrl.denoise (ops.py), everything else calls `denoise` directly."""
         plain = {"num_inference_steps", "guidance_scale", "latents", "blobnet_conditioning_scale", "blobnet_control_guidance_start",
                  "blobnet_control_guidance_end"}
+        sc = kw.get("blobnet_conditioning_scale", 1.0)
+        sc_ok = isinstance(sc, float) or (isinstance(sc, (list, tuple)) and len(sc) > 0 and all(isinstance(v, float) for v in sc))
         if (set(kw) <= plain and kw.get("latents") is not None and fg_image_latents is not None and bg_image_latents is not None
-                and gs_score is not None and dino_feats is not None and kw.get("guidance_scale", 7.5) > 1.0):
+                and gs_score is not None and dino_feats is not None and kw.get("guidance_scale", 7.5) > 1.0 and sc_ok):   # (else: denoise raises)
             from . import ops
-            sc = kw.get("blobnet_conditioning_scale", 1.0)
             return torch.ops.blobctrl.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, kw["latents"],
                                               int(kw.get("num_inference_steps", 50)), float(kw.get("guidance_scale", 7.5)),
                                               [float(v) for v in sc] if isinstance(sc, (list, tuple)) else [float(sc)],

@@ -20,10 +20,10 @@ def test_opcheck_and_dispatch_of_the_module_ops():
     xb, xu, ctx = g(1, B, bcfg.in_channels, H, W).cuda(), g(2, B, ucfg.in_channels, H, W).cuda(), g(3, B, 7, TINY["ctx"]).cuda()
     hb, hu = ops.register(blobnet), ops.register(unet)
     checks = ("test_schema", "test_faketensor")
+    sq = lambda t: t[..., t.shape[-1] - t.shape[-2]:].contiguous()          # the right-hand square the pipeline passes on (pipe:1085-1087)
     torch.library.opcheck(torch.ops.blobctrl.blobnet_forward, (xb, 981.0, 0.8, hb), test_utils=checks)
     outs = torch.ops.blobctrl.blobnet_forward(xb, 981.0, 0.8, hb)
-    torch.library.opcheck(torch.ops.blobctrl.unet_forward, (xu, 981.0, ctx, [o[..., W - H:].contiguous() for o in outs[:12]],
-                                                             outs[12][..., W - H:].contiguous(), [o[..., W - H:].contiguous() for o in outs[13:]], hu),
+    torch.library.opcheck(torch.ops.blobctrl.unet_forward, (xu, 981.0, ctx, [sq(o) for o in outs[:12]], sq(outs[12]), [sq(o) for o in outs[13:]], hu),
                           test_utils=checks)
     torch.library.opcheck(torch.ops.blobctrl.splat_scores, (torch.tensor([[0.4, 0.6, 0.01, 0.002, 0.002, 0.02, 1.0, 0.0]], dtype=torch.float64), 8, 16, 0),
                           test_utils=checks)
@@ -37,11 +37,10 @@ def test_opcheck_and_dispatch_of_the_module_ops():
             return func(*args, **(kwargs or {}))
     with Spy():
         down, mid, up = blobnet(xb, 981.0, conditioning_scale=0.8)
-        dl, ul = [d[..., W - H:].contiguous() for d in down], [u[..., W - H:].contiguous() for u in up]
-        eps = unet(xu, 981.0, ctx, down_block_add_samples=dl, mid_block_add_sample=mid[..., W - H:].contiguous(), up_block_add_samples=ul)[0]
+        dl, ul = [sq(d) for d in down], [sq(u) for u in up]
+        eps = unet(xu, 981.0, ctx, down_block_add_samples=dl, mid_block_add_sample=sq(mid), up_block_add_samples=ul)[0]
     assert seen == ["blobctrl.blobnet_forward.default", "blobctrl.unet_forward.default"] and dl == [] and ul == []      # lists consumed
-    ref = unet._forward_impl(xu, 981.0, ctx, [d[..., W - H:].contiguous() for d in down], mid[..., W - H:].contiguous(),
-                             [u[..., W - H:].contiguous() for u in up])
+    ref = unet._forward_impl(xu, 981.0, ctx, [sq(d) for d in down], sq(mid), [sq(u) for u in up])
     assert torch.equal(eps, ref)
     assert all(torch.equal(a, b) for a, b in zip(list(down) + [mid] + list(up), outs))
 
