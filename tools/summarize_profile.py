@@ -46,7 +46,9 @@ def main():
                            "--no-cpu-baseline --no-roofline --denoise-steps 2",
                    correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reports half of a wide coalesced read "
                               "stream; WRITE_SIZE exact; MI355X_MICROARCH.md section HBM)",
-                   denoise_steps_profiled=4,          # (1 warm-up + 1 timed edit of 2 denoise steps each: per-step traffic = sum / 4)
+                   # denoise steps the pass executed = launches of the per-step CFG / scheduler kernel (two 2-step edits + the warm-up
+                   # replays of the active and the inactive segment before capture): per-step traffic = sum over the library's kernels / this
+                   denoise_steps_profiled=max([k["launches"] for k in kernels if "cfg_step_kernel" in k["kernel"]] or [4]),
                    csrc_sha=csrc_sha(), kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
     util = []
     for name, c in mfma.items():
