@@ -327,7 +327,12 @@ class TrunkPlan:
             h = proj(a, bp + "attn2.to_out.0", Cc, Cc, G128, R=h, ldr=Cc, kind="attn_out")
         # --- GEGLU feed-forward: LayerNorm3 folded into ff.net.0; ff.net.2 (K = 4C) stays on the LDS-DMA tiles with split-K
         g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G320 if M >= 512 else G256, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
-        h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
+        if not os.environ.get("BC_NO_GW_FF2"):
+            # ff.net.2 (K = 4C) unsplit on gemm_wreg: the same step time as the LDS-DMA tiles with split-K 3 (9.42 vs 9.42 ms, same box,
+            # two rounds), without their 15.7 MB of fp32 slabs and the reducer launch
+            h = proj(g, bp + "ff.net.2", Cc, 4 * Cc, G128, R=h, ldr=Cc, kind="ff")
+        else:
+            h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
         out = proj(h, p + "proj_out", Cc, Cc, G128, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True, **self._r2(r2, x.H, x.W))
         return Act(out, Cc, x.H, x.W), None
 
@@ -480,6 +485,7 @@ class TrunkPlan:
                 if cfg.is_blobnet:
                     name = s2.prefix if s2.prefix.endswith("mid_block") else f"{s2.prefix}.{len(s2) - 1}"
                     M = self.B * f.H * f.W
+                    # (the low-resolution zero-convs on gemm_wreg.hip measured the same step time: 9.43 vs 9.43 ms; not taken)
                     r = pre if pre is not None else \
                         self.dense(f.t, M, f.C, name, f.C, kind="zero_conv", alpha=alpha, alpha_dev=alpha_dev,
                                    alpha_idx=alpha_idx, alpha_bstride=alpha_bstride, rows_per_batch=f.H * f.W)
