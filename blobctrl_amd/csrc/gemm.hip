@@ -489,7 +489,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     }
     if (gw) {
         BC_CHECK_ARG(bc_gemm_wreg_ok(p, p.tile_cfg), "bc_gemm: BC_TILE_GW* needs dense A, M%%64==0, N%%(64 NT)==0, K%%320==0 (C1%%320==0), fp16 row-major "
-                     "output, no split-K / row vector / A prologue (M=%d N=%d K=%d C1=%d)", p.M, p.N, p.K, p.C1);
+                     "output, no split-K / row vector / affine table (a_tot1: one source, groups | K <= 2560, no activation) (M=%d N=%d K=%d C1=%d)", p.M, p.N, p.K, p.C1);
         g.nk = p.K / 32; g.kt_per_split = g.nk; p.splitk = 1;
         g.div_rpb = make_fastdiv((unsigned)p.rows_per_batch);
         g.div_outw = make_fastdiv((unsigned)p.out_w);

@@ -113,6 +113,54 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     const int KS = p.K >> 5;
     const int nchunk = KS / GW_KC;
 
+    // ---- GroupNorm in front of the projection (Transformer2D's `norm` -> proj_in, transformer_2d.py:481-484): the finalize runs here, from
+    // the statistics totals (bc_common.h), into a per-channel (a, b) table in LDS that the row staging below applies: no GroupNorm pass,
+    // no normalised activation in HBM.  Before the weight ring is filled, so that nothing of the ring is drained by its waits.
+    constexpr int MAIN_BYTES = 2 * GW_XBUF > GW_BM * BN * 4 + GW_BM * 8 ? 2 * GW_XBUF : GW_BM * BN * 4 + GW_BM * 8;     // = launch_gw's LDS
+    const bool gn = p.a_tot1 != nullptr;
+    float* const abt = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [K][2]
+    if (gn) {
+        const int bimg = (int)fdiv((unsigned)m0, g.div_rpb);
+        double* scr = reinterpret_cast<double*>(smem);                           // [K][2] (the operand buffers are not in use yet)
+        float* stt = reinterpret_cast<float*>(smem + p.K * 16);                  // [groups][2]
+        for (int c = tid; c < p.K; c += 256) {
+            double s_, q_;
+            bc_gn_tot_read(p.a_tot1 + ((size_t)bimg * p.K + c) * BC_GN_TOT_WORDS, s_, q_);
+            scr[c * 2] = s_;
+            scr[c * 2 + 1] = q_;
+        }
+        __syncthreads();
+        const int cpg = p.K / p.a_groups, sub = tid & 7;
+        for (int gi = tid >> 3; gi < p.a_groups; gi += 32) {
+            double s_ = 0.0, q_ = 0.0;
+            for (int cj = sub; cj < cpg; cj += 8) {
+                s_ += scr[(gi * cpg + cj) * 2];
+                q_ += scr[(gi * cpg + cj) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                s_ += __shfl_xor(s_, o);
+                q_ += __shfl_xor(q_, o);
+            }
+            const double n = (double)g.div_rpb.d * cpg;
+            const double mean = s_ / n;
+            double var = q_ / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (sub == 0) {
+                stt[gi * 2] = (float)mean;
+                stt[gi * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < p.K; c += 256) {
+            const int gi = c / cpg;
+            const float av = stt[gi * 2 + 1] * p.a_gamma[c];
+            abt[c * 2] = av;
+            abt[c * 2 + 1] = p.a_beta[c] - stt[gi * 2] * av;
+        }
+        __syncthreads();
+    }
+
     WRing<R> ring;
     ring.p = reinterpret_cast<const uint4*>(p.W) + ((size_t)(jt * 4 + wave) * KS * NT) * 64 + lane;
 #pragma unroll
@@ -142,10 +190,24 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     auto land = [&](int c) {
         char* xb = smem + (c & 1) * GW_XBUF + xbase;
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < 5; ++k) {
+            float4 a4[4];
+            if (gn) {                                   // (a, b) of this piece's 8 channels
+                const float4* ab4 = reinterpret_cast<const float4*>(abt + (c * (GW_KC * 32) + (v8 + 8 * k) * 8) * 2);
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) a4[j4] = ab4[j4];
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const uint4 d = pf[2 * k + j];
+                uint4 d = pf[2 * k + j];
+                if (gn) {
+                    h16* e = reinterpret_cast<h16*>(&d);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        e[2 * j4] = (h16)fmaf((float)e[2 * j4], a4[j4].x, a4[j4].y);
+                        e[2 * j4 + 1] = (h16)fmaf((float)e[2 * j4 + 1], a4[j4].z, a4[j4].w);
+                    }
+                }
                 if (ln) {
                     const h16x2 one = {(h16)1.0f, (h16)1.0f};
                     const h16x2* e = reinterpret_cast<const h16x2*>(&d);
@@ -157,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
                 }
                 *reinterpret_cast<uint4*>(xb + k * 2 * 4096 + j * 32 * 64) = d;
             }
+        }
     };
 
     f32x4v acc[NT][4];
@@ -304,12 +367,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
 template <int NT, int R>
 int launch_gw(const GemmArgs& g, hipStream_t stream) {
     constexpr int BN = 64 * NT;
-    constexpr int LDS = (2 * GW_XBUF > GW_BM * BN * 4 ? 2 * GW_XBUF : GW_BM * BN * 4) + GW_BM * 2 * 4;
-    static_assert(2 * LDS <= 160 * 1024 + 2 * 512, "two workgroups per CU");
+    // two operand buffers | the fp32 epilogue tile + the LayerNorm statistics behind it (the tile of NT <= 4 leaves room inside the 80 KiB)
+    constexpr int LDS = 2 * GW_XBUF > GW_BM * BN * 4 + GW_BM * 8 ? 2 * GW_XBUF : GW_BM * BN * 4 + GW_BM * 8;
+    static_assert(NT == 5 || 2 * LDS <= 160 * 1024, "two workgroups per CU");
+    constexpr int LDS_MAX = LDS + 2560 * 8;                  // + the GroupNorm (a, b) table of up to 2560 channels (one workgroup per CU then)
     static std::atomic<unsigned long long> lds_set{0};
-    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_wreg_kernel<NT, R>), LDS));
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_wreg_kernel<NT, R>), LDS_MAX));
     const int grid = (g.p.M / GW_BM) * (g.p.N / BN);
-    hipLaunchKernelGGL((gemm_wreg_kernel<NT, R>), dim3(grid), dim3(256), LDS, stream, g);
+    hipLaunchKernelGGL((gemm_wreg_kernel<NT, R>), dim3(grid), dim3(256), LDS + (g.p.a_tot1 ? g.p.K * 8 : 0), stream, g);
     BC_CHECK_LAUNCH();
     return 0;
 }
@@ -343,7 +408,13 @@ int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg) {
     if (!nt || p.a_mode != BC_A_DENSE) return 0;
     if (p.M <= 0 || p.M % GW_BM || p.N % (64 * nt) || p.K % (32 * GW_KC)) return 0;
     if (p.A2 && (p.C1 % (32 * GW_KC) || p.C1 <= 0 || p.C1 >= p.K)) return 0;
-    if (p.out_mode != BC_OUT_F16 || p.splitk > 1 || p.rowvec || p.a_affine || p.a_tot1) return 0;
+    if (p.out_mode != BC_OUT_F16 || p.splitk > 1 || p.rowvec || p.a_affine) return 0;
+    if (p.a_tot1) {                                   // GroupNorm finalized in the prologue and applied while the rows are staged
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (!p.a_gamma || !p.a_beta || p.a_groups <= 0 || p.K % p.a_groups || p.a_groups > 256 || p.K > 2560 || p.A2 || p.ln_colsum || rpb % GW_BM ||
+            p.M % rpb || p.a_act != BC_ACT_NONE || p.K * 16 + p.a_groups * 8 > 2 * GW_XBUF)
+            return 0;
+    }
     if (p.act != BC_ACT_NONE && p.act != BC_ACT_GEGLU && p.act != BC_ACT_GELU && p.act != BC_ACT_SILU && p.act != BC_ACT_QUICK_GELU) return 0;
     if (p.ln_colsum && p.A2) return 0;               // (the statistics cover one source)
     if (p.C_t) {

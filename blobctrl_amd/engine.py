@@ -308,12 +308,16 @@ class TrunkPlan:
                 out = rec.empty(M, kw.get("n_t0") or n_out)
             rec.gemm(A=a_t, W=w, M=M, N=N, K=K, out=out, bias=b, tile_cfg=cfg, ln_colsum=cs, **kw)
             return out
-        n = self.groupnorm(x, None, p + "norm", 1e-6, False)
-        h = proj(n.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1")
+        if os.environ.get("BC_GW_GN_PASS"):                 # (diagnostics: the GroupNorm as its own pass in front of proj_in)
+            n = self.groupnorm(x, None, p + "norm", 1e-6, False)
+            h = proj(n.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1")
+        else:                                               # GroupNorm finalized + applied inside proj_in's row staging
+            gn = dict(x1=x.t, C1=Cc, B=B, HW=HW, G=self.G, eps=1e-6, gamma=pw.f[p + "norm.weight"], beta=pw.f[p + "norm.bias"])
+            h = proj(x.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1", a_gn=gn, rows_per_batch=HW)
         # --- self attention: LayerNorm1 folded; q | k row-major, V transposed for the attention kernel
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
-        qk = proj(h, bp + "attn1.to_qk", 3 * Cc, Cc, G256, ln=bp + "norm1", bias=False, extra=(bp + "attn1.to_v.weight",), C_t=vt, ldc_t=ldvt,
+        qk = proj(h, bp + "attn1.to_qk", 3 * Cc, Cc, G128, ln=bp + "norm1", bias=False, extra=(bp + "attn1.to_v.weight",), C_t=vt, ldc_t=ldvt,
                   n_t0=2 * Cc, rows_per_batch=HW, kind="qkv")
         a = rec.empty(M, Cc)
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
@@ -326,7 +330,9 @@ class TrunkPlan:
             rec.attention(q, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
             h = proj(a, bp + "attn2.to_out.0", Cc, Cc, G128, R=h, ldr=Cc, kind="attn_out")
         # --- GEGLU feed-forward: LayerNorm3 folded into ff.net.0; ff.net.2 (K = 4C) stays on the LDS-DMA tiles with split-K
-        g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G320 if M >= 512 else G256, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
+        # (64 x 128 workgroups everywhere: two fit a CU - 80 KiB of LDS each - and measure best at every shape of these levels, e.g.
+        #  LayerNorm + GEGLU [1024 x 10240 x 1280] 51.7 us against 53.5 / 54.8 for the 256- / 320-column workgroups: tools/gw_probe.py)
+        g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G128, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
         if not os.environ.get("BC_NO_GW_FF2"):
             # ff.net.2 (K = 4C) unsplit on gemm_wreg: the same step time as the LDS-DMA tiles with split-K 3 (9.42 vs 9.42 ms, same box,
             # two rounds), without their 15.7 MB of fp32 slabs and the reducer launch

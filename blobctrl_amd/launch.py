@@ -440,7 +440,14 @@ class Recorder:
             # small-M projection with the weights streamed into VGPRs (gemm_wreg.hip); W is the stream packed for this configuration
             assert not conv and a_affine is None and splitk in (None, 1) and rowvec is None
             cfg, sk, bm, bn = tile_cfg, 1, 64, 64 * _lib.GW_TILES[tile_cfg]
-            fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "")
+            fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "") + ("_gn" if a_gn is not None else "")
+            if a_gn is not None:          # GroupNorm(x) -> projection: finalize in the kernel's prologue from the statistics totals of x
+                t1, _ = self.gn_sources(a_gn["x1"], a_gn["C1"], None, 0, a_gn["B"], a_gn["HW"])
+                g.a_tot1 = ptr(t1)
+                g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), a_gn["G"], a_gn["eps"]
+                self.keep.append((t1, a_gn["gamma"], a_gn["beta"]))
+                for t in (t1, a_gn["gamma"], a_gn["beta"]):
+                    self.register(t)
         else:
             assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO / TILE_WREG"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)

@@ -137,7 +137,9 @@ enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_12
        /* small-M projections with the weights streamed straight into VGPRs (gemm_wreg.hip): dense A (one or two sources), M % 64 == 0,
         * K % 320 == 0 (C1 % 320 == 0), workgroup = 64 rows x 128 / 256 / 320 columns (N a multiple of that); `W` is the fragment stream
         * bc_gemm_wreg_pack wrote for the SAME configuration, ldw is ignored; fp16 row-major output, no split-K, no row vector; takes
-        * ln_colsum (folded LayerNorm) and C_t (transposed second output).  Never chosen by BC_TILE_AUTO (bc_gemm_wreg_eligible). */
+        * ln_colsum (folded LayerNorm), C_t (transposed second output) and a_tot1 / a_gamma / a_beta / a_groups / a_eps (the GroupNorm in front
+        * of a Transformer2D's proj_in finalized in the prologue and applied while the rows are staged; one source, K <= 2560, no
+        * activation).  Never chosen by BC_TILE_AUTO (bc_gemm_wreg_eligible). */
        BC_TILE_GW64x128 = 10, BC_TILE_GW64x256 = 11, BC_TILE_GW64x320 = 12 };
 /* Re-order a weight matrix w[N][ldw] into the per-wave fragment streams of a BC_TILE_GW* configuration (out of place;
  * bc_gemm_wreg_stream_elems(N, K) elements incl. the tail the register ring reads past the end): [column tile][wave 4][k-step K / 32]

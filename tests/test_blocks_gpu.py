@@ -123,6 +123,7 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
         assert any("out_ff/2" in v for v in variants), variants
     if mode == "gw":
         assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
+        assert not any(k.startswith("groupnorm") for k in kinds) and sum("_gn" in v for v in variants) == 1, (kinds, variants)
     _run(seg)
     _check(f"{name} ({mode})", _nchw(out, p["B"]), z[name], p["sub"])
 

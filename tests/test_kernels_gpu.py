@@ -676,6 +676,27 @@ def test_gemm_wreg_modes(rec, cfg_i, mode):
         close(decode_gn_tot(rec.tots[out.data_ptr()]), want, rtol=1e-4, atol=1e-2, what="gemm_wreg GroupNorm statistics")
 
 
+@pytest.mark.parametrize("cfg_i", [0, 2])
+def test_gemm_wreg_groupnorm_in_the_row_staging(rec, cfg_i):
+    """GroupNorm(x) -> 1x1 projection (Transformer2D norm -> proj_in) in ONE launch: the finalize runs in the kernel's prologue from the
+    statistics totals of x (here from a bc_gn_stats pass), the affine is applied while the rows are staged."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_gemm_wreg
+    cfg = _gw_cfgs()[cfg_i]
+    nt = _lib.GW_TILES[cfg]
+    B, HW, K, G = 2, 128, 640, 32
+    N, M = 64 * nt * 2, B * HW
+    x = g(1, B, HW, K) * 1.3 + 0.25 * g(2, 1, 1, K)
+    W, b = g(3, N, K) / math.sqrt(K), g(4, N)
+    gamma, beta = 1 + 0.2 * g(5, K), 0.2 * g(6, K)
+    xd = h(x)
+    out = run(rec, lambda: rec.gemm(A=xd, W=pack_gemm_wreg(W.half().cuda(), nt), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), tile_cfg=cfg,
+                                    rows_per_batch=HW, a_gn=dict(x1=xd, C1=K, B=B, HW=HW, G=G, eps=1e-6, gamma=gamma.cuda(), beta=beta.cuda())))
+    assert rec.seg.kinds.get("gn_stats") == 1 and "groupnorm" not in rec.seg.kinds
+    y = F.group_norm(x.half().float().permute(0, 2, 1), G, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, K)
+    close(out, y.half().float() @ W.half().float().t() + b, rtol=3e-3, what=f"gemm_wreg GroupNorm prologue nt={nt}")
+
+
 @pytest.mark.parametrize("cfg_i", [0, 1])
 def test_gemm_wreg_qkv_one_launch(rec, cfg_i):
     """LayerNorm -> to_q | to_k (row-major) and to_v (written transposed [B][C][ldvt] for the attention kernel) as ONE launch."""
