@@ -45,6 +45,8 @@ inline const char* op_signature(int op) {
         case BC_OP_ROWCHAIN: return "iiiipppppifpppiiipppppipffppipi";
         case BC_OP_ASSEMBLE_IM2COL: return "pippiiiiip";
         case BC_OP_MEMSET_ZERO: return "pl";
+        case BC_OP_ROWCHAIN_MIDX: return "iiipppppifppf";
+        case BC_OP_ROWCHAIN_PACK_KV: return "pipiiiip";
         default: return nullptr;
     }
 }

@@ -66,6 +66,9 @@ struct RowChainArgs {
     float gn_eps;
     const h16* res;          // MID / OUT: residual stream before this attention [M][C]
     const h16* res2;         // OUT: the block's input x (added after proj_out)
+                             // MIDX (the struct is kept at its size: a larger one costs every kind scalar registers, and those spill into
+                             // vector lanes): the K / V^T fragment streams [B][waves][XCfg::FR_WAVE + RC_RPAD][64 lanes] x 16 bytes
+                             // (bc_rowchain_pack_kv); r2_xmin = context tokens (<= 80); alpha = softmax scale (head_dim ** -0.5)
     const h16* r2;           // OUT: BlobNet residual [bmod][rows_per_batch][C] added where pixel x >= r2_xmin, or null
     int r2_xmin, r2_bmod, out_w;
     const uint4* wstream;    // [4 waves][fragments in consumption order (+ RC_R of padding)][64 lanes] 16-byte fragments
@@ -86,7 +89,21 @@ struct RowChainArgs {
     unsigned long long* stamps;   // BC_RC_STAMPS diagnostics: [workgroup][16] s_memtime stamps (null in production)
 };
 
+// Cross-attention inside the MID launch (BC_CHAIN_MIDX): 8 heads, a wave's 80 channels are 2 heads of 40 (C = 320) or one of 80 (C = 640)
+template <int C>
+struct XCfg {
+    static constexpr int D = C / 8;                    // head dimension
+    static constexpr int HPW = 80 / D;                 // heads per wave
+    static constexpr int QKS = D == 40 ? 2 : 3;        // 32-channel k-steps of the X image that cover one head's channels
+    static constexpr int NKT = 5;                      // key tiles of 16: up to 80 context tokens
+    static constexpr int VT = D == 40 ? 3 : 5;         // value (output channel) tiles a head touches
+    static constexpr int FR_HEAD = NKT * QKS + VT * 3; // fragments per head: K then V^T
+    static constexpr int FR_WAVE = HPW * FR_HEAD;
+    static constexpr int P_BYTES = 2 * 4096 + 2048;    // one wave's probability image
+};
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int V> struct IC { static constexpr int value = V; };
 
 __device__ __forceinline__ h16x8 as_h8(uint4 v) { return __builtin_bit_cast(h16x8, v); }
 
@@ -147,6 +164,82 @@ __device__ __forceinline__ void gemm_seg(f32x4v (&acc)[NT][4], WRing<RC_R>& r, c
 #pragma unroll
     for (int t = 0; t < NT; ++t) r.f[(POS + (KS - 1) * NT + t) % RC_R] = r.p[t * 64];
     r.p += NT * 64;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same segment for the LAST GEMM of a weight stream that is followed, in consumption order, by fragments that live elsewhere (MIDX:
+// the K / V^T fragments of the workgroup's image at `p2`): its refill number JUMP (of NT * KS) and all later ones come from `p2`, and
+// the ring runs on along that stream.
+template <int NT, int KS, int POS, int RC_R, int JUMP>
+__device__ __forceinline__ void gemm_seg_jump(f32x4v (&acc)[NT][4], WRing<RC_R>& r, const uint4* p2, const char* xb) {
+    h16x8 xq[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xq[0][mt] = *reinterpret_cast<const h16x8*>(xb + mt * 1024);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                r.f[(POS + (s - 1) * NT + t) % RC_R] = (s - 1) * NT + t >= JUMP ? p2[((s - 1) * NT + t - JUMP) * 64] : r.p[t * 64];
+            r.p += NT * 64;
+        }
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xq[(s + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(xb + (s + 1) * 4096 + mt * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h16x8 w = as_h8(r.f[(POS + s * NT + t) % RC_R]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xq[s & 1][mt], acc[t][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r.f[(POS + (KS - 1) * NT + t) % RC_R] = (KS - 1) * NT + t >= JUMP ? p2[((KS - 1) * NT + t - JUMP) * 64] : r.p[t * 64];
+    r.p = p2 + (NT * KS - JUMP) * 64;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// O^T += V^T . P^T for one head (MIDX): NTV value tiles starting at accumulator tile TLO, three k-steps over the (<= 80, padded to 96)
+// keys.  V^T fragments from the ring; P (fp16 probabilities of this wave's 64 rows) from the wave's private image `Pw`: k-steps 0 and 1
+// in the X operand layout, k-step 2 (keys 64..79 only) as [64 rows][32 bytes] - its upper half is zero by construction.
+template <int NTV, int TLO, int POS, int RC_R>
+__device__ __forceinline__ void pv_seg(f32x4v (&o)[5][4], WRing<RC_R>& r, const char* Pw, int xfo, int m, int q) {
+    h16x8 xq[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xq[0][mt] = *reinterpret_cast<const h16x8*>(Pw + mt * 1024 + xfo);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s > 0) {
+#pragma unroll
+            for (int t = 0; t < NTV; ++t) r.f[(POS + (s - 1) * NTV + t) % RC_R] = r.p[t * 64];
+            r.p += NTV * 64;
+        }
+        if (s == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xq[1][mt] = *reinterpret_cast<const h16x8*>(Pw + 4096 + mt * 1024 + xfo);
+        }
+        if (s == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const h16x8 v = *reinterpret_cast<const h16x8*>(Pw + 8192 + (16 * mt + m) * 32 + (q & 1) * 16);
+                xq[0][mt] = q < 2 ? v : (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTV; ++t) {
+            const h16x8 w = as_h8(r.f[(POS + s * NTV + t) % RC_R]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) o[TLO + t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xq[s & 1][mt], o[TLO + t][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NTV; ++t) r.f[(POS + 2 * NTV + t) % RC_R] = r.p[t * 64];
+    r.p += NTV * 64;
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -481,8 +574,9 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
         __syncthreads();
     }
     constexpr bool FFLOOP = KIND == BC_CHAIN_OUT || FF;      // kinds that run the feed-forward loop
-    constexpr int RC_R = RC_C == 320 ? (FFLOOP ? 15 : (KIND == BC_CHAIN_IN ? 13 : 16))
-                                     : (FFLOOP ? 10 : (KIND == BC_CHAIN_IN ? 12 : 12));   // (8 waves: two per SIMD hide more latency)
+    constexpr bool MIDX = KIND == BC_CHAIN_MIDX;
+    constexpr int RC_R = RC_C == 320 ? (FFLOOP ? 15 : (KIND == BC_CHAIN_IN ? 13 : (MIDX ? 12 : 16)))
+                                     : (FFLOOP ? 10 : (KIND == BC_CHAIN_IN ? 12 : (MIDX ? 8 : 12)));   // (8 waves: two per SIMD hide more latency)
     static_assert(RC_R <= RC_RPAD, "stream padding");
     WRing<RC_R> ring;
     ring.p = a.wstream + ((size_t)z * CF::NW + wave) * a.wave_frags * 64 + lane;
@@ -568,6 +662,79 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
         acc_to_S<RC_C>(acc, S, wave, m, q);
         lds_barrier();
         S_to_rows<RC_C>(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        stamp(4);
+        return;
+    }
+    if constexpr (MIDX) {
+        // MID with the cross-attention of the block (attention_processor.py:2191-2224 on the <= 80 context tokens) behind to_q: the
+        // query rows never leave the workgroup.  K and V^T of the workgroup's image arrive as fragment streams through the weight ring
+        // (bc_rowchain_pack_kv: per wave, the heads its 80 channels hold), so S^T = K Q^T and O^T = V^T P^T are two more segments of the
+        // chain; the softmax runs on the swapped accumulator layout (a lane holds 4 keys of one row: two cross-lane steps per row).
+        using XC = XCfg<RC_C>;
+        constexpr int G = RC_NT * RC_KS;
+        layernorm_to_X<RC_C>(acc, vec + RC_C, a.ln_eps, X, wave, m, q);
+        acc_to_S<RC_C>(acc, S, wave, m, q);
+        lds_barrier();
+        S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);           // h1
+        zero_acc(acc);
+        // attn2.to_q; the ring runs on into the K / V^T stream
+        gemm_seg_jump<RC_NT, RC_KS, G % RC_R, RC_R, G - RC_R>(
+            acc, ring, reinterpret_cast<const uint4*>(a.res2) + ((size_t)b * CF::NW + wave) * (XC::FR_WAVE + RC_RPAD) * 64 + lane, X + xfo);
+        lds_barrier();                                                  // X (LayerNorm2 image) and S (h1) are free
+        acc_to_X(acc, X, wave, m, q);                                   // Q of this wave's heads, as operand image (read back by this wave only)
+        f32x4v o[RC_NT][4];
+        zero_acc(o);
+        char* Pw = S + wave * XC::P_BYTES;
+        const float csc = a.alpha * 1.4426950408889634f;
+        const int T = a.r2_xmin;
+        auto head = [&](auto hc) {
+            constexpr int hh = decltype(hc)::value;
+            constexpr int POS_K = (2 * G + hh * XC::FR_HEAD) % RC_R, POS_V = (POS_K + XC::NKT * XC::QKS) % RC_R;
+            constexpr int TLO = XC::D == 40 && hh == 1 ? 2 : 0;
+            const int s0 = (80 * wave + XC::D * hh) >> 5;
+            zero_acc(acc);
+            gemm_seg<XC::NKT, XC::QKS, POS_K, true, RC_R>(acc, ring, X + s0 * 4096 + xfo);   // scores^T[key 16 t + 4 q + r][row 16 mt + m]
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int t = 0; t < XC::NKT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * q + r < T) mx = fmaxf(mx, acc[t][mt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < XC::NKT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = 16 * t + 4 * q + r < T ? __builtin_amdgcn_exp2f((acc[t][mt][r] - mx) * csc) : 0.f;
+                        acc[t][mt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                for (int t = 0; t < XC::NKT; ++t) {
+                    const float v[4] = {acc[t][mt][0] * inv, acc[t][mt][1] * inv, acc[t][mt][2] * inv, acc[t][mt][3] * inv};
+                    char* dst = t < 4 ? Pw + x_off(t >> 1, 16 * mt + m, 2 * (t & 1) + (q >> 1)) + (q & 1) * 8 : Pw + 8192 + (16 * mt + m) * 32 + q * 8;
+                    *reinterpret_cast<h16x4*>(dst) = pack4(v);
+                }
+            }
+            pv_seg<XC::VT, TLO, POS_V, RC_R>(o, ring, Pw, xfo, m, q);
+        };
+        head(IC<0>{});
+        if constexpr (XC::HPW == 2) head(IC<1>{});
+        lds_barrier();                                                  // every wave has read its probability image: S may be overwritten
+        // (lane-derived addresses are recomputed from a laundered thread id: kept alive across the attention they spill)
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int m2 = tid2 & 15, q2 = (tid2 & 63) >> 4;
+        acc_to_S<RC_C>(o, S, wave, m2, q2);
+        lds_barrier();
+        S_to_rows<RC_C>(a.out1 + (size_t)m0 * RC_C, RC_C, S, copy_map<RC_C>(tid2));     // attention output rows
         stamp(4);
         return;
     }
@@ -725,7 +892,7 @@ struct RcStampReport {
                     n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, ff[0] / n, ff[1] / n, ff[2] / n, d[4] / n, d[5] / n, d[6] / n, t1 - t0);
         else
             fprintf(stderr, "[rowchain stamps %s] wgs=%zu | avg ticks: prologue %.0f, first gemm %.0f, epilogue+LN %.0f, rest %.0f | first entry -> last "
-                    "exit %llu ticks\n", kind == BC_CHAIN_IN ? "in" : "mid", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, t1 - t0);
+                    "exit %llu ticks\n", kind == BC_CHAIN_IN ? "in" : kind == BC_CHAIN_MIDX ? "midx" : "mid", n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, t1 - t0);
     }
 };
 
@@ -750,6 +917,7 @@ int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
+#ifndef BC_ROWCHAIN_MIDX_TU
 template <int RC_C>
 long long stream_frags(int kind, int blobnet, int nsplit) {
     using CF = RCfg<RC_C>;
@@ -757,7 +925,7 @@ long long stream_frags(int kind, int blobnet, int nsplit) {
     const long long per_chunk = CF::TP * 2 * CF::KS + RC_NT * (RC_HC / 32);
     long long n = 0;
     if (kind == BC_CHAIN_IN) n = 4 * g;
-    else if (kind == BC_CHAIN_MID) n = 2 * g;
+    else if (kind == BC_CHAIN_MID || kind == BC_CHAIN_MIDX) n = 2 * g;      // (MIDX reads MID's stream)
     else if (kind == BC_CHAIN_OUT) n = 2 * g + CF::NCH * per_chunk + (blobnet ? g : 0);
     else if (kind == BC_CHAIN_OUT_FF && nsplit > 0 && CF::NCH % nsplit == 0) n = g + CF::NCH / nsplit * per_chunk;
     else if (kind == BC_CHAIN_OUT_TAIL) n = g + (blobnet ? g : 0);
@@ -831,3 +999,95 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
     }
     return channels == 320 ? dispatch_chain<320>(kind, blob, a, s) : dispatch_chain<640>(kind, blob, a, s);
 }
+
+#else   // BC_ROWCHAIN_MIDX_TU: rowchain_midx.hip
+}  // namespace
+
+// ---- cross-attention inside the chain (BC_CHAIN_MIDX) ------------------------------------------------------------------------------
+namespace {
+
+// K rows [B * T][ldk] and V^T [B][C][ldvt] of one block's context -> per (image, wave) fragment streams in the consumption order of
+// the MIDX launch: per head of the wave, K as [k-step][key tile] then V^T as [key k-step][value tile], every fragment masked to the
+// head's channels and to keys < T (zeros elsewhere: a k-step of the operand image also holds the neighbouring head's channels).
+template <int RC_C>
+__global__ void rowchain_pack_kv_kernel(const h16* __restrict__ k, int ldk, const h16* __restrict__ vt, int ldvt, int B, int T, long long kvf,
+                                        uint4* __restrict__ out) {
+    using XC = XCfg<RC_C>;
+    constexpr int NW = RCfg<RC_C>::NW;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * NW * kvf * 64) return;
+    const int lane = (int)(idx & 63);
+    const long long fi = idx >> 6;
+    const int f = (int)(fi % kvf), w = (int)((fi / kvf) % NW), b = (int)(fi / (kvf * NW));
+    h16 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
+    if (f < XC::FR_WAVE) {
+        const int hh = f / XC::FR_HEAD, g = f % XC::FR_HEAD;
+        const int c_h = 80 * w + XC::D * hh;
+        if (g < XC::NKT * XC::QKS) {
+            const int ks = g / XC::NKT, t = g % XC::NKT;
+            const int key = 16 * t + (lane & 15), ch0 = 32 * ((c_h >> 5) + ks) + 8 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (key < T && ch0 + j >= c_h && ch0 + j < c_h + XC::D) v[j] = k[((size_t)b * T + key) * ldk + ch0 + j];
+        } else {
+            const int g2 = g - XC::NKT * XC::QKS;
+            const int ks = g2 / XC::VT, tv = g2 % XC::VT;
+            const int tlo = XC::D == 40 && hh == 1 ? 2 : 0;
+            const int ch = 80 * w + 16 * (tlo + tv) + (lane & 15), key0 = 32 * ks + 8 * (lane >> 4);
+            if (ch >= c_h && ch < c_h + XC::D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (key0 + j < T) v[j] = vt[((size_t)b * RC_C + ch) * ldvt + key0 + j];
+            }
+        }
+    }
+    out[idx] = *reinterpret_cast<const uint4*>(v);
+}
+
+}  // namespace
+
+extern "C" long long bc_rowchain_kv_frags(int channels) {
+    // fragments of ONE (image, wave) K / V^T stream incl. the padding the ring reads past its end; -1: unsupported
+    if (channels == 320) return XCfg<320>::FR_WAVE + RC_RPAD;
+    if (channels == 640) return XCfg<640>::FR_WAVE + RC_RPAD;
+    return -1;
+}
+
+extern "C" int bc_rowchain_pack_kv(const bc_half* k, int ldk, const bc_half* vt, int ldvt, int B, int T, int channels, bc_half* out, bc_stream stream) {
+    BC_CHECK_ARG((channels == 320 || channels == 640) && k && vt && out && B > 0 && T > 0 && T <= 80 && ldk >= channels && ldvt >= T,
+                 "bc_rowchain_pack_kv: needs 320 or 640 channels (8 heads), 1 <= T <= 80 context tokens, ldk >= channels, ldvt >= T (channels=%d T=%d)", channels, T);
+    const long long kvf = bc_rowchain_kv_frags(channels);
+    const long long total = (long long)B * (channels / 80) * kvf * 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (channels == 320)
+        hipLaunchKernelGGL(rowchain_pack_kv_kernel<320>, dim3(bc_ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const h16*>(k), ldk,
+                           reinterpret_cast<const h16*>(vt), ldvt, B, T, kvf, reinterpret_cast<uint4*>(out));
+    else
+        hipLaunchKernelGGL(rowchain_pack_kv_kernel<640>, dim3(bc_ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const h16*>(k), ldk,
+                           reinterpret_cast<const h16*>(vt), ldvt, B, T, kvf, reinterpret_cast<uint4*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_rowchain_midx(int channels, int M, int rows_per_batch, const bc_half* x, const bc_half* res, const bc_half* wstream, const float* vec,
+                                const bc_half* kvstream, int n_ctx, float attn_scale, bc_half* out0, bc_half* out1, float ln_eps, bc_stream stream) {
+    BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain_midx: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
+                 "rows_per_batch %% %d == 0 (channels=%d M=%d rows_per_batch=%d)", RC_BM, channels, M, rows_per_batch);
+    BC_CHECK_ARG(x && res && wstream && vec && kvstream && out0 && out1 && n_ctx >= 1 && n_ctx <= 80 && attn_scale > 0.f,
+                 "bc_rowchain_midx: null pointer, or n_ctx = %d outside 1..80", n_ctx);
+    RowChainArgs a = {};
+    a.kind = BC_CHAIN_MIDX; a.M = M; a.rows_per_batch = rows_per_batch;
+    a.x = reinterpret_cast<const h16*>(x); a.res = reinterpret_cast<const h16*>(res);
+    a.r2_bmod = 1; a.out_w = 1; a.nsplit = 1;
+    a.wstream = reinterpret_cast<const uint4*>(wstream);
+    a.wave_frags = bc_rowchain_stream_frags(channels, BC_CHAIN_MID, 0, 1);
+    a.vec = vec;
+    a.res2 = reinterpret_cast<const h16*>(kvstream); a.r2_xmin = n_ctx; a.alpha = attn_scale;      // (see RowChainArgs)
+    a.out0 = reinterpret_cast<h16*>(out0); a.out1 = reinterpret_cast<h16*>(out1);
+    a.ln_eps = ln_eps;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return channels == 320 ? launch_chain<320, BC_CHAIN_MIDX, false>(a, s) : launch_chain<640, BC_CHAIN_MIDX, false>(a, s);
+}
+#endif  // BC_ROWCHAIN_MIDX_TU

@@ -237,12 +237,20 @@ class TrunkPlan:
                       scale, q_off=0, k_off=Cc)
         h = h0
         if pw.has_cross:
-            h1, q2 = rec.empty(M, Cc), rec.empty(M, Cc)
+            h1 = rec.empty(M, Cc)
             w, v = packed(_lib.CHAIN_MID)
-            rec.rowchain(_lib.CHAIN_MID, Cc, M, HW, a, w, v, h1, out1=q2, res=h0)
             ck, cvt, T, ldc_vt = self.ctx_kv[bp]
-            a = rec.empty(M, Cc)
-            rec.attention(q2, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
+            kvs = getattr(self, "ctx_kvs", {}).get(bp)
+            if kvs is not None:
+                # the cross-attention runs inside the MID launch: q never leaves the workgroup, K / V^T come as fragment streams
+                a2 = rec.empty(M, Cc)
+                rec.rowchain_midx(Cc, M, HW, a, w, v, kvs, T, self.heads, scale, h1, a2, res=h0)
+                a = a2
+            else:
+                q2 = rec.empty(M, Cc)
+                rec.rowchain(_lib.CHAIN_MID, Cc, M, HW, a, w, v, h1, out1=q2, res=h0)
+                a = rec.empty(M, Cc)
+                rec.attention(q2, ck, cvt, a, B, self.heads, d, HW, T, Cc, Cc, ldc_vt, Cc, HW * Cc, T * Cc, Cc * ldc_vt, HW * Cc, scale)
             h = h1
         out = rec.empty(M, Cc)
         part = rec.new_tot(B, Cc)                            # GroupNorm statistics of the block output (the next ResBlock's norm1)
@@ -390,7 +398,7 @@ class TrunkPlan:
         """Cross-attention K / V^T of the (step-invariant) prompt embeddings, once per edit
         (attention.py:504-510; SURVEY Appendix A 'step-invariant => precompute once per edit')."""
         rec, pw, B = self.rec, self.pw, self.B
-        self.ctx_kv = {}
+        self.ctx_kv, self.ctx_kvs = {}, {}
         Dc = ctx.shape[-1]
         ldvt = (T + 63) // 64 * 64
         for k in [k for k in pw.h if k.endswith("attn2.to_k.weight")]:
@@ -402,6 +410,9 @@ class TrunkPlan:
             rec.gemm(A=ctx, W=pw.h[bp + "attn2.to_v.weight"], M=B * T, N=Cc, K=Dc, out=cvt, out_mode=_lib.OUT_F16_T,
                      ldc=ldvt, rows_per_batch=T, kind="ctx_kv")
             self.ctx_kv[bp] = (ck, cvt, T, ldvt)
+            # blocks the row-chain takes with 8 heads and <= 80 context tokens: K / V^T also as the fragment streams of CHAIN_MIDX
+            if (Cc in (320, 640) and self.heads == 8 and T <= 80 and not os.environ.get("BC_NO_MIDX") and not os.environ.get("BC_NO_ROWCHAIN")):
+                self.ctx_kvs[bp] = rec.rowchain_kv_stream(ck, cvt, B, T, Cc, ldvt)
 
     # ------------------------------------------------------------------------------------------- per-edit weight collapse
     def record_collapse(self, feat16: torch.Tensor):

@@ -598,6 +598,33 @@ class Recorder:
                  rocprof=f"rowchain_kernel<{Cc}, {kind}, {'true' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else 'false'}>")
         return out0
 
+    def rowchain_kv_stream(self, ck, cvt, B, T, Cc, ldvt):
+        """K rows [B * T][Cc] / V^T [B][Cc][ldvt] of a block's projected context -> the per-(image, wave) fragment streams CHAIN_MIDX
+        reads (bc_rowchain_pack_kv; recorded where the context is projected: once per edit)."""
+        frags = self.lib.bc_rowchain_kv_frags(Cc)
+        if frags < 0:
+            _lib.check(1, "bc_rowchain_kv_frags")
+        out = self.empty(B * (Cc // 80) * frags * 64 * 8)
+        self.keep.append((ck, cvt, out))
+        self._op("bc_rowchain_pack_kv", (ck, Cc, cvt, ldvt, B, T, Cc, out), "pack_kv", variant="rowchain_pack_kv_kernel",
+                 shape=("pack_kv", B, T, Cc), bytes_=2 * (2 * B * T * Cc) + out.numel() * 2, rocprof=f"rowchain_pack_kv_kernel<{Cc}>")
+        return out
+
+    def rowchain_midx(self, Cc, M, rows_per_batch, x, wstream, vec, kvstream, n_ctx, heads, scale, out0, out1, res, ln_eps=1e-5):
+        """CHAIN_MID with the block's cross-attention inside (include/blobctrl_hip.h: bc_rowchain_midx): out0 = h1, out1 = attn2's
+        attention output rows."""
+        assert heads * (Cc // heads) == Cc and heads == 8, "CHAIN_MIDX is laid out for 8 heads"
+        refs = (x, wstream, vec, kvstream, out0, out1, res)
+        self.keep.append(refs)
+        for t in refs:
+            self.register(t)
+        B = M // rows_per_batch
+        self._op("bc_rowchain_midx", (Cc, M, rows_per_batch, x, res, wstream, vec, kvstream, n_ctx, scale, out0, out1, ln_eps), "rowchain",
+                 flops=2 * M * Cc * Cc * 2 + 4 * M * n_ctx * Cc, variant="rowchain_kernel<midx>",
+                 shape=("rowchain_midx", M, Cc, 2 * Cc), bytes_=2 * (2 * Cc * Cc + 3 * M * Cc + 2 * B * n_ctx * Cc),
+                 rocprof=f"rowchain_kernel<{Cc}, {_lib.CHAIN_MIDX}, false>")
+        return out1
+
     # ------------------------------------------------------------------ glue
     def call(self, name, *args, kind=None, keep=()):
         """Record a generic `bc_<name>(*args, stream)` launch (any entry point listed in _lib.OPS)."""

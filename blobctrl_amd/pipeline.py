@@ -208,7 +208,7 @@ class BlobCtrlEngine:
         # ---- step I: UNet only (cond_scale == 0: BlobNet output is multiplied by 0, bn:936-938)
         P.step_inactive = rec.begin("step_inactive")
         unet_i = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
-        unet_i.ctx_kv = unet_a.ctx_kv
+        unet_i.ctx_kv, unet_i.ctx_kvs = unet_a.ctx_kv, getattr(unet_a, "ctx_kvs", {})
         if not temb_per_step:
             unet_i.tproj, unet_i.tproj_table = unet_a.tproj, unet_a.tproj_table
         record_unet(unet_i, None)

@@ -306,7 +306,7 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  * rows_per_batch % 64 == 0.  Every workgroup streams the block's whole weight set (4.1 MB at 320 channels, 16.4 MB at 640): worth it
  * from a few dozen row blocks upwards (the engine takes the 640-channel form from 64 row blocks).
  * --------------------------------------------------------------------------------------------------------------- */
-enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4 };
+enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4, BC_CHAIN_MIDX = 5 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
 long long bc_rowchain_stream_frags(int channels, int kind, int blobnet, int nsplit);
 int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine,
@@ -314,6 +314,17 @@ int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half
                 const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                 const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, unsigned long long* gn_tot, float ln_eps,
                 float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit, bc_stream stream);
+/* BC_CHAIN_MIDX: BC_CHAIN_MID with the block's cross-attention behind to_q, in the same launch (diffusers/src/diffusers/models/
+ * attention.py:491-510 norm2 -> attn2, attention_processor.py:2191-2224 scaled-dot-product attention over the encoder tokens): x =
+ * attn1 output, res = h0: to_out + res -> out0 = h1; LayerNorm2 -> to_q -> softmax(q K^T * attn_scale) V per head (8 heads) -> out1 =
+ * attn2's attention output rows [M][C] (what BC_CHAIN_OUT takes as x).  The query rows stay in the workgroup; K and V^T of the
+ * workgroup's image are read as per-wave fragment streams `kvstream` that bc_rowchain_pack_kv lays out once per edit from the
+ * projected context (K rows [B * T][ldk], V^T [B][C][ldvt]; T <= 80 tokens; bc_rowchain_kv_frags(channels) * 64 * 16 bytes per image
+ * and wave, channels / 80 waves).  `wstream` / `vec` are BC_CHAIN_MID's. */
+long long bc_rowchain_kv_frags(int channels);
+int bc_rowchain_pack_kv(const bc_half* k, int ldk, const bc_half* vt, int ldvt, int B, int T, int channels, bc_half* out, bc_stream stream);
+int bc_rowchain_midx(int channels, int M, int rows_per_batch, const bc_half* x, const bc_half* res, const bc_half* wstream, const float* vec,
+                     const bc_half* kvstream, int n_ctx, float attn_scale, bc_half* out0, bc_half* out1, float ln_eps, bc_stream stream);
 
 /* Layout helpers at the nn.Module boundary (NCHW <-> token-major NHWC, fp32/fp16). */
 int bc_nchw_to_nhwc_f16(const void* src, int src_is_f32, int B, int C, int HW, int Cpad, bc_half* dst, bc_stream stream);
@@ -365,7 +376,7 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
        BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
-       BC_OP_MEMSET_ZERO = 24, BC_OP_COUNT = 25 };
+       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_COUNT = 27 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

@@ -22,10 +22,14 @@ def _block_sd(cross, seed, zero=False, C=320):
     return sd
 
 
-def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1):
+def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T=7, midx=True):
     monkeypatch.setenv("BC_ROWCHAIN_MIN_BLOCKS_640", "1")      # (the engine takes the 640-channel form only from 256 row blocks upwards)
     monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", str(split))  # feed-forward of the block end over `split` workgroups per row block
     monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_320", str(split))
+    if midx:
+        monkeypatch.delenv("BC_NO_MIDX", raising=False)
+    else:
+        monkeypatch.setenv("BC_NO_MIDX", "1")
     if fused:
         monkeypatch.delenv("BC_NO_ROWCHAIN", raising=False)
     else:
@@ -34,7 +38,7 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1):
     rec, seg, plan = _plan("rc", sd, B, H, W, heads=8, cross=768 if cross else None)
     x = g(5, B, C, H, W) * 1.3 + 0.2
     if cross:
-        plan.record_context(g(6, B, 7, 768).reshape(-1, 768).half().cuda(), 7)
+        plan.record_context(g(6, B, T, 768).reshape(-1, 768).half().cuda(), T)
     r2 = None
     if with_r2:
         r2 = (g(7, 1, H * W, C) * 0.7).half().cuda()
@@ -83,6 +87,25 @@ def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2
     assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
 
 
+@pytest.mark.parametrize("B,H,W,C,T", [(2, 16, 32, 320, 77), (1, 8, 24, 320, 80), (2, 8, 8, 320, 1), (2, 16, 32, 640, 77), (1, 8, 8, 640, 48),
+                                       (1, 8, 24, 640, 17)])
+def test_cross_attention_inside_the_mid_launch(monkeypatch, B, H, W, C, T):
+    """BC_CHAIN_MIDX (to_out + residual -> LayerNorm2 -> to_q -> softmax(q K^T) V over the context tokens, one launch) against the same
+    block with BC_CHAIN_MID + bc_attention, and against the unfused launch list: 77 tokens (the CLIP context), the 80-token maximum, a
+    single token (softmax = 1), and counts that leave key tiles partly or wholly masked."""
+    rec_x, out_x, _, _ = _record(monkeypatch, True, True, B, H, W, True, False, C, 1, T=T, midx=True)
+    assert any("midx" in (m["variant"] or "") for m in rec_x.seg.meta)
+    assert not any(m["kind"] == "attention" and m["shape"][-1] == T for m in rec_x.seg.meta)       # the cross-attention launch is gone
+    rec_m, out_m, _, _ = _record(monkeypatch, True, True, B, H, W, True, False, C, 1, T=T, midx=False)
+    assert not any("midx" in (m["variant"] or "") for m in rec_m.seg.meta)
+    _, out_u, _, _ = _record(monkeypatch, False, True, B, H, W, True, False, C, 1, T=T)
+    a, b, c = (o.t.float().cpu().numpy() for o in (out_x, out_m, out_u))
+    rel_m, rel_u = np.abs(a - b).max() / np.abs(b).max(), np.abs(a - c).max() / np.abs(c).max()
+    print(f"MIDX vs MID + attention: {rel_m:.3e} ({psnr(a, b):.1f} dB); vs the unfused block: {rel_u:.3e} ({psnr(a, c):.1f} dB)")
+    assert rel_m < 4e-3 and psnr(a, b) > 54.0
+    assert rel_u < 6e-3 and psnr(a, c) > 50.0
+
+
 def test_rowchain_rejects_unsupported_shapes():
     from blobctrl_amd import _lib
     lib = _lib.load()
@@ -92,4 +115,6 @@ def test_rowchain_rejects_unsupported_shapes():
     assert lib.bc_rowchain_stream_frags(640, 1, 0, 1) == 220 and lib.bc_rowchain_stream_frags(640, 2, 0, 1) == 1420
     # split block end: OUT_FF = to_out + 20 / nsplit chunks of 60 fragments (+ 20 padding), OUT_TAIL = proj_out [+ zero-conv]
     assert lib.bc_rowchain_stream_frags(640, 3, 0, 2) == 100 + 10 * 60 + 20 and lib.bc_rowchain_stream_frags(640, 3, 0, 3) == -1
+    assert lib.bc_rowchain_kv_frags(320) == 2 * (10 + 9) + 20 and lib.bc_rowchain_kv_frags(640) == 15 + 15 + 20 and lib.bc_rowchain_kv_frags(1280) == -1
+    assert lib.bc_rowchain_stream_frags(320, 5, 0, 1) == lib.bc_rowchain_stream_frags(320, 1, 0, 1)       # MIDX reads MID's stream
     assert lib.bc_rowchain_stream_frags(640, 4, 1, 2) == 220 and lib.bc_rowchain_stream_frags(320, 3, 0, 5) == 50 + 2 * 60 + 20
