@@ -290,6 +290,47 @@ def _frag_stream(w: torch.Tensor, row_starts, k0: int = 0, k1: int = None) -> to
     return x.permute(0, 3, 1, 4, 2, 5).reshape(nw, -1, 64, 8).contiguous()  # [wave][s][tile][q][m][8] -> lane = 16 q + m
 
 
+def pack_rowchain_kv(k: torch.Tensor, vt: torch.Tensor, T: int, pad_frags: int = 20) -> torch.Tensor:
+    """Host statement of bc_rowchain_pack_kv (csrc/rowchain.hip): the projected context of one block - K rows `k` [B][T][C], V^T `vt`
+    [B][C][>= T] - as the per-(image, wave) fragment streams BC_CHAIN_MIDX consumes: [B][C / 80 waves][fragments + pad_frags][64 lanes][8]
+    fp16.  8 heads; a wave's 80 channels are 2 heads of 40 (C = 320) or one of 80 (C = 640).  Per head: K as [k-step][5 key tiles] - lane
+    16 q + m holds key 16 t + m, channels 32 (s0 + ks) + 8 q .. + 7 of the operand image's k-step (zero outside the head's channels and
+    for keys >= T) - then V^T as [key k-step 0..2][value tile] - lane holds channel 80 w + 16 (tlo + tv) + m, keys 32 ks + 8 q .. + 7."""
+    B, _, C = k.shape
+    D = C // 8
+    hpw, qks, vtiles = 80 // D, (2 if D == 40 else 3), (3 if D == 40 else 5)
+    fr_head = 5 * qks + 3 * vtiles
+    nw = C // 80
+    out = torch.zeros(B, nw, hpw * fr_head + pad_frags, 64, 8, dtype=torch.float16, device=k.device)
+    kp = torch.zeros(B, 80, C + 64, dtype=torch.float16, device=k.device)      # keys padded to 80, channels padded for the last k-step
+    kp[:, :T, :C] = k[:, :T]
+    vp = torch.zeros(B, C, 96, dtype=torch.float16, device=k.device)
+    vp[:, :, :T] = vt[:, :, :T]
+    lane = torch.arange(64, device=k.device)
+    m, q = lane % 16, lane // 16
+    j = torch.arange(8, device=k.device)
+    for w in range(nw):
+        for hh in range(hpw):
+            c_h = 80 * w + D * hh
+            s0 = c_h // 32
+            f0 = hh * fr_head
+            for ks in range(qks):
+                for t in range(5):
+                    ch = 32 * (s0 + ks) + 8 * q[:, None] + j[None, :]                  # [64][8]
+                    val = kp[:, (16 * t + m)[:, None].expand(64, 8), ch]              # [B][64][8]
+                    inside = (ch >= c_h) & (ch < c_h + D)
+                    out[:, w, f0 + ks * 5 + t] = torch.where(inside[None], val, torch.zeros_like(val))
+            tlo = 2 if (D == 40 and hh == 1) else 0
+            for ks in range(3):
+                for tv in range(vtiles):
+                    chv = 80 * w + 16 * (tlo + tv) + m                                 # [64]
+                    key = 32 * ks + 8 * q[:, None] + j[None, :]
+                    val = vp[:, chv[:, None].expand(64, 8), key]
+                    inside = ((chv >= c_h) & (chv < c_h + D))[:, None].expand(64, 8)
+                    out[:, w, f0 + 5 * qks + ks * vtiles + tv] = torch.where(inside[None], val, torch.zeros_like(val))
+    return out
+
+
 def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str] = None, nsplit: int = 1):
     """Weights of one 320- or 640-channel Transformer2D block `p` (e.g. "down_blocks.0.attentions.0.") as rowchain.hip consumes them:
     (wstream [C / 80 waves][fragments][64][8] fp16 in exact consumption order + RC_RPAD fragments of padding, vec fp32).

@@ -429,3 +429,26 @@ def test_layernorm_fold_and_gemm_wreg_packing_on_the_host():
             n = 64 * nt * j + 16 * nt * wv + 16 * t + (l & 15)
             k = 32 * ks + 8 * (l >> 4)
             assert torch.equal(f[j, wv, ks, t, l], W[n, k:k + 8])
+
+
+@pytest.mark.parametrize("C,T", [(320, 77), (640, 17), (320, 80)])
+def test_rowchain_kv_stream_layout_holds_every_context_value_once(C, T):
+    """weights.pack_rowchain_kv (the host statement of bc_rowchain_pack_kv's layout, compared with the kernel in tests/test_rowchain_gpu.py):
+    every K / V^T value of the T tokens sits in exactly one lane slot of its head's fragments, everything else - other heads' channels
+    inside a shared k-step, keys >= T, the padding fragments - is zero."""
+    import torch
+    from blobctrl_amd.weights import pack_rowchain_kv
+    B = 2
+    k = torch.randint(1, 9, (B, T, C)).half()             # positive integers: sums are exact and no value is zero
+    vt = torch.randint(1, 9, (B, C, 96)).half()
+    o = pack_rowchain_kv(k, vt, T)
+    D = C // 8
+    hpw, qks, vtl = 80 // D, (2 if D == 40 else 3), (3 if D == 40 else 5)
+    fh = 5 * qks + 3 * vtl
+    assert o.shape == (B, C // 80, hpw * fh + 20, 64, 8) and float(o[:, :, hpw * fh:].abs().sum()) == 0.0
+    for hh in range(hpw):
+        kpart, vpart = o[:, :, hh * fh: hh * fh + 5 * qks], o[:, :, hh * fh + 5 * qks: (hh + 1) * fh]
+        for w in range(C // 80):
+            ch = slice(80 * w + D * hh, 80 * w + D * (hh + 1))
+            assert int((kpart[:, w] != 0).sum()) == B * T * D and float(kpart[:, w].double().sum()) == float(k[:, :, ch].double().sum())
+            assert int((vpart[:, w] != 0).sum()) == B * T * D and float(vpart[:, w].double().sum()) == float(vt[:, ch, :T].double().sum())

@@ -106,6 +106,26 @@ def test_cross_attention_inside_the_mid_launch(monkeypatch, B, H, W, C, T):
     assert rel_u < 6e-3 and psnr(a, c) > 50.0
 
 
+@pytest.mark.parametrize("C,T,B", [(320, 77, 2), (640, 77, 2), (320, 80, 1), (640, 5, 1)])
+def test_kv_stream_kernel_equals_the_host_packing(C, T, B):
+    """bc_rowchain_pack_kv (device) and weights.pack_rowchain_kv (host statement of the layout) write the same fragment streams."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import pack_rowchain_kv
+    lib = _lib.load()
+    ldvt = 128
+    k = (g(31, B, T, C) * 2).half().cuda()
+    vt = (g(32, B, C, ldvt) * 2).half().cuda()
+    frags = lib.bc_rowchain_kv_frags(C)
+    out = torch.full((B * (C // 80) * frags * 64 * 8,), 7.0, dtype=torch.float16, device="cuda:0")
+    _lib.check(lib.bc_rowchain_pack_kv(k.data_ptr(), C, vt.data_ptr(), ldvt, B, T, C, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               "bc_rowchain_pack_kv")
+    torch.cuda.synchronize()
+    ref = pack_rowchain_kv(k, vt, T)
+    assert ref.numel() == out.numel() and torch.equal(out.view_as(ref).cpu(), ref.cpu())
+    with pytest.raises(_lib.BlobCtrlHipError):
+        _lib.check(lib.bc_rowchain_pack_kv(k.data_ptr(), C, vt.data_ptr(), ldvt, B, 81, C, out.data_ptr(), 0), "bc_rowchain_pack_kv")
+
+
 def test_rowchain_rejects_unsupported_shapes():
     from blobctrl_amd import _lib
     lib = _lib.load()
