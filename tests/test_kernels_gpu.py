@@ -328,7 +328,11 @@ def test_layernorm(rec, rows, Cc):
 # ---------------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,heads,d,Nq,Nkv", [(2, 8, 40, 512, 512), (1, 8, 80, 256, 256), (2, 8, 160, 128, 128),
                                               (2, 8, 40, 300, 77), (1, 8, 160, 128, 77), (2, 4, 64, 257, 257),
-                                              (2, 2, 8, 128, 128), (1, 2, 16, 32, 7), (1, 2, 32, 8, 8), (1, 8, 80, 200, 77)])
+                                              (2, 2, 8, 128, 128), (1, 2, 16, 32, 7), (1, 2, 32, 8, 8), (1, 8, 80, 200, 77),
+                                              # D = 160 at the 16 x 32 level's 512 tokens, a ragged query block, fewer keys than one tile, ragged
+                                              # last tiles
+                                              (2, 8, 160, 512, 512), (1, 8, 160, 77, 512), (1, 2, 160, 40, 5), (1, 2, 160, 64, 1000),
+                                              (1, 2, 160, 64, 1100)])
 def test_attention(rec, B, heads, d, Nq, Nkv):
     Cc = heads * d
     q, k, v = g(1, B, Nq, Cc), g(2, B, Nkv, Cc), g(3, B, Nkv, Cc)
@@ -369,6 +373,26 @@ def test_attention_large_ragged_uses_128_vgpr_build(rec, eight_waves, monkeypatc
             ref = torch.softmax(qf @ kf.t() * d ** -0.5, -1) @ vf
             worst = max(worst, float((out[b, :, sl].float() - ref).abs().max()))
     assert worst < 2e-3, f"max abs err {worst:.3e}"
+
+
+def test_attention_d160_key_ranges_with_very_different_maxima(rec):
+    """D = 160: key ranges whose score maxima differ by tens of log2 units, the larger ones late in the sequence (the running reference
+    moves twice).  (Scores stay below ~25: the scale rides in the fp16 query, so a score's absolute error grows with its size.)"""
+    B, heads, d, N = 1, 2, 160, 256
+    Cc = heads * d
+    q, k, v = g(1, B, N, Cc), g(2, B, N, Cc), g(3, B, N, Cc)
+    k[:, 32:64] *= 3.0
+    k[:, 224:256] *= 5.0
+    ldvt = 256
+    vt = torch.zeros(B, Cc, ldvt, dtype=torch.float16)
+    vt[:, :, :N] = v.half().transpose(1, 2)
+    out = run(rec, lambda: rec.attention(h(q), h(k), vt.cuda(), rec.empty(B, N, Cc), B, heads, d, N, N, Cc, Cc, ldvt, Cc,
+                                         N * Cc, N * Cc, Cc * ldvt, N * Cc, d ** -0.5))
+    qf = q.half().float().view(B, N, heads, d).transpose(1, 2)
+    kf = k.half().float().view(B, N, heads, d).transpose(1, 2)
+    vf = v.half().float().view(B, N, heads, d).transpose(1, 2)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, N, Cc)
+    close(out, ref, rtol=2e-3, atol=3e-3, what="attention d=160 with uneven key ranges")
 
 
 def test_attention_online_softmax_rescale(rec):
