@@ -16,7 +16,8 @@ namespace bcplan {
 
 constexpr int kMaxStreams = 8;
 const uint32_t kMagic = 0x4E4C5042u;   // "BPLN"
-const uint32_t kVersion = 2;           // 2: BcGemm grew ln_colsum / C_t, GroupNorm statistics totals (round 4)
+const uint32_t kVersion = 3;           // 2: BcGemm grew ln_colsum / C_t, GroupNorm statistics totals; 3: + BC_OP_ROWCHAIN_MIDX / _PACK_KV (round 4)
+const uint32_t kOldestReadable = 2;    // (a version-2 file holds a subset of version 3's records)
 
 // argument kinds of the recordable entry points (stream argument excluded): p = device pointer, i = int, f = float, l = long long
 inline const char* op_signature(int op) {
@@ -107,7 +108,7 @@ inline std::string parse_plan(FILE* f, PlanImage& img, const std::function<uint6
     rewind(f);
     constexpr uint64_t kMaxArena = 1ull << 40;       // 1 TiB: far above any real plan, far below overflow of the running sum
     if (rd.u32() != kMagic) return "not a plan file";
-    if (rd.u32() != kVersion) return "unsupported plan version";
+    { const uint32_t v = rd.u32(); if (v < kOldestReadable || v > kVersion) return "unsupported plan version"; }
     if (rd.u32() != sizeof(BcGemm)) return "BcGemm layout differs from this library build";
     const uint32_t nb = rd.u32();
     if (!rd.ok || nb > (1u << 20)) return "corrupt header";

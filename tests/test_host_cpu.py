@@ -251,7 +251,7 @@ def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
     assert seq == ["step_active"] * 4 + ["step_inactive"] * 2
     raw = open(path, "rb").read()
     magic, version, gsz, nbuf = struct.unpack("<IIII", raw[:16])
-    assert magic == 0x4E4C5042 and version == 2 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
+    assert magic == 0x4E4C5042 and version == 3 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
     for name in (b"latents", b"ctx", b"fg_lat", b"bg_lat", b"fg_score", b"bg_score", b"feat16", b"step_idx", b"coef", b"hist"):
         assert name in raw
     P = eng.plan_for(1, 8, 8, 7, TINY["ctx"], 6)
