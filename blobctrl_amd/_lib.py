@@ -101,6 +101,7 @@ _SIGNATURES = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                               C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "bc_rowchain_sum": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bc_rowchain_kv_frags": (C.c_longlong, [C.c_int]),
     "bc_rowchain_pack_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_rowchain_midx": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
@@ -122,6 +123,7 @@ _SIGNATURES = {
     "bc_plan_capture_loop": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "bc_plan_run_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "bc_plan_run_timed_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bc_plan_run_marked": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_float)]),
     "bc_plan_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]),
     "bc_plan_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bc_plan_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
@@ -146,9 +148,9 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
        "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23, "bc_memset_zero": 24,
-       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26}
+       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26, "bc_rowchain_sum": 27}
 OP_SIGNAL, OP_WAIT = 20, 21
-CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL, CHAIN_MIDX = 0, 1, 2, 3, 4, 5
+CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL, CHAIN_MIDX, CHAIN_OUT_FFP = 0, 1, 2, 3, 4, 5, 6
 GN_TOT_WORDS = 6                      # 64-bit words per (image, channel) of a GroupNorm statistics table (include/blobctrl_hip.h)
 _KIND = {C.c_void_p: "p", C.c_int: "i", C.c_float: "f", C.c_longlong: "l", C.c_char_p: "p"}
 

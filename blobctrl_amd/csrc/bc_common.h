@@ -72,12 +72,14 @@ __device__ __forceinline__ float bc_quick_gelu_f(float x) { return x / (1.0f + _
 // Per (image, channel) BC_GN_TOT_WORDS 64-bit integer accumulators: the sum and the sum of squares of the fp16 activation, each as three
 // signed 40-bit slices of a fixed-point number (units 2^-60, 2^-20, 2^20).  Every producer workgroup reduces its rows in fp32 as
 // before and then ADDS that partial with integer atomics: integer addition commutes, so the totals - and everything downstream - are
-// bit-reproducible whatever the arrival order (an fp32 partial of up to 2^58 in magnitude converts exactly; the slices cannot
-// overflow below 2^23 addends).  Consumers read six words per channel instead of re-reducing `nslab` partials, and no finalize launch
+// bit-reproducible whatever the arrival order (an fp32 partial below 2^50 in magnitude converts exactly - fp16 activations give at
+// most 2^46 per workgroup partial -; the slices cannot overflow below 2^14 addends).  A non-finite or absurd partial adds the POISON
+// 2^50 to slice 2 instead: honest slice-2 sums stay below 2^44 in magnitude, so any count of 1 ... 8191 poisoned addends leaves
+// |slice 2| >= 2^45 (the round-4 poison 2^60 cancelled itself after 16 addends); bc_gn_tot_read turns that into NaN.  Consumers read six words per channel instead of re-reducing `nslab` partials, and no finalize launch
 // sits between a producer and a fused consumer.  The tables are zeroed once per replay (bc_memset_zero at the head of a segment).
 __device__ __forceinline__ void bc_gn_slices(float v, long long (&sl)[3]) {
-    if (!(fabsf(v) < 2.8e17f)) {                       // inf / NaN / absurd: poison the total (consumers turn it into NaN)
-        sl[0] = 0; sl[1] = 0; sl[2] = 1ll << 60;
+    if (!(fabsf(v) < 1.1e15f)) {                       // inf / NaN / absurd: poison the total (consumers turn it into NaN)
+        sl[0] = 0; sl[1] = 0; sl[2] = 1ll << 50;
         return;
     }
     const double d = (double)v;
@@ -99,13 +101,18 @@ __device__ __forceinline__ void bc_gn_tot_add(unsigned long long* t, float s, fl
         if (b[i]) __hip_atomic_fetch_add(t + 3 + i, (unsigned long long)b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// (sum, sum of squares) of one channel; a poisoned total reads as NaN
-__device__ __forceinline__ void bc_gn_tot_read(const unsigned long long* t, double& s, double& q) {
-    const long long a0 = (long long)t[0], a1 = (long long)t[1], a2 = (long long)t[2];
-    const long long b0 = (long long)t[3], b1 = (long long)t[4], b2 = (long long)t[5];
+// (sum, sum of squares) of one channel from its six words; a poisoned total reads as NaN
+__device__ __forceinline__ void bc_gn_tot_decode(unsigned long long w0, unsigned long long w1, unsigned long long w2, unsigned long long w3,
+                                                 unsigned long long w4, unsigned long long w5, double& s, double& q) {
+    const long long a0 = (long long)w0, a1 = (long long)w1, a2 = (long long)w2;
+    const long long b0 = (long long)w3, b1 = (long long)w4, b2 = (long long)w5;
     s = (double)a0 * 8.673617379884035e-19 + (double)a1 * 9.5367431640625e-07 + (double)a2 * 1048576.0;
     q = (double)b0 * 8.673617379884035e-19 + (double)b1 * 9.5367431640625e-07 + (double)b2 * 1048576.0;
-    if (a2 >= (1ll << 50) || b2 >= (1ll << 50) || a2 <= -(1ll << 50)) { s = __builtin_nan(""); q = s; }
+    const long long lim = 1ll << 45;
+    if (a2 >= lim || a2 <= -lim || b2 >= lim || b2 <= -lim) { s = __builtin_nan(""); q = s; }
+}
+__device__ __forceinline__ void bc_gn_tot_read(const unsigned long long* t, double& s, double& q) {
+    bc_gn_tot_decode(t[0], t[1], t[2], t[3], t[4], t[5], s, q);
 }
 
 __device__ __forceinline__ uint4 bc_ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }

@@ -103,9 +103,14 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     unsigned long long* const stamps = g.halo_stamps;        // BC_WREG_STAMPS diagnostics (null in production): waves 0 (three tiles) and 2 (staging)
     auto stamp = [&](int i) {
         if (stamps && lane == 0 && (wave == 0 || wave == 2))
-            stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + (wave >> 1)) * 8 + i] = __builtin_amdgcn_s_memtime();
+            stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + (wave >> 1)) * 16 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    // The time-embedding row of a captured step sits in a per-edit table behind a device-side step counter.  The counter is fetched
+    // with a SCALAR load (lgkmcnt): as a vector load its wait (vmcnt is in-order) sat in front of, or behind, everything the prologue
+    // requests - an exposed memory round trip before the halo rows were even asked for.
+    unsigned rv_idx = 0;
+    if (p.rowvec && p.rowvec_idx) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(rv_idx) : "s"(p.rowvec_idx) : "memory");
 
     const h16* __restrict__ A1 = reinterpret_cast<const h16*>(p.A);
     const h16* __restrict__ A2 = reinterpret_cast<const h16*>(p.A2);
@@ -236,12 +241,131 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         // Request order = order of use: the first two halo images, ring group 0, the tables; then the rest of chunk 0's weights.  (A
         // workgroup's first requests - 48 KiB of halo rows + 144-216 KiB of weights - take ~5000 cycles at the per-CU fetch rate: the
         // first MFMA waits only for what it needs.)
+        // AFFINE == 2, channel span <= FIN_FAST_CH (round 5): the finalize no longer waits for the halo rows and the first weight fragments.
+        // Its inputs (statistics totals, gamma, beta) are requested FIRST by the three-tile waves with inline-asm loads and waited for with
+        // a counted vmcnt - vector-memory operations return in issue order, so they land ahead of everything requested behind them -
+        // and only those waves compute: they issue no LDS-DMA, so hipcc has no reason to drain the memory counter in front of their
+        // plain LDS accesses, and the two barriers inside are LDS-only (a __syncthreads() waits for vmcnt(0): in round 4 the first one
+        // waited for 48 KiB of halo rows + the first ring group, and the rest of chunk 0's weights was requested behind the whole finalize:
+        // 21k cycles to the first MFMA against 10k with a finalize launch - BC_WREG_STAMPS).
+        constexpr int FIN_T = 4;                                  // channels per finalize thread (256 of them)
+        const int fin_cpg = AFFINE == 2 ? p.Cin / p.a_groups : 1;
+        const int fin_k_lo = c_begin * 64, fin_k_hi = fin_k_lo + nch * 64;
+        const int fin_g_lo = fin_k_lo / fin_cpg, fin_g_hi = AFFINE == 2 ? min(p.a_groups, (fin_k_hi + fin_cpg - 1) / fin_cpg) : 1;
+        const int fin_c_lo = fin_g_lo * fin_cpg, fin_nc = fin_g_hi * fin_cpg - fin_c_lo;
+        const bool fin_fast = AFFINE == 2 && fin_nc <= 256 * FIN_T && !(g.halo_dbg & 0x100);   // (workgroup-uniform; nch * 64 <= fin_nc; BC_WREG_FIN_SLOW=1: the round-4 form)
+        const int ft = ((wave < 2 ? wave : wave - 4) << 6) | lane;        // finalize thread id: waves 0, 1, 6, 7
+        u32x4v fq[FIN_T][3];
+        float fg[FIN_T], fb[FIN_T];
+        if (AFFINE == 2 && !STG && fin_fast) {
+            // (the two table pointers are pinned in scalar registers: a per-lane select between two kernel-argument FIELDS makes hipcc
+            //  select the field's address and fetch the pointer itself with a vector load - an exposed round trip per channel)
+            unsigned long long tp1 = (unsigned long long)p.a_tot1, tp2 = (unsigned long long)(p.A2 ? p.a_tot2 : p.a_tot1);
+            asm volatile("" : "+s"(tp1), "+s"(tp2));
+            const int C1s = p.A2 ? p.C1 : p.Cin, C2s = p.Cin - C1s;      // channels of the first / second source
+#pragma unroll
+            for (int j = 0; j < FIN_T; ++j) {
+                const int cc = ft + 256 * j;
+                const int c = fin_c_lo + (cc < fin_nc ? cc : 0);
+                const bool second = c >= C1s;
+                const unsigned long long ta = (second ? tp2 : tp1) + ((unsigned long long)((long long)b * (second ? C2s : C1s) + (second ? c - C1s : c))) * (BC_GN_TOT_WORDS * 8);
+                const unsigned long long* t = reinterpret_cast<const unsigned long long*>(ta);
+                asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32"
+                             : "=&v"(fq[j][0]), "=&v"(fq[j][1]), "=&v"(fq[j][2]) : "v"(t) : "memory");
+                const int i = ft + 256 * j;                               // table entry (channel fin_k_lo + i) this thread writes
+                const int ci = fin_k_lo + (i < nch * 64 ? i : 0);
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(fg[j]), "=&v"(fb[j]) : "v"(p.a_gamma + ci), "v"(p.a_beta + ci) : "memory");
+            }
+        }
+        stamp(8);
         if (STG) {
             issue_a(0, 0, true);
             issue_a(1, 1, nch > 1);
         }
         BC_WREG_LOAD_GROUP(0, wb)
-        if (AFFINE == 2) {
+        stamp(9);
+        if (AFFINE == 2 && fin_fast && !STG) {
+            // the totals have landed (younger: this wave's ring group 0)
+#define BC_FIN_TIE(j) "+v"(fq[j][0]), "+v"(fq[j][1]), "+v"(fq[j][2])
+            asm volatile("s_waitcnt vmcnt(%12)" : BC_FIN_TIE(0), BC_FIN_TIE(1), BC_FIN_TIE(2), BC_FIN_TIE(3) : "n"(G) : "memory");
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(fg[0]), "+v"(fg[1]), "+v"(fg[2]), "+v"(fg[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3])
+                         : "n"(G) : "memory");
+#undef BC_FIN_TIE
+        }
+        // bias and the time-embedding row of this image (epilogue): requested here - behind the finalize's counted wait, ahead of ring
+        // groups 1 and 2 -, stored to LDS behind the first in-place pass.  Branch-free, raw bits: a conditional load or an immediate
+        // fp16 -> fp32 conversion makes hipcc wait for it on the spot.
+        stamp(10);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rv_idx)::"memory");
+        const bool eok = p.splitk == 1 && tid < HBN;
+        const float* epi_bp = (eok && p.bias) ? p.bias + n0 + tid : reinterpret_cast<const float*>(g_zero_line_w);
+        const h16* epi_rp = (eok && p.rowvec) ? reinterpret_cast<const h16*>(p.rowvec) + (size_t)rv_idx * p.rowvec_step + (size_t)b * p.ld_rowvec + n0 + tid : zero;
+        const float epi_bv = *epi_bp;
+        const unsigned short epi_rraw = *reinterpret_cast<const unsigned short*>(epi_rp);
+        if (AFFINE == 2 && fin_fast) {
+            double* scr = reinterpret_cast<double*>(smem + OFF_FIN);           // [nc][2] = (sum, sum of squares) per channel
+            float* stat = reinterpret_cast<float*>(scr + fin_nc * 2);          // [groups][2] = (mean, rstd)
+            if (!STG) {
+#pragma unroll
+                for (int j = 0; j < FIN_T; ++j) {
+                    const int cc = ft + 256 * j;
+                    if (cc < fin_nc) {
+                        double s_, q_;
+                        auto w64 = [](unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); };
+                        bc_gn_tot_decode(w64(fq[j][0][0], fq[j][0][1]), w64(fq[j][0][2], fq[j][0][3]), w64(fq[j][1][0], fq[j][1][1]),
+                                         w64(fq[j][1][2], fq[j][1][3]), w64(fq[j][2][0], fq[j][2][1]), w64(fq[j][2][2], fq[j][2][3]), s_, q_);
+                        scr[cc * 2] = s_;
+                        scr[cc * 2 + 1] = q_;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stamp(11);
+            if (!STG) {   // eight lanes per group: 32 groups per pass of the four finalize waves, fixed summation order
+                const int sub = ft & 7;
+                for (int gi = fin_g_lo + (ft >> 3); gi < fin_g_hi; gi += 32) {
+                    double s_ = 0.0, q_ = 0.0;
+                    for (int cj = sub; cj < fin_cpg; cj += 8) {
+                        s_ += scr[((gi - fin_g_lo) * fin_cpg + cj) * 2];
+                        q_ += scr[((gi - fin_g_lo) * fin_cpg + cj) * 2 + 1];
+                    }
+#pragma unroll
+                    for (int o = 4; o > 0; o >>= 1) {
+                        s_ += __shfl_xor(s_, o);
+                        q_ += __shfl_xor(q_, o);
+                    }
+                    const double n = (double)g.div_rpb.d * fin_cpg;
+                    const double mean = s_ / n;
+                    double var = q_ / n - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    if (sub == 0) {
+                        stat[(gi - fin_g_lo) * 2] = (float)mean;
+                        stat[(gi - fin_g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stamp(12);
+            if (!STG) {
+                float* abt = reinterpret_cast<float*>(smem + OFF_AB);
+#pragma unroll
+                for (int j = 0; j < FIN_T; ++j) {
+                    const int i = ft + 256 * j;
+                    if (i < nch * 64) {
+                        const int gi = (fin_k_lo + i) / fin_cpg - fin_g_lo;
+                        const float a = stat[gi * 2 + 1] * fg[j];
+                        abt[i * 2] = a;
+                        abt[i * 2 + 1] = fb[j] - stat[gi * 2] * a;
+                    }
+                }
+            }
+            stamp(13);
+            // (no barrier here: the table is read behind the "raw rows visible" barrier below)
+        } else if (AFFINE == 2) {
             // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the statistics totals (six
             // words per channel, order-independent integer sums: bc_common.h), while the first halo rows and weight fragments are in
             // flight.  Scratch behind the loop's LDS (the halo images are already being written).
@@ -315,25 +439,10 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             }
             __syncthreads();                                              // (the scratch overlaps the epilogue vectors staged next)
         }
-        {   // affine table of the chunk range, bias and time-embedding row of this image -> LDS: all global loads first, then the stores
+        if (AFFINE == 1) {   // affine table of the chunk range (bc_gn_finalize ran) -> LDS
             const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
             float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
-            const bool tok = AFFINE == 1 && tid < nch * 32, eok = p.splitk == 1 && tid < HBN;
-            float4 tv = {0.f, 0.f, 0.f, 0.f};
-            float bv = 0.f, rv = 0.f;
-            if (tok) tv = src[tid];
-            if (eok) {
-                if (p.bias) bv = p.bias[n0 + tid];
-                if (p.rowvec) rv = (float)(rowvec_base(p) + (size_t)b * p.ld_rowvec)[n0 + tid];
-            }
-            if (tok) dst[tid] = tv;
-            if (AFFINE == 1)
-                for (int i = tid + 512; i < nch * 32; i += 512) dst[i] = src[i];
-            if (eok) {                                            // (the epilogue finds them in LDS)
-                float* ev = reinterpret_cast<float*>(smem + OFF_EPI);
-                ev[tid] = bv;
-                ev[HBN + tid] = rv;
-            }
+            for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
         }
         BC_WREG_LOAD_GROUP(1, wb)
         BC_WREG_LOAD_GROUP(2, wb)
@@ -344,6 +453,11 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         asm volatile("" ::: "memory");
         stamp(6);
         if (AFFINE) transform_first();
+        if (eok) {                                                // (the epilogue finds them in LDS; the region is clear of the finalize's scratch by now)
+            float* ev = reinterpret_cast<float*>(smem + OFF_EPI);
+            ev[tid] = epi_bv;
+            ev[HBN + tid] = (float)__builtin_bit_cast(h16, epi_rraw);
+        }
         stamp(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // halo image 0 complete
@@ -666,7 +780,8 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;
-    g.halo_dbg = 0;
+    static const int fin_slow = getenv("BC_WREG_FIN_SLOW") ? 0x100 : 0;        // diagnostics: the round-4 in-prologue finalize (every wave, three __syncthreads)
+    g.halo_dbg = fin_slow;
     g.halo_stamps = nullptr;
     int sk = std::max(1, std::min(p.splitk, g.halo_nch));
     g.halo_cps = bc_ceil_div(g.halo_nch, sk);
@@ -687,8 +802,8 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     static unsigned long long* stamp_buf = nullptr;
     const size_t nwg_s = (size_t)grid.x * grid.y * grid.z;
     if (want_stamps && nwg_s <= 4096) {
-        if (!stamp_buf) BC_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&stamp_buf), 4096 * 16 * sizeof(unsigned long long)));
-        BC_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, nwg_s * 16 * sizeof(unsigned long long), stream));
+        if (!stamp_buf) BC_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&stamp_buf), 4096 * 32 * sizeof(unsigned long long)));
+        BC_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, nwg_s * 32 * sizeof(unsigned long long), stream));
         g.halo_stamps = stamp_buf;
     }
     struct StampReport {
@@ -696,19 +811,27 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
         ~StampReport() {
             if (!buf) return;
             if (hipStreamSynchronize(stream) != hipSuccess) return;
-            std::vector<unsigned long long> h(n * 16);
-            if (hipMemcpy(h.data(), buf, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+            std::vector<unsigned long long> h(n * 32);
+            if (hipMemcpy(h.data(), buf, n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
             for (int w = 0; w < 2; ++w) {
                 double d[5] = {0, 0, 0, 0, 0};
                 for (size_t i = 0; i < n; ++i)
-                    for (int k = 0; k < 5; ++k) d[k] += (double)(h[(i * 2 + w) * 8 + k + 1] - h[(i * 2 + w) * 8 + k]);
+                    for (int k = 0; k < 5; ++k) d[k] += (double)(h[(i * 2 + w) * 16 + k + 1] - h[(i * 2 + w) * 16 + k]);
                 double e[3] = {0, 0, 0};                              // stamp 1 -> 6 (landing + barrier), 6 -> 7 (first in-place pass), 7 -> 2
                 for (size_t i = 0; i < n; ++i) {
-                    const unsigned long long* q = &h[(i * 2 + w) * 8];
+                    const unsigned long long* q = &h[(i * 2 + w) * 16];
                     e[0] += (double)(q[6] - q[1]);
                     e[1] += (double)(q[7] - q[6]);
                     e[2] += (double)(q[2] - q[7]);
                 }
+                double pr[6] = {0, 0, 0, 0, 0, 0};                   // prologue detail: stamps 8..13 relative to stamp 0 (0 where not taken)
+                for (size_t i = 0; i < n; ++i)
+                    for (int k = 0; k < 6; ++k) {
+                        const unsigned long long* q = &h[(i * 2 + w) * 16];
+                        if (q[8 + k]) pr[k] += (double)(q[8 + k] - q[0]);
+                    }
+                fprintf(stderr, "[wreg stamps] prologue detail (ticks since entry): inputs requested %.0f, ring group 0 requested %.0f, totals landed %.0f, "
+                        "barrier 1 %.0f, barrier 2 %.0f, table written %.0f\n", pr[0] / n, pr[1] / n, pr[2] / n, pr[3] / n, pr[4] / n, pr[5] / n);
                 fprintf(stderr, "[wreg stamps] M=%d N=%d Cin=%d sk=%d cps=%d wgs=%zu %s | avg ticks: setup+table %.0f, first halo %.0f (landing %.0f, pass %.0f, "
                         "next DMA + barrier %.0f), loop %.0f (%.0f per tap), k-half sum %.0f, stores %.0f\n", p.M, p.N, p.Cin, p.splitk, cps, n,
                         w ? "staging wave " : "3-tile wave  ", d[0] / n, d[1] / n, e[0] / n, e[1] / n, e[2] / n, d[2] / n, d[2] / n / (cps * 9), d[3] / n, d[4] / n);

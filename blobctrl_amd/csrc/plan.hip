@@ -91,6 +91,8 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
                                     MP(bc_half, 10), MP(bc_half, 11), F(12), s);
         case BC_OP_ROWCHAIN_PACK_KV:
             return bc_rowchain_pack_kv(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), I(6), MP(bc_half, 7), s);
+        case BC_OP_ROWCHAIN_SUM:
+            return bc_rowchain_sum(I(0), I(1), I(2), CP(bc_half, 3), I(4), MP(bc_half, 5), MP(unsigned long long, 6), MP(bc_half, 7), s);
         case BC_OP_GN_APPLY:
             return bc_gn_apply(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), CP(float, 6), I(7), MP(bc_half, 8), s);
         case BC_OP_LAYERNORM:
@@ -389,6 +391,36 @@ extern "C" int bc_plan_run_timed_kernels(BcPlan* pl, int seg, bc_stream stream, 
                 ms_reduce[i] = 0.f;
             }
         }
+    }
+    return rc;
+}
+
+// Concurrent replay with sparse timestamps (round 5, tools/concurrent_timeline.py): the segment is replayed eagerly on its own streams -
+// the two queues overlap as they do inside the graph - and a timing event is recorded on the launch's OWN stream behind each launch listed
+// in `marks` (ascending launch indices); ms_out[k] = time from the start of the replay (an event on stream 0, in front of the fork) to
+// that event.  A few dozen marks cost nothing measurable; an event behind EVERY launch would add ~5 us each and distort the overlap.
+extern "C" int bc_plan_run_marked(BcPlan* pl, int seg, const bc_stream* streams, int nstreams, const int* marks, int nmarks, float* ms_out) {
+    SEG(pl, seg);
+    BC_CHECK_ARG(marks != nullptr && ms_out != nullptr && nmarks >= 0, "bc_plan_run_marked: bad arguments");
+    hipStream_t st[kMaxStreams];
+    int rc = get_streams(pl, streams, nstreams, st);
+    if (rc) return rc;
+    EventSet ev((size_t)nmarks + 1);
+    for (auto& e : ev.ev) BC_CHECK_HIP(hipEventCreate(&e));
+    BC_CHECK_HIP(hipEventRecord(ev[0], st[0]));
+    int k = 0;
+    for (size_t i = 0; i < sg.recs.size() && !rc; ++i) {
+        Rec& r = sg.recs[i];
+        if (r.enabled) rc = launch_rec(pl, r, st, kMaxStreams);
+        while (k < nmarks && marks[k] == (int)i) {
+            BC_CHECK_HIP(hipEventRecord(ev[1 + k], st[r.sid < kMaxStreams ? r.sid : 0]));
+            ++k;
+        }
+    }
+    BC_CHECK_ARG(rc || k == nmarks, "bc_plan_run_marked: marks must be ascending launch indices of the segment");
+    if (!rc) {
+        for (int i = 0; i < kMaxStreams; ++i) BC_CHECK_HIP(hipStreamSynchronize(st[i]));
+        for (int j = 0; j < nmarks; ++j) BC_CHECK_HIP(hipEventElapsedTime(&ms_out[j], ev[0], ev[1 + j]));
     }
     return rc;
 }

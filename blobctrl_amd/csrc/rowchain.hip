@@ -492,10 +492,16 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     // OUT_FF: nsplit workgroups share a row block, each with its own slice of the hidden chunks (and its own weight stream)
-    constexpr bool FF = KIND == BC_CHAIN_OUT_FF, TAIL = KIND == BC_CHAIN_OUT_TAIL;
+    // OUT_FFP (round 5): OUT_FF that goes on THROUGH proj_out [and the zero-conv] on its own partial sum - both are linear, so the sum over
+    // the slices moves behind them and OUT_TAIL's GEMMs run on nsplit times as many CUs; what is left is an elementwise sum of nsplit
+    // fp16 partial outputs (rowchain_sum_kernel).  Its slices are SLICE-MAJOR in the remapped workgroup id: an XCD holds the workgroups
+    // of one slice (nsplit = 4: two XCDs per slice), so its L2 fetches one quarter of the feed-forward weights instead of all of them.
+    constexpr bool FFP = KIND == BC_CHAIN_OUT_FFP;
+    constexpr bool FF = KIND == BC_CHAIN_OUT_FF || FFP, TAIL = KIND == BC_CHAIN_OUT_TAIL;
     const int wg = bc_xcd_remap(blockIdx.x, gridDim.x);
-    const int z = FF ? wg % a.nsplit : 0;
-    const int m0 = (FF ? wg / a.nsplit : wg) * RC_BM;
+    const int nrb = a.M / RC_BM;
+    const int z = FFP ? wg / nrb : (FF ? wg % a.nsplit : 0);
+    const int m0 = (FFP ? wg % nrb : (FF ? wg / a.nsplit : wg)) * RC_BM;
     const int b = m0 / a.rows_per_batch;
     const int pix0 = m0 - b * a.rows_per_batch;
     const int xfo = m * 64 + ((q ^ ((0 - (m >> 2)) & 3)) << 4);        // this lane's fragment offset inside a (k-step, row-tile) KiB
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
         stamps[(size_t)blockIdx.x * 16 + 9] = acc_t[1];
         stamps[(size_t)blockIdx.x * 16 + 10] = acc_t[2];
     }
-    if (FF) {                                                            // this slice's partial sum (fp32), one 16-byte store per tile
+    if (KIND == BC_CHAIN_OUT_FF) {                                       // this slice's partial sum (fp32), one 16-byte store per tile
         float* dst = a.part + ((size_t)z * a.M + m0) * RC_C + 80 * wave + 4 * q;
 #pragma unroll
         for (int t = 0; t < RC_NT; ++t)
@@ -822,10 +828,12 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
 #define q q_
 #define xfo xfo_
 #define cm cm_
-    epi_bias_res<RC_C, false>(acc, vec + 3 * RC_C + 8 * RC_C, S, wave, m, q);  // + ff.net.2 bias -> h3
+    // OUT_FFP: everything that is NOT linear in the partial sum (biases, the block input x, the BlobNet residual) belongs to slice 0 only
+    const bool first = !FFP || z == 0;                                   // (workgroup-uniform)
+    if (first) epi_bias_res<RC_C, false>(acc, vec + 3 * RC_C + 8 * RC_C, S, wave, m, q);  // + ff.net.2 bias -> h3
     lds_barrier();                                                      // every wave is done with the last hidden chunk (S) and with X
     acc_to_X(acc, X, wave, m, q);
-    rows_to_S<RC_C>(a.res2 + (size_t)m0 * RC_C, S, cm);
+    if (first) rows_to_S<RC_C>(a.res2 + (size_t)m0 * RC_C, S, cm);
     lds_barrier();
     zero_acc(acc);
     constexpr int POS_PO = TAIL ? 0 : (RC_NT * RC_KS) % RC_R;           // (the feed-forward consumed whole rings; OUT_TAIL's stream starts here)
@@ -833,8 +841,8 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     gemm_seg<RC_NT, RC_KS, POS_PO, true>(acc, ring, X + xfo);          // proj_out
     stamp(6);
     const float* bpo = vec + 3 * RC_C + 8 * RC_C + RC_C;
-    epi_bias_res<RC_C, true>(acc, bpo, S, wave, m, q);                        // + bias + x
-    if (a.r2) {                                                          // + BlobNet residual on the right-hand part of the canvas
+    if (first) epi_bias_res<RC_C, true>(acc, bpo, S, wave, m, q);             // + bias + x
+    if (a.r2 && first) {                                                 // + BlobNet residual on the right-hand part of the canvas
         const bool any = ((pix0 % a.out_w) + RC_BM > a.r2_xmin) || (pix0 % a.out_w) + RC_BM > a.out_w;
         if (any) {                                                       // (workgroup-uniform)
             lds_barrier();
@@ -846,8 +854,11 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     lds_barrier();
     acc_to_S<RC_C>(acc, S, wave, m, q);
     lds_barrier();
-    S_to_rows<RC_C>(a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
-    if (a.gn_tot) gn_partials_from_S<RC_C>(S, a.gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid);
+    // OUT_FFP: this slice's fp16 partial OUTPUT [nsplit][M][C] (in `part`; behind it the zero-conv partials); the statistics of the
+    // summed output are the sum kernel's
+    h16* const p16 = reinterpret_cast<h16*>(a.part);
+    S_to_rows<RC_C>(FFP ? p16 + ((size_t)z * a.M + m0) * RC_C : a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
+    if (!FFP && a.gn_tot) gn_partials_from_S<RC_C>(S, a.gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid);
     stamp(7);
     if (BLOB) {
         // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
@@ -855,13 +866,13 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
         lds_barrier();
         zero_acc(acc);
         gemm_seg<RC_NT, RC_KS, (POS_PO + RC_NT * RC_KS) % RC_R, true>(acc, ring, X + xfo);
-        epi_bias_res<RC_C, false>(acc, bpo + RC_C, S, wave, m, q);
+        if (first) epi_bias_res<RC_C, false>(acc, bpo + RC_C, S, wave, m, q);
         float alpha = a.alpha;
         if (a.alpha_dev) alpha *= a.alpha_dev[(a.alpha_idx ? *a.alpha_idx : 0) * (a.alpha_bstride > 0 ? a.alpha_bstride : 1) + (a.alpha_bstride > 0 ? b : 0)];
         lds_barrier();                                                  // S (block output) copied out and transposed into X by everyone
         acc_to_S<RC_C>(acc, S, wave, m, q, alpha);
         lds_barrier();
-        S_to_rows<RC_C>(a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
+        S_to_rows<RC_C>(FFP ? p16 + ((size_t)(a.nsplit + z) * a.M + m0) * RC_C : a.out1 + (size_t)m0 * RC_C, RC_C, S, cm);
     }
 #undef m
 #undef q
@@ -912,12 +923,74 @@ int launch_chain(const RowChainArgs& a_in, hipStream_t stream) {
     RcStampReport report{stream, nwg, a.stamps, KIND};
     static std::atomic<unsigned long long> lds_set{0};
     BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&rowchain_kernel<RC_C, KIND, BLOB>), CF::LDS));
-    hipLaunchKernelGGL((rowchain_kernel<RC_C, KIND, BLOB>), dim3(a.M / RC_BM * (KIND == BC_CHAIN_OUT_FF ? a.nsplit : 1)), dim3(CF::NTH), CF::LDS, stream, a);
+    hipLaunchKernelGGL((rowchain_kernel<RC_C, KIND, BLOB>), dim3(a.M / RC_BM * (KIND == BC_CHAIN_OUT_FF || KIND == BC_CHAIN_OUT_FFP ? a.nsplit : 1)), dim3(CF::NTH), CF::LDS, stream, a);
     BC_CHECK_LAUNCH();
     return 0;
 }
 
 #ifndef BC_ROWCHAIN_MIDX_TU
+// ---- the block end's reduction (round 5): out = sum over the nsplit fp16 partial outputs of BC_CHAIN_OUT_FFP (fp32 sum in slice order:
+// bit-reproducible), its GroupNorm statistics added to the consumer's totals; with out1 the zero-conv partials behind them likewise.
+// One thread = 8 channels (16-byte accesses) of SUM_ROWS / RL rows; HBM-bound: (nsplit + 1) * M * C * 2 bytes.
+constexpr int SUM_ROWS = 64;           // rows per workgroup = the producers' row block: the same number of statistics atomics as BC_CHAIN_OUT
+template <int RC_C>
+__global__ __launch_bounds__(640) void rowchain_sum_kernel(const h16* __restrict__ part, int nsplit, int M, int rows_per_batch, h16* __restrict__ out0,
+                                                           unsigned long long* __restrict__ gn_tot, h16* __restrict__ out1) {
+    constexpr int NC = RC_C / 8, RL = 640 / NC, RPT = SUM_ROWS / RL;       // column groups of 8 channels, row lanes (8 / 16), rows per thread (8 / 4)
+    __shared__ float red[RL][NC][16];
+    const int tid = threadIdx.x, cg = tid % NC, rl = tid / NC;
+    const int m0 = blockIdx.x * SUM_ROWS;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const size_t off = (size_t)(m0 + rl + RL * i) * RC_C + cg * 8;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (o == 1 && !out1) break;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            for (int z = 0; z < nsplit; ++z) {
+                const h16x8 d = *reinterpret_cast<const h16x8*>(part + ((size_t)(o * nsplit + z) * M) * RC_C + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)d[j];
+            }
+            h16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (h16)v[j];
+            *reinterpret_cast<h16x8*>((o ? out1 : out0) + off) = r;
+            if (o == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (float)r[j];                    // statistics of the fp16-ROUNDED output, as every other producer's
+                    s[j] += f;
+                    q[j] = fmaf(f, f, q[j]);
+                }
+            }
+        }
+    }
+    if (gn_tot) {                                                   // (workgroup-uniform)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[rl][cg][j] = s[j];
+            red[rl][cg][8 + j] = q[j];
+        }
+        __syncthreads();
+        const int b = m0 / rows_per_batch;
+        if (tid < RC_C) {                                           // one channel per thread, the row lanes in a fixed order
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int r2 = 0; r2 < RL; ++r2) {
+                ss += red[r2][tid >> 3][tid & 7];
+                qq += red[r2][tid >> 3][8 + (tid & 7)];
+            }
+            bc_gn_tot_add(gn_tot + ((size_t)b * RC_C + tid) * BC_GN_TOT_WORDS, ss, qq);
+        }
+    }
+}
+
 template <int RC_C>
 long long stream_frags(int kind, int blobnet, int nsplit) {
     using CF = RCfg<RC_C>;
@@ -928,6 +1001,7 @@ long long stream_frags(int kind, int blobnet, int nsplit) {
     else if (kind == BC_CHAIN_MID || kind == BC_CHAIN_MIDX) n = 2 * g;      // (MIDX reads MID's stream)
     else if (kind == BC_CHAIN_OUT) n = 2 * g + CF::NCH * per_chunk + (blobnet ? g : 0);
     else if (kind == BC_CHAIN_OUT_FF && nsplit > 0 && CF::NCH % nsplit == 0) n = g + CF::NCH / nsplit * per_chunk;
+    else if (kind == BC_CHAIN_OUT_FFP && nsplit > 0 && CF::NCH % nsplit == 0) n = 2 * g + CF::NCH / nsplit * per_chunk + (blobnet ? g : 0);
     else if (kind == BC_CHAIN_OUT_TAIL) n = g + (blobnet ? g : 0);
     else return -1;
     return n + RC_RPAD;
@@ -940,6 +1014,7 @@ int dispatch_chain(int kind, bool blob, const RowChainArgs& a, hipStream_t s) {
         case BC_CHAIN_MID: return launch_chain<RC_C, BC_CHAIN_MID, false>(a, s);
         case BC_CHAIN_OUT_FF: return launch_chain<RC_C, BC_CHAIN_OUT_FF, false>(a, s);
         case BC_CHAIN_OUT_TAIL: return blob ? launch_chain<RC_C, BC_CHAIN_OUT_TAIL, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT_TAIL, false>(a, s);
+        case BC_CHAIN_OUT_FFP: return blob ? launch_chain<RC_C, BC_CHAIN_OUT_FFP, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT_FFP, false>(a, s);
         default: return blob ? launch_chain<RC_C, BC_CHAIN_OUT, true>(a, s) : launch_chain<RC_C, BC_CHAIN_OUT, false>(a, s);
     }
 }
@@ -965,10 +1040,11 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
                            bc_stream stream) {
     BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
                  "rows_per_batch %% %d == 0 (channels=%d M=%d rows_per_batch=%d)", RC_BM, channels, M, rows_per_batch);
-    BC_CHECK_ARG(kind >= BC_CHAIN_IN && kind <= BC_CHAIN_OUT_TAIL, "bc_rowchain: unknown kind %d", kind);
-    BC_CHECK_ARG(wstream && vec && (x || kind == BC_CHAIN_OUT_TAIL) && (out0 || kind == BC_CHAIN_OUT_FF), "bc_rowchain: null pointer");
-    const bool blob = (kind == BC_CHAIN_OUT || kind == BC_CHAIN_OUT_TAIL) && out1 != nullptr;
-    if (kind == BC_CHAIN_OUT_FF || kind == BC_CHAIN_OUT_TAIL)
+    BC_CHECK_ARG((kind >= BC_CHAIN_IN && kind <= BC_CHAIN_OUT_TAIL) || kind == BC_CHAIN_OUT_FFP, "bc_rowchain: unknown kind %d", kind);
+    BC_CHECK_ARG(wstream && vec && (x || kind == BC_CHAIN_OUT_TAIL) && (out0 || kind == BC_CHAIN_OUT_FF || kind == BC_CHAIN_OUT_FFP),
+                 "bc_rowchain: null pointer");
+    const bool blob = (kind == BC_CHAIN_OUT || kind == BC_CHAIN_OUT_TAIL || kind == BC_CHAIN_OUT_FFP) && out1 != nullptr;
+    if (kind == BC_CHAIN_OUT_FF || kind == BC_CHAIN_OUT_TAIL || kind == BC_CHAIN_OUT_FFP)
         BC_CHECK_ARG(part && nsplit >= 1 && (4 * channels / 128) % nsplit == 0, "bc_rowchain(OUT_FF / OUT_TAIL): needs the partial-sum buffer and nsplit "
                      "dividing the %d hidden chunks (nsplit=%d)", 4 * channels / 128, nsplit);
     RowChainArgs a;
@@ -993,11 +1069,31 @@ extern "C" int bc_rowchain(int kind, int channels, int M, int rows_per_batch, co
         BC_CHECK_ARG(out1 && out2 && ldvt >= rows_per_batch && ldvt % 8 == 0, "bc_rowchain(IN): needs out1 (q|k), out2 (V^T) and ldvt >= rows_per_batch, ldvt %% 8 == 0");
     if (kind == BC_CHAIN_MID) BC_CHECK_ARG(res && out1, "bc_rowchain(MID): needs res and out1");
     if (kind == BC_CHAIN_OUT_FF) BC_CHECK_ARG(res, "bc_rowchain(OUT_FF): needs res");
+    if (kind == BC_CHAIN_OUT_FFP) {
+        BC_CHECK_ARG(res && res2 && !gn_tot, "bc_rowchain(OUT_FFP): needs res and res2; the statistics totals belong to bc_rowchain_sum");
+        BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT_FFP): r2 needs out_w dividing rows_per_batch");
+    }
     if (kind == BC_CHAIN_OUT || kind == BC_CHAIN_OUT_TAIL) {
         BC_CHECK_ARG((res || kind == BC_CHAIN_OUT_TAIL) && res2, "bc_rowchain(OUT / OUT_TAIL): needs res and res2");
         BC_CHECK_ARG(!r2 || (out_w > 0 && rows_per_batch % out_w == 0), "bc_rowchain(OUT): r2 needs out_w dividing rows_per_batch");
     }
     return channels == 320 ? dispatch_chain<320>(kind, blob, a, s) : dispatch_chain<640>(kind, blob, a, s);
+}
+
+extern "C" int bc_rowchain_sum(int channels, int M, int rows_per_batch, const bc_half* part, int nsplit, bc_half* out0, unsigned long long* gn_tot,
+                               bc_half* out1, bc_stream stream) {
+    BC_CHECK_ARG(bc_rowchain_supported(channels, M, rows_per_batch), "bc_rowchain_sum: needs 320 or 640 channels, M %% rows_per_batch == 0 and "
+                 "rows_per_batch %% %d == 0 (channels=%d M=%d rows_per_batch=%d)", RC_BM, channels, M, rows_per_batch);
+    BC_CHECK_ARG(part && out0 && nsplit >= 1 && nsplit <= 40, "bc_rowchain_sum: null pointer or nsplit = %d outside 1..40", nsplit);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (channels == 320)
+        hipLaunchKernelGGL(rowchain_sum_kernel<320>, dim3(M / SUM_ROWS), dim3(640), 0, s, reinterpret_cast<const h16*>(part), nsplit, M, rows_per_batch,
+                           reinterpret_cast<h16*>(out0), gn_tot, reinterpret_cast<h16*>(out1));
+    else
+        hipLaunchKernelGGL(rowchain_sum_kernel<640>, dim3(M / SUM_ROWS), dim3(640), 0, s, reinterpret_cast<const h16*>(part), nsplit, M, rows_per_batch,
+                           reinterpret_cast<h16*>(out0), gn_tot, reinterpret_cast<h16*>(out1));
+    BC_CHECK_LAUNCH();
+    return 0;
 }
 
 #else   // BC_ROWCHAIN_MIDX_TU: rowchain_midx.hip

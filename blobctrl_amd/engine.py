@@ -197,9 +197,13 @@ class TrunkPlan:
         (BlobNet) three quarters of the chip idle meanwhile.  BC_ROWCHAIN_FF_SPLIT_640 / _320 override (must divide 20 / 10 chunks)."""
         blocks = M // 64
         if Cc == 640:
+            # (round 5, OUT_FFP: proj_out [+ zero-conv] run inside every slice, so the split no longer pays for itself with a tail
+            #  launch that re-reads nsplit fp32 slabs: as many slices as it takes to put a workgroup on every CU - 4 at 64 row blocks,
+            #  the UNet at batch 1; BlobNet's 32 row blocks likewise 4 = 128 workgroups)
+            dflt = "4" if not os.environ.get("BC_NO_FFP") else "2"
             if self.cfg.is_blobnet and os.environ.get("BC_ROWCHAIN_FF_SPLIT_640_BLOB"):
                 return int(os.environ["BC_ROWCHAIN_FF_SPLIT_640_BLOB"]) if blocks <= 64 else 1
-            return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", "2")) if blocks <= 64 else 1
+            return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", dflt)) if blocks <= 64 else 1
         return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_320", "1")) if blocks <= 128 else 1
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
@@ -266,7 +270,15 @@ class TrunkPlan:
             kw.update(out1=res_out, alpha=alpha, alpha_dev=alpha_dev, alpha_idx=alpha_idx, alpha_bstride=alpha_bstride)
         zname = zero[0] if zero is not None else None
         nsplit = self.rowchain_ff_split(Cc, M)
-        if nsplit > 1:
+        if nsplit > 1 and not os.environ.get("BC_NO_FFP"):
+            # the block end as OUT_FFP + sum (round 5): every slice goes on through proj_out [and the zero-conv] on its own partial sum
+            # (both linear); what remains is an elementwise sum of nsplit fp16 partial outputs, with the GroupNorm statistics
+            pp = rec.empty((2 if zero is not None else 1) * nsplit, M, Cc)
+            w, v = packed(_lib.CHAIN_OUT_FFP, zname, nsplit)
+            kw2 = {k: v_ for k, v_ in kw.items() if k != "out1"}
+            rec.rowchain(_lib.CHAIN_OUT_FFP, Cc, M, HW, a, w, v, None, out1=res_out, res=h, res2=x.t, part=pp, nsplit=nsplit, **kw2)
+            rec.rowchain_sum(Cc, M, HW, pp, nsplit, out, gn_tot=part, out1=res_out)
+        elif nsplit > 1:
             # the block end as two launches, the feed-forward's hidden chunks spread over `nsplit` workgroups per row block
             ffp = rec.empty(nsplit, M, Cc, dtype=torch.float32)
             w, v = packed(_lib.CHAIN_OUT_FF, zname, nsplit)

@@ -38,7 +38,10 @@ def decode_gn_tot(tot: torch.Tensor) -> torch.Tensor:
     """GroupNorm statistics totals [..., GN_TOT_WORDS] int64 (include/blobctrl_hip.h) -> (sum, sum of squares) [..., 2] float64."""
     t = tot.to(torch.float64).cpu()
     w = torch.tensor([2.0 ** -60, 2.0 ** -20, 2.0 ** 20], dtype=torch.float64)
-    return torch.stack([(t[..., 0:3] * w).sum(-1), (t[..., 3:6] * w).sum(-1)], -1)
+    out = torch.stack([(t[..., 0:3] * w).sum(-1), (t[..., 3:6] * w).sum(-1)], -1)
+    poisoned = (tot[..., 2].cpu().abs() >= 2 ** 45) | (tot[..., 5].cpu().abs() >= 2 ** 45)      # bc_gn_tot_read's rule
+    out[poisoned] = float("nan")
+    return out
 
 
 def encode_gn_tot(sums: torch.Tensor) -> torch.Tensor:
@@ -139,6 +142,15 @@ class Segment:
         _lib.check(self.rec.lib.bc_plan_run_timed_kernels(self.rec.plan, self.id, stream, a, b), "bc_plan_run_timed_kernels")
         return [(m, a[i], b[i]) for i, m in enumerate(self.meta)]
 
+    def run_marked(self, stream: int, side: int, extra, marks):
+        """Concurrent eager replay on the segment's own streams with a timestamp behind each launch index in `marks` (ascending):
+        milliseconds from the start of the replay, one per mark (include/blobctrl_hip.h: bc_plan_run_marked)."""
+        arr, n = _stream_array(stream, side, extra)
+        mk = (C.c_int * max(1, len(marks)))(*marks)
+        ms = (C.c_float * max(1, len(marks)))()
+        _lib.check(self.rec.lib.bc_plan_run_marked(self.rec.plan, self.id, arr, n, mk, len(marks), ms), "bc_plan_run_marked")
+        return [ms[i] for i in range(len(marks))]
+
     def enable(self, index: int, on: bool):
         """Diagnostics (ablation probes): skip / restore one launch; re-capture afterwards."""
         _lib.check(self.rec.lib.bc_plan_enable(self.rec.plan, self.id, index, 1 if on else 0), "bc_plan_enable")
@@ -171,7 +183,7 @@ class Recorder:
             self.num_cu = info[0]
         self.bytes_allocated = 0
         self.tots = {}                      # data_ptr of an activation -> its GroupNorm statistics totals [B][C][GN_TOT_WORDS] (int64)
-        self._tot_chunk = None              # (segment id, stream id, chunk tensor, used words): the arena new tables are carved from
+        self._tot_chunk = {}                # (segment id, stream id) -> [chunk tensor, used words]: the arenas new tables are carved from
         self.sid = 0                        # stream id new launches are recorded for (0 main, 1 side)
         self.events = []
         self.loop_graphs = []
@@ -314,14 +326,17 @@ class Recorder:
         carved from the current (segment, stream) chunk.  A chunk is zeroed by ONE bc_memset_zero recorded where it is first used -
         before every producer that adds to it - so a replay starts from zero totals with one extra launch per segment and stream."""
         n = B * Cc * _lib.GN_TOT_WORDS
-        ch = self._tot_chunk
-        if ch is None or ch[0] != self.seg.id or ch[1] != self.sid or ch[3] + n > ch[2].numel():
+        # one open chunk per (segment, stream): recording that switches back to a stream goes on carving from that stream's chunk
+        # (ADVICE r4: a fresh 8 MiB chunk + memset per switch grew with the number of stream switches)
+        key = (self.seg.id, self.sid)
+        ch = self._tot_chunk.get(key)
+        if ch is None or ch[1] + n > ch[0].numel():
             t = self.zeros(max(self.TOT_CHUNK_WORDS, n), dtype=torch.int64)
             self.keep.append(t)
             self._op("bc_memset_zero", (t, t.numel() * 8), "memset", variant="memset_zero", shape=("memset", t.numel() * 8))
-            ch = self._tot_chunk = [self.seg.id, self.sid, t, 0]
-        view = ch[2][ch[3]:ch[3] + n].view(B, Cc, _lib.GN_TOT_WORDS)
-        ch[3] += (n + 31) // 32 * 32        # (256-byte aligned tables)
+            ch = self._tot_chunk[key] = [t, 0]
+        view = ch[0][ch[1]:ch[1] + n].view(B, Cc, _lib.GN_TOT_WORDS)
+        ch[1] += (n + 31) // 32 * 32        # (256-byte aligned tables)
         return view
 
     # ------------------------------------------------------------------ GEMM family
@@ -581,21 +596,36 @@ class Recorder:
                  alpha_bstride=0, part=None, nsplit=1):
         """`part` / `nsplit`: the split form of the block end (CHAIN_OUT_FF writes, CHAIN_OUT_TAIL reads the fp32 partial sums
         [nsplit][M][C] of the feed-forward: include/blobctrl_hip.h)."""
+        # (algorithmic work: OUT_FF / OUT_FFP repeat to_out [proj_out, zero-conv] in every slice - that is not counted)
         mult = {_lib.CHAIN_IN: 4, _lib.CHAIN_MID: 2, _lib.CHAIN_OUT: 14 + (1 if out1 is not None else 0), _lib.CHAIN_OUT_FF: 13,
-                _lib.CHAIN_OUT_TAIL: 1 + (1 if out1 is not None else 0)}[kind]
+                _lib.CHAIN_OUT_TAIL: 1 + (1 if out1 is not None else 0), _lib.CHAIN_OUT_FFP: 14 + (1 if out1 is not None else 0)}[kind]
         # gn_in = (totals of x, gamma, beta, groups, eps): CHAIN_IN finalizes the GroupNorm in front of proj_in in its own prologue
         g_tot, g_gamma, g_beta, g_groups, g_eps = gn_in if gn_in is not None else (None, None, None, 0, 0.0)
         refs = (x, wstream, vec, out0, out1, out2, affine, res, res2, r2, gn_tot, alpha_dev, alpha_idx, part, g_tot, g_gamma, g_beta)
         self.keep.append(refs)
         for t in refs:
             self.register(t)
-        name = {_lib.CHAIN_IN: "in", _lib.CHAIN_MID: "mid", _lib.CHAIN_OUT: "out", _lib.CHAIN_OUT_FF: f"out_ff/{nsplit}", _lib.CHAIN_OUT_TAIL: "out_tail"}[kind]
+        name = {_lib.CHAIN_IN: "in", _lib.CHAIN_MID: "mid", _lib.CHAIN_OUT: "out", _lib.CHAIN_OUT_FF: f"out_ff/{nsplit}", _lib.CHAIN_OUT_TAIL: "out_tail",
+                _lib.CHAIN_OUT_FFP: f"out_ffp/{nsplit}"}[kind]
+        zk = (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL, _lib.CHAIN_OUT_FFP)
         self._op("bc_rowchain", (kind, Cc, M, rows_per_batch, x, affine, g_tot, g_gamma, g_beta, g_groups, g_eps, res, res2, r2, r2_xmin, r2_bmod, out_w, wstream, vec, out0, out1, out2,
                                  ldvt, gn_tot, ln_eps, alpha, alpha_dev, alpha_idx, alpha_bstride, part, nsplit), "rowchain",
                  flops=2 * M * Cc * Cc * mult,
-                 variant=f"rowchain_kernel<{name}{',zero' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else ''}>",
+                 variant=f"rowchain_kernel<{name}{',zero' if kind in zk and out1 is not None else ''}>",
                  shape=("rowchain_" + name, M, Cc, mult * Cc), bytes_=2 * (mult * Cc * Cc + 2 * M * Cc),
-                 rocprof=f"rowchain_kernel<{Cc}, {kind}, {'true' if kind in (_lib.CHAIN_OUT, _lib.CHAIN_OUT_TAIL) and out1 is not None else 'false'}>")
+                 rocprof=f"rowchain_kernel<{Cc}, {kind}, {'true' if kind in zk and out1 is not None else 'false'}>")
+        return out0
+
+    def rowchain_sum(self, Cc, M, rows_per_batch, part, nsplit, out0, gn_tot=None, out1=None):
+        """The reduction behind CHAIN_OUT_FFP (include/blobctrl_hip.h: bc_rowchain_sum): out0 [, out1] = the nsplit fp16 partial outputs
+        [, zero-conv partials] summed in slice order; the output's GroupNorm statistics are added to gn_tot."""
+        refs = (part, out0, gn_tot, out1)
+        self.keep.append(refs)
+        for t in refs:
+            self.register(t)
+        nout = 2 if out1 is not None else 1
+        self._op("bc_rowchain_sum", (Cc, M, rows_per_batch, part, nsplit, out0, gn_tot, out1), "rowchain_sum", variant="rowchain_sum_kernel",
+                 shape=("rowchain_sum", M, Cc, nsplit), bytes_=2 * nout * (nsplit + 1) * M * Cc, rocprof=f"rowchain_sum_kernel<{Cc}>")
         return out0
 
     def rowchain_kv_stream(self, ck, cvt, B, T, Cc, ldvt):

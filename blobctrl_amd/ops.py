@@ -123,10 +123,13 @@ def _(sample, timestep, encoder_hidden_states, down_add, mid_add, up_add, handle
 @torch.library.custom_op("blobctrl::denoise", mutates_args=())
 def denoise(prompt_embeds: torch.Tensor, fg_image_latents: torch.Tensor, bg_image_latents: torch.Tensor, gs_score: torch.Tensor,
             dino_feats: torch.Tensor, latents: torch.Tensor, num_inference_steps: int, guidance_scale: float,
-            conditioning_scales: List[float], guidance_start: float, guidance_end: float, handle: int) -> torch.Tensor:
-    """The denoise loop of one edit (or one request batch) at tensor level: final latents [B][4][h][w] fp32 on the engine's device."""
+            conditioning_scales: List[float], guidance_start: float, guidance_end: float, handle: int,
+            scales_are_per_request: bool = False) -> torch.Tensor:
+    """The denoise loop of one edit (or one request batch) at tensor level: final latents [B][4][h][w] fp32 on the engine's device.
+    `scales_are_per_request`: the caller passed a LIST of conditioning scales (one per request; `denoise` validates its length exactly
+    as for a direct call) rather than one float (a one-element list used to be collapsed to a scalar and broadcast)."""
     eng = _get(handle)
-    sc = conditioning_scales[0] if len(conditioning_scales) == 1 else list(conditioning_scales)
+    sc = list(conditioning_scales) if scales_are_per_request else conditioning_scales[0]
     return eng.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, num_inference_steps=num_inference_steps,
                        guidance_scale=guidance_scale, latents=latents, blobnet_conditioning_scale=sc,
                        blobnet_control_guidance_start=guidance_start, blobnet_control_guidance_end=guidance_end)
@@ -134,6 +137,6 @@ def denoise(prompt_embeds: torch.Tensor, fg_image_latents: torch.Tensor, bg_imag
 
 @denoise.register_fake
 def _(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, latents, num_inference_steps, guidance_scale,
-      conditioning_scales, guidance_start, guidance_end, handle):
+      conditioning_scales, guidance_start, guidance_end, handle, scales_are_per_request=False):
     eng = _get(handle)
     return torch.empty(tuple(latents.shape), dtype=torch.float32, device=eng.device)

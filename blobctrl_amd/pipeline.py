@@ -153,6 +153,9 @@ class BlobCtrlEngine:
         def half_plan(b0):
             hp = TrunkPlan(rec, self.unet_w, self.unet_cfg, B, H, W)
             hp.ctx_kv = {bp: (ck[b0 * T:(b0 + B) * T], cvt[b0:b0 + B], T_, ld) for bp, (ck, cvt, T_, ld) in unet_a.ctx_kv.items()}
+            # (the K / V^T fragment streams of CHAIN_MIDX are laid out per image too: without the slice both halves fell back to the
+            #  unfused MID + attention launches)
+            hp.ctx_kvs = {bp: kvs.view(2 * B, -1)[b0:b0 + B].reshape(-1) for bp, kvs in getattr(unet_a, "ctx_kvs", {}).items()}
             hp.tproj, hp.tproj_table = half_time.tproj, half_time.tproj_table
             return hp
 
@@ -499,15 +502,17 @@ class BlobCtrlEngine:
         plain = {"num_inference_steps", "guidance_scale", "latents", "blobnet_conditioning_scale", "blobnet_control_guidance_start",
                  "blobnet_control_guidance_end"}
         sc = kw.get("blobnet_conditioning_scale", 1.0)
-        sc_ok = isinstance(sc, float) or (isinstance(sc, (list, tuple)) and len(sc) > 0 and all(isinstance(v, float) for v in sc))
+        # (ints and anything else take `denoise` directly, which raises the reference's TypeError for them)
+        is_list = isinstance(sc, (list, tuple))
+        sc_ok = isinstance(sc, float) or (is_list and len(sc) > 0 and all(isinstance(v, float) for v in sc))
         if (set(kw) <= plain and kw.get("latents") is not None and fg_image_latents is not None and bg_image_latents is not None
                 and gs_score is not None and dino_feats is not None and kw.get("guidance_scale", 7.5) > 1.0 and sc_ok):   # (else: denoise raises)
             from . import ops
             return torch.ops.blobctrl.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, kw["latents"],
                                               int(kw.get("num_inference_steps", 50)), float(kw.get("guidance_scale", 7.5)),
-                                              [float(v) for v in sc] if isinstance(sc, (list, tuple)) else [float(sc)],
+                                              [float(v) for v in sc] if is_list else [float(sc)],
                                               float(kw.get("blobnet_control_guidance_start", 0.0)),
-                                              float(kw.get("blobnet_control_guidance_end", 1.0)), ops.register(self))
+                                              float(kw.get("blobnet_control_guidance_end", 1.0)), ops.register(self), is_list)
         return self.denoise(prompt_embeds, fg_image_latents, bg_image_latents, gs_score, dino_feats, **kw)
 
     def compile_plan(self, path, B, h, w, T, ctx_dim, num_inference_steps, guidance_scale=7.5, blobnet_conditioning_scale=1.0,

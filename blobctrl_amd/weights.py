@@ -341,6 +341,8 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
                 [, zero-conv bias]
     kind 3 OUT_FF (nsplit slices): per slice z: attnX.to_out, the hidden chunks [z, z + 1) * (4C / 128) / nsplit -> wstream
                 [nsplit][waves][fragments][64][8]; kind 4 OUT_TAIL: proj_out[, zero-conv].  Both take the vec of kind 2.
+    kind 6 OUT_FFP (nsplit slices): as kind 3 with proj_out[, zero-conv] behind every slice's chunks (the reduction over the slices
+                happens behind them: bc_rowchain_sum); vec of kind 2.
     Built on the device from the trunk's packed matrices (every rank builds its own: nothing to broadcast)."""
     h, f = pw.h, pw.f
     bp = p + "transformer_blocks.0."
@@ -387,16 +389,19 @@ def pack_rowchain(pw: "PackedTrunk", p: str, kind: int, zero_name: Optional[str]
             segs = [seg_proj_out]
         vec = [f[bp + att + ".to_out.0.bias"], f[bp + "norm3.weight"], f[bp + "norm3.bias"], torch.cat(ffb), f[bp + "ff.net.2.bias"],
                f[p + "proj_out.bias"]]
+        seg_zero = None
         if zero_name is not None:
-            if kind != 3:
-                segs.append(_frag_stream(h[zero_name + ".weight"], nC))
+            seg_zero = _frag_stream(h[zero_name + ".weight"], nC)
+            if kind not in (3, 6):
+                segs.append(seg_zero)
             vec.append(f[zero_name + ".bias"])
-        if kind == 3:
+        if kind in (3, 6):
             nchunks = len(chunks)
             assert nchunks % nsplit == 0, (nchunks, nsplit)
             pad = torch.zeros(nw, RC_RPAD, 64, 8, dtype=torch.float16, device=seg_to_out.device)
             per = nchunks // nsplit
-            slices = [torch.cat([seg_to_out] + [x for cs in chunks[z * per:(z + 1) * per] for x in cs] + [pad], 1) for z in range(nsplit)]
+            tail = ([seg_proj_out] + ([seg_zero] if seg_zero is not None else [])) if kind == 6 else []
+            slices = [torch.cat([seg_to_out] + [x for cs in chunks[z * per:(z + 1) * per] for x in cs] + tail + [pad], 1) for z in range(nsplit)]
             return torch.stack(slices).contiguous(), torch.cat([v.reshape(-1).float() for v in vec]).contiguous()
     pad = torch.zeros(nw, RC_RPAD, 64, 8, dtype=torch.float16, device=segs[0].device)
     return torch.cat(segs + [pad], 1).contiguous(), torch.cat([v.reshape(-1).float() for v in vec]).contiguous()

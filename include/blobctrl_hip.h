@@ -301,12 +301,20 @@ int bc_cfg_scheduler_step(const float* eps, float* latents, const float* coef, i
  *                 OUT; grid = row blocks x nsplit): to_out + res -> LayerNorm -> its NCH / nsplit hidden chunks -> part[z][M][C] fp32
  *                 (slice 0 on top of the residual stream).  OUT_TAIL (res2, r2, out0, out1, gn_tot as for OUT): sum of the nsplit
  *                 slices + ff.net.2 bias -> proj_out + res2 (+ r2) [-> zero-conv].  nsplit divides 4C / 128.
+ *   BC_CHAIN_OUT_FFP + bc_rowchain_sum  (round 5) the block end with the reduction moved BEHIND proj_out [and the zero-conv]: both are
+ *                 linear, so every one of the `nsplit` workgroups of a row block runs to_out + res -> LayerNorm -> its hidden chunks ->
+ *                 proj_out [-> zero-conv x alpha] on its own partial sum (slice 0 carries the residual stream, the biases, res2 and r2)
+ *                 and writes an fp16 partial OUTPUT: part = bc_half [nsplit][M][C] (+ [nsplit][M][C] zero-conv partials behind it when
+ *                 out1 != NULL; out1 is only the BlobNet flag here).  OUT_TAIL's GEMMs thus run on nsplit times as many CUs, its fp32
+ *                 partial sums (nsplit x 160 KB read per workgroup) are gone, and the slices are slice-major over the XCDs (an XCD's L2
+ *                 fetches 1 / nsplit of the feed-forward weights).  bc_rowchain_sum adds the partial outputs in slice order (fp32, rounded
+ *                 once: bit-reproducible) into out0 [, out1] and adds the output's GroupNorm statistics to gn_tot.
  * `wstream` / `vec`: the block's weights packed by blobctrl_amd/weights.py:pack_rowchain (per-wave fragment streams in
  * consumption order, for OUT_FF one set per slice; bc_rowchain_stream_frags(channels, kind, blobnet, nsplit) gives the length).  M % rows_per_batch == 0,
  * rows_per_batch % 64 == 0.  Every workgroup streams the block's whole weight set (4.1 MB at 320 channels, 16.4 MB at 640): worth it
  * from a few dozen row blocks upwards (the engine takes the 640-channel form from 64 row blocks).
  * --------------------------------------------------------------------------------------------------------------- */
-enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4, BC_CHAIN_MIDX = 5 };
+enum { BC_CHAIN_IN = 0, BC_CHAIN_MID = 1, BC_CHAIN_OUT = 2, BC_CHAIN_OUT_FF = 3, BC_CHAIN_OUT_TAIL = 4, BC_CHAIN_MIDX = 5, BC_CHAIN_OUT_FFP = 6 };
 int bc_rowchain_supported(int channels, int M, int rows_per_batch);
 long long bc_rowchain_stream_frags(int channels, int kind, int blobnet, int nsplit);
 int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half* x, const float* affine,
@@ -314,6 +322,8 @@ int bc_rowchain(int kind, int channels, int M, int rows_per_batch, const bc_half
                 const bc_half* res2, const bc_half* r2, int r2_xmin, int r2_bmod, int out_w, const bc_half* wstream,
                 const float* vec, bc_half* out0, bc_half* out1, bc_half* out2, int ldvt, unsigned long long* gn_tot, float ln_eps,
                 float alpha, const float* alpha_dev, const int* alpha_idx, int alpha_bstride, float* part, int nsplit, bc_stream stream);
+int bc_rowchain_sum(int channels, int M, int rows_per_batch, const bc_half* part, int nsplit, bc_half* out0, unsigned long long* gn_tot,
+                    bc_half* out1, bc_stream stream);
 /* BC_CHAIN_MIDX: BC_CHAIN_MID with the block's cross-attention behind to_q, in the same launch (diffusers/src/diffusers/models/
  * attention.py:491-510 norm2 -> attn2, attention_processor.py:2191-2224 scaled-dot-product attention over the encoder tokens): x =
  * attn1 output, res = h0: to_out + res -> out0 = h1; LayerNorm2 -> to_q -> softmax(q K^T * attn_scale) V per head (8 heads) -> out1 =
@@ -376,7 +386,7 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
        BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
-       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_COUNT = 27 };
+       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_ROWCHAIN_SUM = 27, BC_OP_COUNT = 28 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */
@@ -404,6 +414,10 @@ int bc_plan_capture_loop(BcPlan* plan, const int* seg_sequence, int n, const bc_
 int bc_plan_run_timed(BcPlan* plan, int seg, bc_stream stream, float* ms_out /* [bc_plan_num_launches] */);
 /* same, with a split-K GEMM's time divided into its main kernel and its reducer (ms_reduce[i] = 0 when launch i has none) */
 int bc_plan_run_timed_kernels(BcPlan* plan, int seg, bc_stream stream, float* ms_main, float* ms_reduce);
+/* Concurrent eager replay of a segment on its own streams with a timing event behind each launch listed in `marks` (ascending launch
+ * indices), recorded on that launch's stream: ms_out[k] = milliseconds from the start of the replay to that event (diagnostics:
+ * where the two queues really are inside an overlapped step). */
+int bc_plan_run_marked(BcPlan* plan, int seg, const bc_stream* streams, int nstreams, const int* marks, int nmarks, float* ms_out);
 int bc_plan_save(BcPlan* plan, const char* path, const BcPlanBuffer* buffers, int nbuffers);
 int bc_plan_load(const char* path, BcPlan** out);
 int bc_plan_buffer(BcPlan* plan, const char* name, void** ptr, long long* bytes);

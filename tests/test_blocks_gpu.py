@@ -91,25 +91,31 @@ def test_transformer_block(z, name, fused, monkeypatch):
     if ctx is not None:
         plan.record_context(ctx.reshape(-1, p["ctx"]).half().cuda(), ctx.shape[1])
     out, _ = plan.transformer("blk.", _act(x))
-    kinds = rec.seg.kinds
+    kinds, variants = rec.seg.kinds, [m.get("variant", "") for m in rec.seg.meta]
     assert ("rowchain" in kinds) == fused, kinds
+    # the cross-attention of a fused cross block runs INSIDE the row-chain's MID launch (CHAIN_MIDX): the reference comparison below
+    # is then a comparison of that launch, not of MID + bc_attention (VERDICT r4 item 7 iii)
+    assert any("midx" in v for v in variants) == (fused and ctx is not None), variants
     _run(seg)
     _check(name + (" (row-chain)" if fused else " (unfused)"), _nchw(out, p["B"]), z[name])
 
 
-@pytest.mark.parametrize("name,mode", [("tfm_640_cross", "rowchain"), ("tfm_640_cross", "rowchain_nsplit1"), ("tfm_640_cross", "unfused"),
+@pytest.mark.parametrize("name,mode", [("tfm_640_cross", "rowchain"), ("tfm_640_cross", "rowchain_tail"), ("tfm_640_cross", "rowchain_nsplit1"),
+                                       ("tfm_640_cross", "unfused"),
                                        ("tfm_640_self_only", "rowchain"), ("tfm_640_self_only", "unfused"),
                                        ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "unfused"), ("tfm_1280_self_only", "gw")])
 def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     """The block sizes rounds 3 / 4 built kernels for, against the reference's Transformer2DModel: 640 channels
-    on a 32 x 64 map at B = 2 (64 row blocks: the row-chain with the block end as OUT_FF + OUT_TAIL over two workgroups per row
-    block, its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
+    on a 32 x 64 map at B = 2 (64 row blocks: the row-chain with the block end as OUT_FFP + sum over four workgroups per row block
+    (round 5), as OUT_FF + OUT_TAIL over two (round 3), its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
     in one launch; and the unfused list)."""
     if mode == "unfused":
         monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
         monkeypatch.setenv("BC_NO_GW", "1")
     if mode == "rowchain_nsplit1":
         monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", "1")
+    if mode == "rowchain_tail":                  # the round-3 block end: OUT_FF + OUT_TAIL over fp32 partial sums
+        monkeypatch.setenv("BC_NO_FFP", "1")
     _, p = BLOCK_CASES[name]
     x, _, ctx = block_inputs(name)
     rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"], heads=p["heads"], cross=p["ctx"])
@@ -119,8 +125,12 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     kinds, variants = rec.seg.kinds, [m.get("variant", "") for m in rec.seg.meta]
     assert ("rowchain" in kinds) == mode.startswith("rowchain"), kinds
     assert any("gemm_wreg_kernel" in v for v in variants) == (mode == "gw"), variants
-    if mode == "rowchain":
-        assert any("out_ff/2" in v for v in variants), variants
+    if mode.startswith("rowchain"):
+        assert any("midx" in v for v in variants) == (ctx is not None), variants
+    if mode == "rowchain":                       # round 5: OUT_FFP (4 slices, each through proj_out) + the sum of the fp16 partial outputs
+        assert any("out_ffp/4" in v for v in variants) and "rowchain_sum" in kinds, variants
+    if mode == "rowchain_tail":
+        assert any("out_ff/2" in v for v in variants) and any("out_tail" in v for v in variants), variants
     if mode == "gw":
         assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
         assert not any(k.startswith("groupnorm") for k in kinds) and sum("_gn" in v for v in variants) == 1, (kinds, variants)

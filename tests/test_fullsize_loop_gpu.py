@@ -253,3 +253,73 @@ def test_free_running_fifty_step_edit_matches_the_reference_final_latents(full, 
         print(f"   after step {k:2d}: max-abs/scale {r:.3e}, PSNR {psnr(xg, xr):.1f} dB")
         assert r < 1e-2 and psnr(xg, xr) > 40.0, (tag, k, r)
     assert rel < 1e-2 and psnr(final, ref) > 40.0, (tag, rel, psnr(final, ref))
+
+
+GOLD_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loop_configs.npz")
+
+
+def _check_against(z, tag, final, trace):
+    ref = z[f"{tag}_final"]
+    rel = np.abs(final - ref).max() / np.abs(ref).max()
+    print(f"{tag}: FINAL latents (free-running, {int(z['steps'])} steps) max-abs/scale {rel:.3e}, PSNR {psnr(final, ref):.1f} dB, |x| max {np.abs(ref).max():.1f}",
+          flush=True)
+    for k in (1, 5):
+        xr, xg = z[f"{tag}_x{k}"], trace[k - 1][1].float().cpu().numpy()
+        r = np.abs(xg - xr).max() / np.abs(xr).max()
+        print(f"   after step {k}: max-abs/scale {r:.3e}, PSNR {psnr(xg, xr):.1f} dB")
+        assert r < 1e-2 and psnr(xg, xr) > 40.0, (tag, k, r)
+    assert rel < 1e-2 and psnr(final, ref) > 40.0, (tag, rel, psnr(final, ref))
+
+
+def test_c5_768_free_running_ten_steps_match_the_reference(full):
+    """VERDICT r4 item 7 i: BASELINE configs[4]'s resolution FREE-RUNNING against the REAL reference (vendored diffusers UNet + BlobNet,
+    CPU fp32, tools/make_golden.py golden_config_loops: 768 x 768, canvas 96 x 192, 10 DDIM steps, window [0, 0.9], bench.py's weights
+    and inputs): final latents and the checkpoints after steps 1 and 5 to the north star's bar (1e-2 of scale, 40 dB).  The whole-edit
+    graph gives the final latents; the checkpoints come from a per-step trace run, which must reproduce them bit for bit."""
+    import bench
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import splat_features
+    z = np.load(GOLD_CFG)
+    h = w = 96
+    inp = bench.synth_inputs(h, w, batch=1)
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
+    eng = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
+    kw = dict(num_inference_steps=int(z["steps"]), guidance_scale=7.5, latents=inp["latents"], blobnet_control_guidance_end=float(z["window_end"]))
+    final = eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], **kw).float().cpu().numpy()
+    trace = []
+    again = eng(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], trace=trace, **kw).float().cpu().numpy()
+    assert np.array_equal(again, final)
+    _check_against(z, "c5", final, trace)
+
+
+def test_c3_requests_free_running_match_the_reference_alone_and_inside_the_batch(full):
+    """VERDICT r4 item 7 ii: two requests of the mixed-operation batch of configs[2] - request 0 (`move`, strength 1.0) and request 1
+    (`remove`: strength 0.0, gs_score = (1, 0), inf:175-188) - FREE-RUNNING for 10 UniPC steps against the REAL reference, which runs
+    one edit per call (fixture: tools/make_golden.py golden_config_loops).  Checked twice: the request run alone, and the same request
+    INSIDE the per-request batch of 8 (1029-channel conv_in, per-image conditioning scales) - so the batch-8 path has a multi-step
+    reference number too, not only HIP-vs-HIP."""
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import blob_dict_from_ellipse, splat_features
+    z = np.load(GOLD_CFG)
+    eng = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="unipc")
+    B, h, w, steps = 8, 64, 64, int(z["steps"])
+    ells = [[[200.0 + 30 * i, 180.0 + 25 * i], [60.0 + 6 * i, 90.0 - 4 * i], 20.0 * i] for i in range(B)]
+    strengths = [1.0, 0.0, 1.0, 1.2, 0.0, 1.0, 0.6, 1.0]
+    score = torch.cat([splat_features(**blob_dict_from_ellipse(e, 512, 512), score_size=(h, w), return_d_score=True, device="cuda:0")
+                       for e in ells]).float()
+    for b, s in enumerate(strengths):
+        if s == 0.0:
+            score[b, 0], score[b, 1] = 1.0, 0.0
+    fg, bg = g(201, B, 4, h, w) * 0.18215 * 5, g(202, B, 4, h, w) * 0.18215 * 5
+    dino, lat = g(203, B, 1, 1024), g(204, B, 4, h, w)
+    neg, pos = g(205, 1, 77, 768).repeat(B, 1, 1), g(206, B, 77, 768)
+    kw = dict(num_inference_steps=steps, guidance_scale=7.5, blobnet_control_guidance_end=float(z["window_end"]))
+    trace8 = []
+    out8 = eng(torch.cat([neg, pos]), fg, bg, score, dino, latents=lat, blobnet_conditioning_scale=strengths, trace=trace8, **kw).float().cpu().numpy()
+    for b in (0, 1):
+        trace = []
+        single = eng(torch.cat([neg[b:b + 1], pos[b:b + 1]]), fg[b:b + 1], bg[b:b + 1], score[b:b + 1], dino[b:b + 1], latents=lat[b:b + 1],
+                     blobnet_conditioning_scale=strengths[b], trace=trace, **kw).float().cpu().numpy()
+        _check_against(z, f"c3_r{b}", single, trace)
+        print(f"   (request {b} inside the batch of 8:)")
+        _check_against(z, f"c3_r{b}", out8[b:b + 1], [(e, x[b:b + 1]) for e, x in trace8])

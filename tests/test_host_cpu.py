@@ -251,7 +251,7 @@ def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
     assert seq == ["step_active"] * 4 + ["step_inactive"] * 2
     raw = open(path, "rb").read()
     magic, version, gsz, nbuf = struct.unpack("<IIII", raw[:16])
-    assert magic == 0x4E4C5042 and version == 3 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
+    assert magic == 0x4E4C5042 and version == 4 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
     for name in (b"latents", b"ctx", b"fg_lat", b"bg_lat", b"fg_score", b"bg_score", b"feat16", b"step_idx", b"coef", b"hist"):
         assert name in raw
     P = eng.plan_for(1, 8, 8, 7, TINY["ctx"], 6)
@@ -350,6 +350,17 @@ def test_rowchain_weight_streams_follow_the_kernels_consumption_order(C):
     j0 = 128 * c + hpw * wave + 16 * ps
     assert torch.equal(v_o[off:off + 16], b1[j0:j0 + 16]) and torch.equal(v_o[off + 16:off + 32], b1[4 * C + j0:4 * C + j0 + 16])
     assert torch.equal(v_o[-C:], sd["blobnet_down_blocks.1.bias"])
+    # OUT_FFP (kind 6): per slice z: to_out, the slice's hidden chunks, then proj_out and the zero-conv - the one-launch stream's own
+    # segments regrouped per slice; same fp32 vector
+    for nsplit in (2, 5 if C == 320 else 4):
+        w_p, v_p = weights.pack_rowchain(pw, p, 6, "blobnet_down_blocks.1", nsplit)
+        per = nch // nsplit
+        assert tuple(w_p.shape) == (nsplit, nw, g + per * per_chunk + 2 * g + weights.RC_RPAD, 64, 8) and torch.equal(v_p, v_o)
+        for z in range(nsplit):
+            assert torch.equal(w_p[z, :, :g], w_o[:, :g])                                                         # to_out
+            assert torch.equal(w_p[z, :, g:g + per * per_chunk], w_o[:, g + z * per * per_chunk: g + (z + 1) * per * per_chunk])
+            assert torch.equal(w_p[z, :, g + per * per_chunk: g + per * per_chunk + 2 * g], w_o[:, g + nch * per_chunk: g + nch * per_chunk + 2 * g])
+            assert float(w_p[z, :, -weights.RC_RPAD:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("N,Cin", [(160, 64), (320, 192)])

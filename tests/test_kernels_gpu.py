@@ -318,6 +318,61 @@ def test_groupnorm_stats_from_splitk_reducer(rec):
     close(out, ref, what="groupnorm stats from split-K reducer")
 
 
+@pytest.mark.parametrize("HW", [1024, 4096, 8192])
+def test_groupnorm_totals_poison_survives_many_addends(rec, HW):
+    """ADVICE r4 / VERDICT r4 item 7 iv: a channel that is non-finite in EVERY producer workgroup (the common overflow case) must
+    surface as NaN over its whole group - the reference's GroupNorm propagates NaN to the group - and not as finite garbage.  The
+    round-4 poison (2^60 in slice 2) cancelled itself mod 2^64 after 16 addends; HW = 4096 on 128-row tiles is 32 addends."""
+    from blobctrl_amd.launch import decode_gn_tot
+    B, K, N, G = 1, 64, 320, 32
+    M = B * HW
+    A, W, b = g(1, M, K), g(2, N, K) / math.sqrt(K), g(3, N)
+    b[7] = float("inf")                                         # channel 7 -> group 0 (channels 0..9) of the output
+    gamma, beta = 1 + 0.1 * g(5, N), 0.1 * g(6, N)
+
+    def fn():
+        y = rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=rec.empty(M, N), bias=b.cuda(), rows_per_batch=HW, want_gn=True)
+        tot = rec.tots[y.data_ptr()]
+        return y, tot, rec.groupnorm(y, N, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda(), True)
+    y, tot, out = run(rec, fn)
+    assert rec.seg.kinds.get("groupnorm_fused_stats") == 1
+    addends = int(tot.cpu()[0, 7, 2]) >> 50
+    print(f"HW {HW}: {addends} poisoned addends on channel 7")
+    assert addends >= 4 and torch.isnan(decode_gn_tot(tot)[0, 7]).all()
+    o = out.float().cpu().view(HW, N)
+    assert torch.isnan(o[:, :10]).all(), "the poisoned group must read as NaN"
+    assert torch.isfinite(o[:, 10:]).all(), "the other groups are untouched"
+    # a standalone statistics pass over a tensor with a NaN channel, consumed by the convolution's in-prologue finalize
+    x = g(7, B, HW, 64)
+    x[:, :, 3] = float("nan")
+    ab = run(rec, lambda: rec.gn_affine(h(x), 64, None, 0, B, HW, 8, 1e-5, torch.ones(64).cuda(), torch.zeros(64).cuda()))
+    ab = ab.cpu()
+    assert torch.isnan(ab[0, :8]).all() and torch.isfinite(ab[0, 8:]).all()
+
+
+@pytest.mark.parametrize("k", [1, 8, 16, 32, 4096, 8191])
+def test_groupnorm_totals_poison_by_addend_count(rec, k):
+    """The same contract on hand-built totals: k poisoned addends on top of an honest sum, on either statistic, either sign of the
+    wrapped slice - every consumer-side reader (bc_gn_tot_read) must see NaN."""
+    from blobctrl_amd.launch import encode_gn_tot
+    B, HW, Cc, G = 1, 4096, 64, 8
+    x = g(9, B, HW, Cc)
+    xs = x.half().float()
+    base = encode_gn_tot(torch.stack([xs.sum(1), (xs * xs).sum(1)], -1))          # [B][C][6]
+    for word in (2, 5):
+        tot = base.clone()
+        tot[0, 20, word] += k << 50                                                 # channel 20 -> group 2 (channels 16..23)
+        t = tot.cuda()
+
+        def fn():
+            xd = h(x)
+            rec.tots[xd.data_ptr()] = t
+            return rec.gn_affine(xd, Cc, None, 0, B, HW, G, 1e-5, torch.ones(Cc).cuda(), torch.zeros(Cc).cuda())
+        ab = run(rec, fn).cpu()
+        assert torch.isnan(ab[0, 16:24]).all(), (k, word)
+        assert torch.isfinite(ab[0, :16]).all() and torch.isfinite(ab[0, 24:]).all()
+
+
 @pytest.mark.parametrize("rows,Cc", [(100, 320), (77, 640), (513, 1280), (9, 64), (5, 16)])
 def test_layernorm(rec, rows, Cc):
     x, gamma, beta = g(1, rows, Cc) * 3 + 1, 1 + 0.1 * g(2, Cc), 0.1 * g(3, Cc)

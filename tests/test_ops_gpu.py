@@ -64,3 +64,25 @@ def test_engine_call_goes_through_the_denoise_op():
         a = pipe(*args, num_inference_steps=3, guidance_scale=7.5, latents=g(31, 1, 4, 8, 8))
     b = pipe.denoise(*args, num_inference_steps=3, guidance_scale=7.5, latents=g(31, 1, 4, 8, 8))
     assert seen == ["blobctrl.denoise.default"] and torch.equal(a, b)
+
+
+def test_list_valued_conditioning_scale_is_validated_identically_through_the_op():
+    """`blobnet_conditioning_scale=[s]` for a per-request batch of 2 is a list of the wrong length - the dispatcher path
+    used to collapse it to a scalar and broadcast it; it must raise exactly what the direct `denoise` call raises.  A correct
+    per-request list, and a one-element list for a single edit, give the direct call's result bit for bit."""
+    from tests.gpu_common import make_pipeline
+    from oracle import blob_splat
+    usd, bsd = tiny_weights()
+    pipe = make_pipeline(usd, bsd, scheduler="ddim")
+    sc = torch.from_numpy(blob_splat.splat_scores_from_ellipse([[40.0, 42.0], [20.0, 30.0], 25.0], 64, 64, 8, 8))
+    two = (g(32, 4, 7, TINY["ctx"]), g(33, 2, 4, 8, 8), g(34, 2, 4, 8, 8), torch.cat([sc, sc]), g(35, 2, 1, TINY["feat"]))
+    kw = dict(num_inference_steps=2, guidance_scale=7.5, latents=g(31, 2, 4, 8, 8))
+    for call in (pipe, pipe.denoise):
+        with pytest.raises(ValueError, match="expected 2 values, got 1"):
+            call(*two, blobnet_conditioning_scale=[0.7], **kw)
+    a = pipe(*two, blobnet_conditioning_scale=[0.7, 0.0], **kw)
+    b = pipe.denoise(*two, blobnet_conditioning_scale=[0.7, 0.0], **kw)
+    assert torch.equal(a, b)
+    one = (g(32, 2, 7, TINY["ctx"]), g(33, 1, 4, 8, 8), g(34, 1, 4, 8, 8), sc, g(35, 1, 1, TINY["feat"]))
+    kw1 = dict(num_inference_steps=2, guidance_scale=7.5, latents=g(31, 1, 4, 8, 8))
+    assert torch.equal(pipe(*one, blobnet_conditioning_scale=[0.7], **kw1), pipe.denoise(*one, blobnet_conditioning_scale=0.7, **kw1))

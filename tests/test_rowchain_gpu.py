@@ -67,9 +67,22 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T
     (True, 2, 16, 32, True, False, 640, 2), (False, 1, 8, 24, False, True, 640, 4), (True, 1, 8, 8, True, False, 640, 5),
     (True, 2, 16, 32, True, False, 320, 2), (False, 1, 16, 32, False, True, 320, 5)])
 def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C, split):
+    monkeypatch.delenv("BC_NO_FFP", raising=False)
     rec_f, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
-    assert any("out_ff" in (m["variant"] or "") for m in rec_f.seg.meta) == (split > 1)
+    # split block end (round 5): OUT_FFP (every slice through proj_out [+ zero-conv]) + the sum of the fp16 partial outputs
+    assert any("out_ffp/" in (m["variant"] or "") for m in rec_f.seg.meta) == (split > 1)
+    assert any(m["kind"] == "rowchain_sum" for m in rec_f.seg.meta) == (split > 1)
     _, out_u, pre_u, _ = _record(monkeypatch, False, cross, B, H, W, with_r2, zero, C)
+    if split > 1:        # the round-3 form (OUT_FF + OUT_TAIL over fp32 partial sums) stays available behind BC_NO_FFP=1
+        monkeypatch.setenv("BC_NO_FFP", "1")
+        rec_t, out_t, pre_t, _ = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
+        monkeypatch.delenv("BC_NO_FFP")
+        assert any("out_tail" in (m["variant"] or "") for m in rec_t.seg.meta) and not any(m["kind"] == "rowchain_sum" for m in rec_t.seg.meta)
+        t_, u_ = out_t.t.float().cpu().numpy(), out_u.t.float().cpu().numpy()
+        assert np.abs(t_ - u_).max() / np.abs(u_).max() < 6e-3 and psnr(t_, u_) > 50.0
+        if zero:
+            zt, zu = pre_t.float().cpu().numpy().reshape(-1), pre_u.float().cpu().numpy().reshape(-1)
+            assert np.abs(zt - zu).max() / np.abs(zu).max() < 6e-3
     a, b = out_f.t.float().cpu().numpy(), out_u.t.float().cpu().numpy()
     rel = np.abs(a - b).max() / np.abs(b).max()
     print(f"row-chain vs unfused block output: max-abs/scale {rel:.3e}, PSNR {psnr(a, b):.1f} dB")

@@ -308,6 +308,161 @@ def golden_fullsize_loop(variants=None):
         print("wrote", tag, "->", path)
 
 
+def _ref_loop(unet, blob, pipe, sch, steps, ge, latents, prompt, fg, bg, gs_score, dino, strength, h, keep_at=()):
+    """The loop body of pipe:1025-1102 on the reference classes (one request, CFG 7.5); returns the final latents and checkpoints."""
+    import time
+    bg_s, fg_s = gs_score.unbind(dim=1)
+    bg_s, fg_s = bg_s.unsqueeze(1).repeat(2, 1, 1, 1).float(), fg_s.unsqueeze(1).repeat(2, 1, 1, 1).float()
+    fg_lat, bg_lat = fg.repeat(2, 1, 1, 1), bg.repeat(2, 1, 1, 1)
+    feats = pipe.splat_features_from_scores(fg_s, dino.repeat(2, 1, 1), size=h, channels_last=False)
+    sch.set_timesteps(steps)
+    latents = latents * sch.init_noise_sigma
+    keep = [1.0 - float(i / steps < 0.0 or (i + 1) / steps > ge) for i in range(steps)]
+    cps, t0 = {}, time.time()
+    for i, t in enumerate(sch.timesteps):
+        lmi = sch.scale_model_input(torch.cat([latents] * 2), t)
+        bi = pipe.construct_blobnet_input(lmi, fg_s, fg_lat, feats, background=False)
+        d, m, u = blob(bi, t, conditioning_scale=float(strength) * keep[i], return_dict=False)
+        ui = pipe.construct_blobnet_input(lmi, bg_s, bg_lat, background=True)
+        npred = unet(ui, t, encoder_hidden_states=prompt, down_block_add_samples=[x[..., -x.shape[-2]:] for x in d],
+                     mid_block_add_sample=m[..., -m.shape[-2]:], up_block_add_samples=[x[..., -x.shape[-2]:] for x in u],
+                     return_dict=False)[0]
+        npred = npred[..., :, npred.shape[-1] // 2:]
+        nu, nt = npred.chunk(2)
+        latents = sch.step(nu + 7.5 * (nt - nu), t, latents, return_dict=False)[0]
+        if i + 1 in keep_at:
+            cps[i + 1] = latents.numpy().copy()
+        print(f"   step {i + 1}/{steps} |x| max {latents.abs().max():.2f} ({time.time() - t0:.0f} s)", flush=True)
+    return latents.numpy().copy(), cps
+
+
+def golden_config_loops(which=None):
+    """multi-step FREE-RUNNING reference runs at the other BASELINE configurations (only C2 had one).
+    (i) `c5`: 768 x 768 (canvas 96 x 192), batch 1, 10 DDIM steps, window [0, 0.9] on bench.py's synthetic weights / inputs;
+    (ii) `c3_r0` / `c3_r1`: requests 0 (move, strength 1.0) and 1 (`remove`: strength 0.0, gs_score = (1, 0), inf:175-188) of the
+    mixed-operation batch of tests/test_fullsize_loop_gpu.py::test_c3_*, each alone (the reference runs one edit per call), 10 UniPC
+    steps.  Stored: final latents + checkpoints after steps 1 and 5.  ~45 s per 768^2 step and ~15 s per 512^2 step on 8 cores."""
+    import bench
+    which = which or ["c5", "c3_r0", "c3_r1"]
+    path = os.path.join(OUT, "loop_configs.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(in_channels=5, out_channels=4, cross_attention_dim=768, attention_head_dim=8)
+        blob = BlobNetModel(in_channels=4, conditioning_channels=1025, cross_attention_dim=None, attention_head_dim=8)
+    usd, bsd = bench.synth_weights()
+    unet.load_state_dict(usd, strict=True, assign=True)
+    blob.load_state_dict(bsd, strict=True, assign=True)
+    unet.eval(); blob.eval()
+    pipe = StableDiffusionBlobNetPipeline.__new__(StableDiffusionBlobNetPipeline)
+    steps, ge = 10, 0.9
+
+    def ref_score(ell, W, H, h, w):
+        mean, cov = ref_inf.get_gs_from_ellipse(ell)
+        nm, nc = ref_inf.normalize_gs(mean, cov, W, H)
+        return splat_features(**ref_inf.get_blob_dict_from_norm_gs(nm, nc), score_size=(h, w), return_d_score=True)
+
+    for tag in which:
+        if f"{tag}_final" in out:
+            print("have", tag)
+            continue
+        print("running", tag, flush=True)
+        if tag == "c5":
+            h = w = 96
+            inp = bench.synth_inputs(h, w)
+            s = (8 * w) / 512.0
+            score = ref_score([[361.1067 * s, 367.8526 * s], [85.4812 * s, 103.6543 * s], 87.3739], 8 * w, 8 * h, h, w)
+            sch = DDIMScheduler(**SD_SCHED, clip_sample=False, set_alpha_to_one=False)
+            final, cps = _ref_loop(unet, blob, pipe, sch, steps, ge, inp["latents"], inp["prompt"], inp["fg"], inp["bg"], score,
+                                   inp["dino"], 1.0, h, keep_at=(1, 5))
+        else:
+            b = int(tag[-1])
+            B, h, w = 8, 64, 64
+            ells = [[[200.0 + 30 * i, 180.0 + 25 * i], [60.0 + 6 * i, 90.0 - 4 * i], 20.0 * i] for i in range(B)]
+            strengths = [1.0, 0.0, 1.0, 1.2, 0.0, 1.0, 0.6, 1.0]
+            score = ref_score(ells[b], 512, 512, h, w)
+            if strengths[b] == 0.0:
+                score[:, 0], score[:, 1] = 1.0, 0.0
+            fg, bg = g(201, B, 4, h, w) * 0.18215 * 5, g(202, B, 4, h, w) * 0.18215 * 5
+            dino, lat = g(203, B, 1, 1024), g(204, B, 4, h, w)
+            neg, pos = g(205, 1, 77, 768).repeat(B, 1, 1), g(206, B, 77, 768)
+            sch = UniPCMultistepScheduler(**SD_SCHED)
+            final, cps = _ref_loop(unet, blob, pipe, sch, steps, ge, lat[b:b + 1], torch.cat([neg[b:b + 1], pos[b:b + 1]]),
+                                   fg[b:b + 1], bg[b:b + 1], score, dino[b:b + 1], strengths[b], h, keep_at=(1, 5))
+        out[f"{tag}_final"] = final
+        for k, v in cps.items():
+            out[f"{tag}_x{k}"] = v
+        out["steps"], out["window_end"] = np.int32(steps), np.float32(ge)
+        np.savez_compressed(path, **out)
+        print("wrote", tag, "->", path, flush=True)
+
+
+def golden_cpu_step_seconds():
+    """ONE denoise step of the REAL reference (vendored diffusers UNet + BlobNet classes at CFG batch 2, fp32,
+    pipe:1043-1090) timed beside the oracle's `noise_pred_step` on the same cores, same weights and inputs, interleaved (one warm-up
+    each, then alternating, best of 2): tests/golden/cpu_step_seconds.json.  bench.py's cpu_baseline (kind "port") quotes the ratio
+    so that the port is shown to cost what the reference's own path costs (it was 3x slower while the oracle materialised the
+    attention scores instead of calling F.scaled_dot_product_attention)."""
+    import time
+    import bench
+    from oracle.nets import NetConfig
+    from oracle.pipeline import noise_pred_step
+    h = w = 64
+    inp = bench.synth_inputs(h, w)
+    usd, bsd = bench.synth_weights()
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(in_channels=5, out_channels=4, cross_attention_dim=768, attention_head_dim=8)
+        blob = BlobNetModel(in_channels=4, conditioning_channels=1025, cross_attention_dim=None, attention_head_dim=8)
+    unet.load_state_dict(usd, strict=True, assign=True)
+    blob.load_state_dict(bsd, strict=True, assign=True)
+    unet.eval(); blob.eval()
+    pipe = StableDiffusionBlobNetPipeline.__new__(StableDiffusionBlobNetPipeline)
+    ell = [[361.1067, 367.8526], [85.4812, 103.6543], 87.3739]
+    mean, cov = ref_inf.get_gs_from_ellipse(ell)
+    nm, nc = ref_inf.normalize_gs(mean, cov, 512, 512)
+    gs_score = splat_features(**ref_inf.get_blob_dict_from_norm_gs(nm, nc), score_size=(h, w), return_d_score=True)
+    bg_s, fg_s = gs_score.unbind(dim=1)
+    bg_s, fg_s = bg_s.unsqueeze(1).repeat(2, 1, 1, 1).float(), fg_s.unsqueeze(1).repeat(2, 1, 1, 1).float()
+    fg_lat, bg_lat = inp["fg"].repeat(2, 1, 1, 1), inp["bg"].repeat(2, 1, 1, 1)
+    feats = pipe.splat_features_from_scores(fg_s, inp["dino"].repeat(2, 1, 1), size=h, channels_last=False)
+    ucfg, bcfg = NetConfig(in_channels=5, cross_attention_dim=768), NetConfig(in_channels=1029, cross_attention_dim=None)
+    x = inp["latents"]
+
+    def ref_step(t):
+        lmi = torch.cat([x] * 2)
+        bi = pipe.construct_blobnet_input(lmi, fg_s, fg_lat, feats, background=False)
+        d, m, u = blob(bi, t, conditioning_scale=1.0, return_dict=False)
+        ui = pipe.construct_blobnet_input(lmi, bg_s, bg_lat, background=True)
+        npred = unet(ui, t, encoder_hidden_states=inp["prompt"], down_block_add_samples=[r[..., -r.shape[-2]:] for r in d],
+                     mid_block_add_sample=m[..., -m.shape[-2]:], up_block_add_samples=[r[..., -r.shape[-2]:] for r in u],
+                     return_dict=False)[0]
+        npred = npred[..., :, npred.shape[-1] // 2:]
+        nu, nt = npred.chunk(2)
+        return nu + 7.5 * (nt - nu)
+
+    def port_step(t):
+        return noise_pred_step(usd, ucfg, bsd, bcfg, x, t, inp["prompt"], fg_lat, bg_lat, fg_s, bg_s, feats, 1.0, 7.5)
+
+    times = {"reference": [], "port": []}
+    outs = {}
+    for rnd in range(3):                                   # round 0 = warm-up of both
+        for name, fn in (("reference", ref_step), ("port", port_step)):
+            t0 = time.perf_counter()
+            outs[name] = fn(torch.tensor(981))
+            dt = time.perf_counter() - t0
+            if rnd:
+                times[name].append(round(dt, 3))
+            print(f"round {rnd} {name}: {dt:.2f} s", flush=True)
+    rel = float((outs["port"] - outs["reference"]).abs().max() / outs["reference"].abs().max())
+    doc = dict(threads=torch.get_num_threads(), cpus=len(os.sched_getaffinity(0)), resolution="512x512",
+               what="one BlobNet-active denoise step, BlobNet AND UNet at CFG batch 2, fp32, after one warm-up step; best of 2",
+               reference_s=min(times["reference"]), port_s=min(times["port"]), samples=times,
+               port_vs_reference_ratio=round(min(times["port"]) / min(times["reference"]), 3),
+               guided_eps_max_abs_rel_port_vs_reference=rel)
+    with open(os.path.join(OUT, "cpu_step_seconds.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps(doc))
+
+
 # ------------------------------------------------------------------------------------------------ 5. dinov2
 def golden_dinov2():
     from transformers import Dinov2Config, Dinov2Model
@@ -718,6 +873,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         if sys.argv[1] == "golden_fullsize_loop":             # python tools/make_golden.py golden_fullsize_loop [unipc:1.0 ...]
             golden_fullsize_loop(sys.argv[2:] or None)
+            sys.exit(0)
+        if sys.argv[1] == "golden_config_loops":              # python tools/make_golden.py golden_config_loops [c5 c3_r0 c3_r1]
+            golden_config_loops(sys.argv[2:] or None)
             sys.exit(0)
         for fn in sys.argv[1:]:
             globals()[fn]()
