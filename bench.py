@@ -126,7 +126,15 @@ def cpu_baseline_worker(h, w, steps):
               f"{' (skipped for the time budget: ' + str(skipped) + ')' if skipped else ''}; best {t_step:.2f} s/step on {cores} threads "
               f"({physical} physical cores on the host); value = 1 / (s/step x {steps}) is an EXTRAPOLATION of the measured step time "
               "to the whole edit (the scheduler update is negligible)")
-    print(json.dumps(dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample,
+    ratio = None
+    try:                  # the port against the REAL reference on the build container's cores (tools/make_golden.py golden_cpu_step_seconds)
+        with open(os.path.join(REPO, "tests", "golden", "cpu_step_seconds.json")) as f:
+            ref = json.load(f)
+        ratio = dict(port_vs_reference_ratio=ref["port_vs_reference_ratio"], reference_s_per_step=ref["reference_s"], port_s_per_step=ref["port_s"],
+                     measured_on=f"{ref['threads']} threads of the build container, same weights and inputs, interleaved")
+    except (OSError, KeyError, ValueError):
+        pass
+    print(json.dumps(dict(value=1.0 / (t_step * steps), unit="edits/s", cores=cores, kind="port", sample=sample, port_vs_reference=ratio,
                           host_cpus_visible=len(avail), physical_cores=physical, pinned_cpus=len(cpus) if pinned else None,
                           s_per_step=round(t_step, 3), step_times_s=table,
                           c1_20step_edit_s_extrapolated=round(t_step * 20, 1), edit_s_extrapolated=round(t_step * steps, 1))), flush=True)
@@ -468,7 +476,7 @@ def roofline(pipe, plan, res=512, batch=1):
         dict(by_kernel=table, top_shapes=detail)
 
 
-def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3):
+def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3, batch=1):
     """One complete edit as scripts/blobctrl_inference.py runs it (UniPC, guidance window [0, 0.9], CFG 7.5), every stage on the
     clock: Gaussian-blob splat + DINOv2 ViT-L/14 on the 224^2 crop + CLIP text encoder (prompt and negative prompt) + 2 VAE encodes
     + the denoise loop (45 BlobNet-active + 5 UNet-only steps) + VAE decode.  Seeded synthetic weights of the real architectures;
@@ -489,7 +497,7 @@ def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3):
     fg = torch.from_numpy(rng.uniform(-1, 1, (1, 3, res, res)).astype(np.float32)).to(dev)
     bg = torch.from_numpy(rng.uniform(-1, 1, (1, 3, res, res)).astype(np.float32)).to(dev)
     crop = torch.from_numpy(rng.standard_normal((1, 3, 224, 224)).astype(np.float32)).to(dev)      # processor output (host side)
-    ids = torch.from_numpy(rng.integers(0, 49408, size=(2, 1, 77)).astype(np.int64)).to(dev)
+    ids = torch.from_numpy(rng.integers(0, 49408, size=(2, 1, 77)).astype(np.int64)).repeat(1, batch, 1).to(dev)   # prompt=[scene_prompt] * num_samples (inf:196)
     sc = res / 512.0
     blob = blob_dict_from_ellipse([[361.1067 * sc, 367.8526 * sc], [85.4812 * sc, 103.6543 * sc], 87.3739], res, res)
 
@@ -521,7 +529,15 @@ def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3):
     names = ["splat_ms", "dinov2_ms", "clip_text_ms", "vae_encode_x2_ms", "denoise_loop_ms", "vae_decode_ms"]
     out = {n: round(v, 3) for n, v in zip(names, med)}
     out["edit_ms_end_to_end"] = round(statistics.median(sum(r) for r in runs), 2)
-    out["config"] = f"{res}x{res}, {denoise_steps} UniPC steps, guidance window [0, 0.9] (script defaults, inf:300-307), CFG 7.5, batch 1"
+    out["config"] = f"{res}x{res}, {denoise_steps} UniPC steps, guidance window [0, 0.9] (script defaults, inf:300-307), CFG 7.5, batch {batch}"
+    if batch > 1:
+        P = eng.plan_for(batch, res // 8, res // 8, 77, 768, denoise_steps)
+        from blobctrl_amd.pipeline import blobnet_keep
+        active = sum(1 for k in blobnet_keep(denoise_steps, 0.0, 0.9) if k != 0.0)
+        flops = P.step_active.flops * active + P.step_inactive.flops * (denoise_steps - active)
+        out["denoise_step_ms"] = round(out["denoise_loop_ms"] / denoise_steps, 3)
+        out["images_per_s"] = round(batch / (out["edit_ms_end_to_end"] * 1e-3), 4)
+        out["loop_frac_of_peak"] = round(flops / (out["denoise_loop_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
     return out
 
 
@@ -705,7 +721,24 @@ def main():
     if world > 1:
         tdist.barrier()
     dt = bdist.barrier_max_seconds(time.perf_counter() - t0, dev)
-    release_cpu_baseline(cpu_handle)                   # (the CPU baseline runs beside the optional blocks below, not beside the timed region)
+    # The CPU baseline runs beside the optional blocks below (never beside the timed region above).  Its worker is pinned to socket 0:
+    # move this process (host side of the roofline / configs / end-to-end blocks) OFF those CPUs first, and say in the line what ran
+    # beside what.
+    cpu_overlap = None
+    if cpu_handle is not None:
+        try:
+            mine = set(os.sched_getaffinity(0))
+            other = sorted(mine - set(socket0_cpus()))
+            if other:
+                os.sched_setaffinity(0, other)
+                cpu_overlap = (f"the bench process moved to the {len(other)} CPUs outside socket 0 before the worker was released; the worker's steps "
+                               "ran beside the roofline / configs / end-to-end blocks of this line (GPU-bound; host side on the other socket)")
+            else:
+                cpu_overlap = ("single-socket host: the worker's steps ran beside the host side of the roofline / configs / end-to-end blocks on "
+                               "the SAME CPUs (those blocks are GPU-bound; their host threads are few)")
+        except (AttributeError, OSError) as e:
+            cpu_overlap = f"affinity not available ({e}): the worker's steps ran beside the optional blocks, unpinned parent"
+    release_cpu_baseline(cpu_handle)
     weights_s = [round(t_weights, 2)]
     ident = dict(rank=rank, local_rank=local, backend=(tdist.get_backend() if world > 1 else None), **device_identity(dev))
     ranks = [ident]
@@ -764,8 +797,15 @@ def main():
         if e2e is not None:
             line["edit_ms_end_to_end"] = e2e["edit_ms_end_to_end"]
             line["end_to_end"] = e2e
+    if rank == 0 and world == 1 and not args.no_e2e and not args.no_configs and args.batch == 1 and not args.requests and args.res == 512:
+        # what `python scripts/blobctrl_inference.py` runs with no arguments (inf:276,304-311): num_samples = 2 (prompt = [scene_prompt] * 2:
+        # two variations of ONE edit in a batch), UniPC, guidance window [0, 0.9], 50 steps - end to end
+        sd = guarded("script_default", lambda: end_to_end(pw_u, pw_b, ucfg, bcfg, dev, args.res, args.denoise_steps, reps=3, batch=2))
+        if sd is not None:
+            line.setdefault("configs", {})["script_default"] = sd
     if cpu_handle is not None:
         line["cpu_baseline"] = collect_cpu_baseline(cpu_handle)
+        line["cpu_baseline"]["beside"] = cpu_overlap
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -200,11 +200,22 @@ class TrunkPlan:
             # (round 5, OUT_FFP: proj_out [+ zero-conv] run inside every slice, so the split no longer pays for itself with a tail
             #  launch that re-reads nsplit fp32 slabs: as many slices as it takes to put a workgroup on every CU - 4 at 64 row blocks,
             #  the UNet at batch 1; BlobNet's 32 row blocks likewise 4 = 128 workgroups)
-            dflt = "4" if not os.environ.get("BC_NO_FFP") else "2"
+            dflt = "4" if self.rowchain_ffp() else "2"
             if self.cfg.is_blobnet and os.environ.get("BC_ROWCHAIN_FF_SPLIT_640_BLOB"):
                 return int(os.environ["BC_ROWCHAIN_FF_SPLIT_640_BLOB"]) if blocks <= 64 else 1
             return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", dflt)) if blocks <= 64 else 1
         return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_320", "1")) if blocks <= 128 else 1
+
+    def rowchain_ffp(self):
+        """The split block end as OUT_FFP + sum (round 5) instead of OUT_FF + OUT_TAIL (round 3)?  OUT_FFP repeats to_out, proj_out [and
+        the zero-conv] in every slice: 104 instead of 145 us per block on the UNet's queue - the step's critical path - for ~35 % more
+        CU-time.  The step is bound by the CU-time of BOTH queues' kernels at least as much as by the UNet chain (tools/
+        concurrent_timeline.py): measured on one box, the UNet takes it (9.27 = 9.27 ms per step at batch 1), BlobNet, which
+        runs ahead of the UNet with a millisecond of slack, keeps the form with the smaller footprint (batch 2, where only BlobNet's
+        64 row blocks split: 15.73 vs 15.88 ms).  BC_NO_FFP=1 / BC_FFP_BLOB=1 override."""
+        if os.environ.get("BC_NO_FFP"):
+            return False
+        return not self.cfg.is_blobnet or bool(os.environ.get("BC_FFP_BLOB"))
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
         """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
@@ -270,7 +281,7 @@ class TrunkPlan:
             kw.update(out1=res_out, alpha=alpha, alpha_dev=alpha_dev, alpha_idx=alpha_idx, alpha_bstride=alpha_bstride)
         zname = zero[0] if zero is not None else None
         nsplit = self.rowchain_ff_split(Cc, M)
-        if nsplit > 1 and not os.environ.get("BC_NO_FFP"):
+        if nsplit > 1 and self.rowchain_ffp():
             # the block end as OUT_FFP + sum (round 5): every slice goes on through proj_out [and the zero-conv] on its own partial sum
             # (both linear); what remains is an elementwise sum of nsplit fp16 partial outputs, with the GroupNorm statistics
             pp = rec.empty((2 if zero is not None else 1) * nsplit, M, Cc)

@@ -68,6 +68,7 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T
     (True, 2, 16, 32, True, False, 320, 2), (False, 1, 16, 32, False, True, 320, 5)])
 def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C, split):
     monkeypatch.delenv("BC_NO_FFP", raising=False)
+    monkeypatch.setenv("BC_FFP_BLOB", "1")                   # (BlobNet's blocks keep OUT_FF + OUT_TAIL by default: engine.rowchain_ffp)
     rec_f, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
     # split block end (round 5): OUT_FFP (every slice through proj_out [+ zero-conv]) + the sum of the fp16 partial outputs
     assert any("out_ffp/" in (m["variant"] or "") for m in rec_f.seg.meta) == (split > 1)

@@ -10,9 +10,10 @@ from blobctrl_amd.vae import AutoencoderKL           # noqa: E402
 
 def main():
     res = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # images per call (scripts/blobctrl_inference.py decodes num_samples = 2 at once)
     sd = synth.synth_state_dict(synth.vae_param_shapes(), 33)
     vae = AutoencoderKL(sd)
-    z = torch.randn(1, 4, res // 8, res // 8).cuda()
+    z = torch.randn(B, 4, res // 8, res // 8).cuda()
     x = torch.randn(1, 3, res, res).clamp(-1, 1).cuda()
     for name, fn in (("decode", lambda: vae.decode(z)), ("encode", lambda: vae.encode(x))):
         for _ in range(3):
@@ -24,7 +25,7 @@ def main():
             fn()
         b.record()
         torch.cuda.synchronize()
-        print(f"{name} {res}x{res}: {a.elapsed_time(b) / 10:.3f} ms")
+        print(f"{name} {res}x{res} batch {z.shape[0] if name == 'decode' else 1}: {a.elapsed_time(b) / 10:.3f} ms")
     for key, P in vae._plans.items():
         rows = P.seg.run_timed(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
