@@ -83,16 +83,30 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     const bool three = grp == 0 || grp == 3;                      // 3 | 2 | 2 | 3 column tiles
     const int tile0 = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 5 : 7;
 
-    const int plane = gridDim.x * gridDim.y;
+    // Every kernel-argument field the prologue reads is fetched HERE, in two clumps of scalar loads: left alone hipcc loads each field where
+    // its first use sits, behind a dozen separate s_waitcnt - at the cold start of a launch each one a scalar-cache miss of its own in
+    // front of the workgroup's first memory request (BC_WREG_STAMPS: 4.3k cycles from entry to the first request).
+    asm volatile("" ::"s"(p.A), "s"(p.A2), "s"(p.W), "s"(p.Hv), "s"(p.Wv), "s"(p.Hin), "s"(p.Win), "s"(p.lda), "s"(p.lda2), "s"(p.C1), "s"(p.Cin),
+                 "s"(p.splitk), "s"(p.a_act), "s"(g.halo_tpi), "s"(g.halo_tx), "s"(g.halo_nch), "s"(g.halo_cps), "s"(g.nband), "s"(g.halo_stamps));
+    asm volatile("" ::"s"(g.wr_plane.mul), "s"(g.wr_plane.shift), "s"(g.wr_plane.d), "s"(g.wr_gx.mul), "s"(g.wr_gx.shift), "s"(g.wr_gx.d), "s"(g.wr_gy.mul),
+                 "s"(g.wr_gy.shift), "s"(g.wr_gy.d), "s"(g.wr_tpi.mul), "s"(g.wr_tpi.shift), "s"(g.wr_tx.mul), "s"(g.wr_tx.shift), "s"(p.bias), "s"(p.rowvec),
+                 "s"(p.rowvec_idx), "s"(p.rowvec_step), "s"(p.ld_rowvec), "s"(g.halo_dbg), "s"(g.div_rpb.d));
+    if (AFFINE == 2)
+        asm volatile("" ::"s"(p.a_tot1), "s"(p.a_tot2), "s"(p.a_gamma), "s"(p.a_beta), "s"(p.a_groups), "s"(p.a_eps), "s"(g.wr_cpg.mul), "s"(g.wr_cpg.shift));
+    // (index arithmetic with host-made reciprocals: the seven integer divisions here were ~250 scalar instructions in front of the first
+    //  memory request of every workgroup)
+    const int plane = (int)g.wr_plane.d;
     const int lin3 = bc_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), plane * gridDim.z);
-    const int lin = lin3 % plane;
-    const int split = lin3 / plane;
-    const int tile = g.nband ? lin % (int)gridDim.y : lin / (int)gridDim.x;
-    const int ntile = g.nband ? lin / (int)gridDim.y : lin % (int)gridDim.x;
+    const int split = (int)fdiv((unsigned)lin3, g.wr_plane);
+    const int lin = lin3 - split * plane;
+    const int q_gx = (int)fdiv((unsigned)lin, g.wr_gx), q_gy = (int)fdiv((unsigned)lin, g.wr_gy);
+    const int tile = g.nband ? lin - q_gy * (int)g.wr_gy.d : q_gx;
+    const int ntile = g.nband ? q_gy : lin - q_gx * (int)g.wr_gx.d;
     const int n0 = ntile * HBN;
-    const int b = tile / g.halo_tpi;
+    const int b = (int)fdiv((unsigned)tile, g.wr_tpi);
     const int tin = tile - b * g.halo_tpi;
-    const int ty0 = (tin / g.halo_tx) * TH, tx0 = (tin % g.halo_tx) * TW;
+    const int ty_ = (int)fdiv((unsigned)tin, g.wr_tx);
+    const int ty0 = ty_ * TH, tx0 = (tin - ty_ * g.halo_tx) * TW;
     // H x W = the image the convolution runs over; with UPS2 (exact nearest-neighbour 2x upsample in front: D/models/upsampling.py:
     // F.interpolate(scale_factor=2.0, mode="nearest") -> conv) that is the VIRTUAL image and a halo pixel reads source pixel (y/2, x/2)
     const int H = p.Hv, W = p.Wv;
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         constexpr int FIN_T = 4;                                  // channels per finalize thread (256 of them)
         const int fin_cpg = AFFINE == 2 ? p.Cin / p.a_groups : 1;
         const int fin_k_lo = c_begin * 64, fin_k_hi = fin_k_lo + nch * 64;
-        const int fin_g_lo = fin_k_lo / fin_cpg, fin_g_hi = AFFINE == 2 ? min(p.a_groups, (fin_k_hi + fin_cpg - 1) / fin_cpg) : 1;
+        const int fin_g_lo = (int)fdiv((unsigned)fin_k_lo, g.wr_cpg), fin_g_hi = AFFINE == 2 ? min(p.a_groups, (int)fdiv((unsigned)(fin_k_hi + fin_cpg - 1), g.wr_cpg)) : 1;
         const int fin_c_lo = fin_g_lo * fin_cpg, fin_nc = fin_g_hi * fin_cpg - fin_c_lo;
         const bool fin_fast = AFFINE == 2 && fin_nc <= 256 * FIN_T && !(g.halo_dbg & 0x100);   // (workgroup-uniform; nch * 64 <= fin_nc; BC_WREG_FIN_SLOW=1: the round-4 form)
         const int ft = ((wave < 2 ? wave : wave - 4) << 6) | lane;        // finalize thread id: waves 0, 1, 6, 7
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 for (int j = 0; j < FIN_T; ++j) {
                     const int i = ft + 256 * j;
                     if (i < nch * 64) {
-                        const int gi = (fin_k_lo + i) / fin_cpg - fin_g_lo;
+                        const int gi = (int)fdiv((unsigned)(fin_k_lo + i), g.wr_cpg) - fin_g_lo;
                         const float a = stat[gi * 2 + 1] * fg[j];
                         abt[i * 2] = a;
                         abt[i * 2 + 1] = fb[j] - stat[gi * 2] * a;
@@ -792,6 +806,12 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     BC_CHECK_ARG((long long)p.M * std::max(p.lda, p.lda2) < 2147483647LL, "bc_gemm(wreg conv): activation of %d pixels x stride %d exceeds 32-bit element offsets",
                  p.M, std::max(p.lda, p.lda2));
     dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    g.wr_plane = make_fastdiv(grid.x * grid.y);
+    g.wr_gx = make_fastdiv(grid.x);
+    g.wr_gy = make_fastdiv(grid.y);
+    g.wr_tpi = make_fastdiv((unsigned)g.halo_tpi);
+    g.wr_tx = make_fastdiv((unsigned)g.halo_tx);
+    g.wr_cpg = make_fastdiv((unsigned)(p.a_tot1 && p.a_groups > 0 ? p.Cin / p.a_groups : 1));
     {
         static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
         static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;

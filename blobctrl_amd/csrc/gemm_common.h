@@ -46,6 +46,8 @@ struct GemmArgs {
     int nband;               // fast GEMM: 1 = an XCD owns a band of COLUMN tiles (all row tiles): it fetches 1/8 of the weights and the
                              // whole activation - chosen when the weight matrix is the larger operand (low-resolution levels)
     unsigned long long* halo_stamps;   // halo conv: BC_HALO_STAMPS=1 -> [workgroup][8] s_memtime stamps (diagnostics), else null
+    FastDiv wr_plane, wr_gx, wr_gy, wr_tpi, wr_tx, wr_cpg;   // conv_wreg: grid plane / grid.x / grid.y / tiles per image / tiles per image row / channels per
+                                                             // GroupNorm group (the kernel's prologue did seven integer divisions in SALU code)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a [rows][64] fp16 tile
