@@ -1,27 +1,21 @@
-// 3x3 / stride-1 / pad-1 convolution, LDS-resident input halo, WEIGHTS STREAMED STRAIGHT INTO VGPRs (gfx950, v_mfma_f32_16x16x32_f16).
+// conv_wreg.hip as HALF-CU workgroups (round 5): 4 waves, 8 x 16 output pixels x 80 output channels, <= 80 KiB of LDS, so that TWO
+// workgroups share a CU - of this launch, or one of this launch beside a workgroup of the other queue's kernel (row-chain, attention,
+// gemm_wreg workgroups are half-CU sized already).
 //
-// Same contract, tile (8 x 16 output pixels x 160 output channels per workgroup), halo staging (raw rows by LDS-DMA into their final
-// swizzled slots, in-place GroupNorm + SiLU pass, zero padding after the activation), split-K over 64-channel chunks and epilogue as
-// conv_halo.hip, which it replaces for the ResBlock convolutions (D/models/resnet.py:327-341, :351-366).  What changed is the main loop.
-// conv_halo.hip brings the weights of every tap in by LDS-DMA (20 KiB per tap and workgroup, one barrier per tap) and measures ~1500
-// cycles per tap against 640 cycles of MFMA: the LDS-DMA path of a CU delivers ~22 B/clk here (tools/wreg_probe.hip), the
-// ordinary global-load path more than twice that.  So:
-//   * the B operand never touches LDS: weights are pre-packed (bc_conv_wreg_pack / weights.pack_conv_wreg) into one CONTIGUOUS stream
-//     of 1-KiB MFMA fragments per wave - lane l of a fragment holds W[n0 + (l & 15)][k0 + 8 (l >> 4) .. + 8] - read with one
-//     global_load_dwordx4 per fragment into a register ring that runs a whole chunk (9 taps) ahead: 144-216 KiB in flight per CU;
-//   * 8 waves = 4 column groups of 3 | 2 | 2 | 3 MFMA column tiles x 2 K halves of each 64-channel chunk; wave w runs on SIMD w % 4, the
-//     groups are assigned so that every SIMD owns 5 tile columns (waves 0, 1, 6, 7 three tiles; 2 - 5 two): no weight byte is fetched
-//     twice and the matrix pipes are evenly loaded;
-//   * every wave covers all 8 pixel rows of the tile, so an A fragment (16 pixels of halo row r at x shift kx) serves the three taps
-//     (ky = 0..2) that read row r: 10 ds_read_b128 per kx group instead of 24, 0.4 LDS reads per MFMA;
-//   * one barrier per CHUNK: the halo images are triple-buffered; the four two-tile waves (which have matrix-pipe time to spare, and run
-//     at raised priority) issue the LDS-DMA of chunk c + 2 and run the in-place pass over chunk c + 1 while everybody multiplies chunk c.
-// Every LDS access of the loop and the whole weight ring are inline asm with hand-counted lgkmcnt / vmcnt waits: hipcc orders plain
-// LDS reads behind every LDS-DMA in flight, and with an LDS-DMA in the same loop it drains the memory counter (vmcnt(0)) at the first
-// use of any loaded register.  Two rules follow for registers the asm loads into (both learnt the hard way): they must
-// reach their wait on a straight path (no load or wait under a run-time condition: the last chunk is PEELED instead), and nothing may
-// still be in flight when such a register dies - hipcc re-uses it at once and the late data lands in somebody else's value.
-// Vector-memory operations complete in issue order, so a counted vmcnt states exactly which of them have landed.
+// Why.  The 8-wave kernel (conv_wreg.hip: 512 threads x up to 256 VGPRs, 115 KiB of LDS) owns its CU, and of a workgroup's ~75k cycles
+// only the tap loop (~40k) feeds the matrix pipes: ~20k go by before the first MFMA (the launch's cold start: every workgroup's first
+// bytes take ~10k cycles whatever is asked for - BC_WREG_STAMPS) and ~15k in the epilogue.  The step is bound by the
+// CU-time of BOTH queues' kernels (tools/concurrent_timeline.py): cycles a CU spends waiting inside a workgroup that nothing else
+// may share are lost to both.  With two workgroups per CU one's prologue / epilogue runs under the other's tap loop.
+//
+// What changes against conv_wreg.hip: a workgroup takes one HALF of a 160-column block - column groups {0, 1} (3 | 2 tiles) or {2, 3}
+// (2 | 3 tiles) x 2 K halves = 4 waves; the weight streams are the SAME (bc_conv_wreg_pack: a wave reads the stream of its (group, K
+// half)), so no weight byte is fetched twice by a CU pair of halves; the halo image is staged once per half (24 KiB per chunk and
+// workgroup - the price: LDS-DMA and the in-place GroupNorm + SiLU pass run twice per 160 channels), by the two two-tile waves (12 slots per
+// lane instead of 6); the affine table holds <= 14 chunks (LDS: 3 x 24 KiB images + 7 KiB + the epilogue vectors = 79.6 KiB) and the
+// in-prologue finalize is the counted-wait form only (span <= 1024 channels): launches outside that stay on the 8-wave kernel.
+// Everything else - tap loop, ring, counted waits, K-half exchange, epilogue arithmetic and its order - is conv_wreg.hip's: results are
+// bit-identical to the 8-wave kernel's.
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -44,24 +38,24 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
 
 constexpr int TW = 16, TH = 8;
 constexpr int HBM = TW * TH;                    // 128 output pixels per workgroup
-constexpr int HBN = 160;                        // output channels per workgroup
+constexpr int HBN = 80;                         // output channels per workgroup: one half of a 160-column block of the weight streams
 constexpr int HSTR = TW + 2;                    // halo row stride (pixels)
 constexpr int HPIX = (TH + 2) * HSTR;           // 180 halo pixels
 constexpr int HALO_BYTES = 24 * 1024;           // one 64-channel chunk of the halo: 192 pixel slots x 128 B (the last 12 are padding)
 constexpr int NBUF = 3;                         // halo images: multiplied | being transformed | landing
 constexpr int OFF_AB = NBUF * HALO_BYTES;
-constexpr int MAX_CH = 40;                      // channel chunks per workgroup (affine table: 512 B per chunk)
+constexpr int MAX_CH = 14;                      // channel chunks per workgroup (affine table: 512 B per chunk)
+constexpr int SWEEP = 25;                       // rows per sweep of the epilogue's row pass (250 of the 256 threads: 25 rows x 10 eight-column chunks)
 constexpr int TS = HBN + 4;                     // epilogue tile row stride (floats)
 constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
 constexpr int LDS_LOOP = OFF_AB + MAX_CH * 512;
-constexpr int LDS_EPI = OFF_SCR + 24 * HBN * 2 * 4;
+constexpr int LDS_EPI = OFF_SCR + SWEEP * HBN * 2 * 4;
 constexpr int OFF_EPI = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;   // bias[160] | time-embedding row[160] (floats), staged in the prologue
 constexpr int LDS_TOTAL = OFF_EPI + 2 * HBN * 4;
-static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES, "LDS budget");
-constexpr int FIN_MAX_CH = 2752;                // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
-constexpr int OFF_FIN = LDS_LOOP;               // its scratch: [span][2] doubles + [groups][2] floats, behind the loop's LDS
-constexpr int LDS_TOTAL_FIN = OFF_FIN + FIN_MAX_CH * 16 + 1024 > LDS_TOTAL ? OFF_FIN + FIN_MAX_CH * 16 + 1024 : LDS_TOTAL;
-static_assert(LDS_TOTAL_FIN <= 160 * 1024, "LDS budget (in-kernel finalize)");
+static_assert(LDS_TOTAL <= 80 * 1024 && HPIX * 128 <= HALO_BYTES && LDS_EPI <= LDS_LOOP, "LDS budget: two workgroups per CU");
+constexpr int FIN_MAX_CH = 1024;                // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
+constexpr int OFF_FIN = 2 * HALO_BYTES;         // its scratch: [span][2] doubles + [groups][2] floats in halo image 2 (first written at the top of chunk 0)
+static_assert(FIN_MAX_CH * 16 + 1024 <= HALO_BYTES, "finalize scratch fits a halo image");
 
 template <int N>
 __device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -72,16 +66,13 @@ template <int V> using IC = std::integral_constant<int, V>;
 
 // AFFINE: 0 = plain convolution, 1 = affine table from global memory (bc_gn_finalize ran), 2 = GroupNorm finalize in the prologue
 template <int AFFINE>
-__global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void conv_wreg4_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BcGemm& p = g.p;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave & 1;                                      // K half of every chunk
-    const int grp = ((wave >> 1) & 1) | ((wave >> 2) << 1);       // column group <- waves {0,1} {2,3} {4,5} {6,7}
-    const bool three = grp == 0 || grp == 3;                      // 3 | 2 | 2 | 3 column tiles
-    const int tile0 = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 5 : 7;
 
     // Every kernel-argument field the prologue reads is fetched HERE, in two clumps of scalar loads: left alone hipcc loads each field where
     // its first use sits, behind a dozen separate s_waitcnt - at the cold start of a launch each one a scalar-cache miss of its own in
@@ -101,8 +92,15 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     const int lin = lin3 - split * plane;
     const int q_gx = (int)fdiv((unsigned)lin, g.wr_gx), q_gy = (int)fdiv((unsigned)lin, g.wr_gy);
     const int tile = g.nband ? lin - q_gy * (int)g.wr_gy.d : q_gx;
-    const int ntile = g.nband ? q_gy : lin - q_gx * (int)g.wr_gx.d;
-    const int n0 = ntile * HBN;
+    const int ntile2 = g.nband ? q_gy : lin - q_gx * (int)g.wr_gx.d;
+    // (readfirstlane: the branch between the two wave kinds below hangs on `half`; without it hipcc selects vector instructions somewhere
+    //  along the index arithmetic, the branch becomes a divergent one, and every scalar operand inside it an "illegal VGPR to SGPR copy")
+    const int ntile = __builtin_amdgcn_readfirstlane(ntile2 >> 1), half = __builtin_amdgcn_readfirstlane(ntile2 & 1);   // 160-column block of the weight streams, and which half of it
+    const int grp = 2 * half + (wave >> 1);                       // column group (3 | 2 | 2 | 3 tiles) <- waves {0,1} {2,3}
+    const bool three = grp == 0 || grp == 3;
+    const int tile0 = grp == 0 ? 0 : grp == 1 ? 3 : grp == 2 ? 5 : 7;
+    const int tile0l = tile0 - 5 * half;                          // first tile inside this workgroup's 80 columns
+    const int n0 = ntile * 160 + 80 * half;
     const int b = (int)fdiv((unsigned)tile, g.wr_tpi);
     const int tin = tile - b * g.halo_tpi;
     const int ty_ = (int)fdiv((unsigned)tin, g.wr_tx);
@@ -116,8 +114,8 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
 
     unsigned long long* const stamps = g.halo_stamps;        // BC_WREG_STAMPS diagnostics (null in production): waves 0 (three tiles) and 2 (staging)
     auto stamp = [&](int i) {
-        if (stamps && lane == 0 && (wave == 0 || wave == 2))
-            stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + (wave >> 1)) * 16 + i] = __builtin_amdgcn_s_memtime();
+        if (stamps && lane == 0 && kg == 0)
+            stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 2 + (three ? 0 : 1)) * 16 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     // The time-embedding row of a captured step sits in a per-edit table behind a device-side step counter.  The counter is fetched
@@ -131,14 +129,15 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     const h16* __restrict__ A2 = reinterpret_cast<const h16*>(p.A2);
     const h16* zero = reinterpret_cast<const h16*>(g_zero_line_w);
 
-    // ---- staging duty (waves 2-5, 256 lanes): lane owns six 16-byte slots of every halo image: bytes [sidx * 16 + 4096 q, + 16) =
-    // halo pixel hp = (sidx >> 3) + 32 q, 16-byte slot sidx & 7.  The swizzle (chunk c lives in slot c ^ swz(hx)) is applied to the
+    // ---- staging duty (the two two-tile waves, 128 lanes): lane owns TWELVE 16-byte slots of every halo image: bytes [sidx * 16 + 2048 q,
+    // + 16) = halo pixel hp = (sidx >> 3) + 16 q, 16-byte slot sidx & 7.  The swizzle (chunk c lives in slot c ^ swz(hx)) is applied to the
     // SOURCE address; the lane that brings a slot in by LDS-DMA is the lane that later normalises it in place.
-    const int sidx = ((wave >= 2 ? wave - 2 : 0) << 6) | lane;
-    int pixv[6], csubv[6];
+    constexpr int NSL = 12;
+    const int sidx = (kg << 6) | lane;                            // (the two staging waves are the two K halves of the two-tile group)
+    int pixv[NSL], csubv[NSL];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int hp = (sidx >> 3) + 32 * q;
+    for (int q = 0; q < NSL; ++q) {
+        const int hp = (sidx >> 3) + 16 * q;
         const int hy = hp / HSTR, hx = hp - hy * HSTR;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inh = hp < HPIX;
@@ -155,12 +154,12 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         const h16* src = second ? A2 : A1;
         const int stride = second ? p.lda2 : p.lda;           // (element offsets fit 32 bits: checked by the launcher)
         const int kin = second ? k0 - p.C1 : k0;
-        char* dst = smem + buf * HALO_BYTES + (wave - 2) * 1024;
+        char* dst = smem + buf * HALO_BYTES + kg * 1024;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < NSL; ++q) {
             const int off = pixv[q] * stride + kin + csubv[q] * 8;
             const h16* s = (valid && pixv[q] >= 0) ? src + off : zero;
-            glds16(s, dst + q * 4096);
+            glds16(s, dst + q * 2048);
         }
     };
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)(smem);
@@ -193,41 +192,52 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         if (outside) outraw = (u32x4v){0u, 0u, 0u, 0u};
         if (store) asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(outraw) : "memory");
     };
-    // FIRST image (prologue): every lane of the workgroup owns three 16-byte slots for the in-place pass: bytes [tid * 16 + 8192 q,
-    // + 16), q < 3, = halo pixel (tid >> 3) + 64 q, slot tid & 7 (the staging waves waited for the LDS-DMA that filled them and a
-    // barrier has passed since).  tinfo: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
-    unsigned tinfo = 0;
+    // FIRST image (prologue): every lane of the workgroup owns SIX 16-byte slots for the in-place pass: bytes [tid * 16 + 4096 q,
+    // + 16), q < 6, = halo pixel (tid >> 3) + 32 q, slot tid & 7 (the staging waves waited for the LDS-DMA that filled them and a
+    // barrier has passed since).  tinfo0 (q < 3) / tinfo1: per q, bit 0 = inside the halo, bit 1 = outside the image, bits 2-4 = 8-channel sub-chunk.
+    unsigned tinfo0 = 0u, tinfo1 = 0u;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int hp = (tid >> 3) + 64 * q;
+    for (int q = 0; q < 6; ++q) {
+        const int hp = (tid >> 3) + 32 * q;
         const int hy = hp / HSTR, hx = hp - hy * HSTR;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const unsigned inh = hp < HPIX, outside = !((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);
-        tinfo |= (inh | outside << 1 | (unsigned)((tid & 7) ^ (((hx >> 1) & 3) << 1)) << 2) << (8 * q);
+        const unsigned bits = (inh | outside << 1 | (unsigned)((tid & 7) ^ (((hx >> 1) & 3) << 1)) << 2) << (8 * (q % 3));
+        if (q < 3) tinfo0 |= bits;
+        else tinfo1 |= bits;
     }
     const unsigned tslot = lds0 + tid * 16;
     // in the loop the pass belongs to the staging waves (the three-tile waves have neither the registers nor the issue slots to spare):
     // two of the lane's six DMA slots after each kx group, reads of both issued before the arithmetic
-    auto transform_pair = [&](auto kxc, int cl, int buf) {
-        constexpr int q0 = 2 * decltype(kxc)::value;
-        Pending pa, pb;
-        const unsigned sa = slot_addr + buf * HALO_BYTES + 4096 * q0, ab = ab_base + cl * 512;      // (64 channels x (a, b) x 4 bytes per chunk)
-        const bool in0 = (sidx >> 3) + 32 * q0 < HPIX, in1 = (sidx >> 3) + 32 * (q0 + 1) < HPIX;
-        // (reads and arithmetic are unconditional - the padding slots of the image are readable - only the store is predicated: the
-        // registers the asm reads land in reach their wait on a straight path)
-        tr_issue(sa, ab + csubv[q0] * 64, pa);
-        tr_issue(sa + 4096, ab + csubv[q0 + 1] * 64, pb);
-        tr_finish(sa, pixv[q0] < 0, in0, pa);
-        tr_finish(sa + 4096, pixv[q0 + 1] < 0, in1, pb);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto transform_pair = [&](auto kxc, int cl, int buf) {       // FOUR of the lane's twelve slots after each kx group, as two pairs
+        const unsigned ab = ab_base + cl * 512;                  // (64 channels x (a, b) x 4 bytes per chunk)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            constexpr int qb = 4 * decltype(kxc)::value;
+            const int q0 = qb + 2 * h2;
+            Pending pa, pb;
+            const unsigned sa = slot_addr + buf * HALO_BYTES + 2048 * q0;
+            const bool in0 = (sidx >> 3) + 16 * q0 < HPIX, in1 = (sidx >> 3) + 16 * (q0 + 1) < HPIX;
+            // (reads and arithmetic are unconditional - the padding slots of the image are readable - only the store is predicated: the
+            // registers the asm reads land in reach their wait on a straight path)
+            tr_issue(sa, ab + csubv[q0] * 64, pa);
+            tr_issue(sa + 2048, ab + csubv[q0 + 1] * 64, pb);
+            tr_finish(sa, pixv[q0] < 0, in0, pa);
+            tr_finish(sa + 2048, pixv[q0 + 1] < 0, in1, pb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     };
-    auto transform_first = [&]() {                                // image 0, all three slots with the reads issued together
+    auto transform_round = [&](unsigned ti, unsigned base) {      // three slots with the reads issued together
         Pending pd[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) tr_issue(tslot + 8192 * q, ab_base + ((tinfo >> (8 * q + 2)) & 7) * 64, pd[q]);
+        for (int q = 0; q < 3; ++q) tr_issue(base + 4096 * q, ab_base + ((ti >> (8 * q + 2)) & 7) * 64, pd[q]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) tr_finish(tslot + 8192 * q, (tinfo >> (8 * q + 1)) & 1, (tinfo >> (8 * q)) & 1, pd[q]);
+        for (int q = 0; q < 3; ++q) tr_finish(base + 4096 * q, (ti >> (8 * q + 1)) & 1, (ti >> (8 * q)) & 1, pd[q]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto transform_first = [&]() {                                // image 0: six slots per lane, three at a time
+        transform_round(tinfo0, tslot);
+        transform_round(tinfo1, tslot + 3 * 4096);
     };
 
     // ---- prologue: affine table of this chunk range -> LDS ----
@@ -263,13 +273,13 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         // plain LDS accesses, and the two barriers inside are LDS-only (a __syncthreads() waits for vmcnt(0): in round 4 the first one
         // waited for 48 KiB of halo rows + the first ring group, and the rest of chunk 0's weights was requested behind the whole finalize:
         // 21k cycles to the first MFMA against 10k with a finalize launch - BC_WREG_STAMPS).
-        constexpr int FIN_T = 4;                                  // channels per finalize thread (256 of them)
+        constexpr int FIN_T = 8;                                  // channels per finalize thread (128 of them: the two three-tile waves)
         const int fin_cpg = AFFINE == 2 ? p.Cin / p.a_groups : 1;
         const int fin_k_lo = c_begin * 64, fin_k_hi = fin_k_lo + nch * 64;
         const int fin_g_lo = (int)fdiv((unsigned)fin_k_lo, g.wr_cpg), fin_g_hi = AFFINE == 2 ? min(p.a_groups, (int)fdiv((unsigned)(fin_k_hi + fin_cpg - 1), g.wr_cpg)) : 1;
         const int fin_c_lo = fin_g_lo * fin_cpg, fin_nc = fin_g_hi * fin_cpg - fin_c_lo;
-        const bool fin_fast = AFFINE == 2 && fin_nc <= 256 * FIN_T && !(g.halo_dbg & 0x100);   // (workgroup-uniform; nch * 64 <= fin_nc; BC_WREG_FIN_SLOW=1: the round-4 form)
-        const int ft = ((wave < 2 ? wave : wave - 4) << 6) | lane;        // finalize thread id: waves 0, 1, 6, 7
+        constexpr bool fin_fast = AFFINE == 2;                           // (the launcher sends wider spans to the 8-wave kernel)
+        const int ft = (kg << 6) | lane;                                  // finalize thread id: the two three-tile waves
         u32x4v fq[FIN_T][3];
         float fg[FIN_T], fb[FIN_T];
         if (AFFINE == 2 && !STG && fin_fast) {
@@ -280,14 +290,14 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             const int C1s = p.A2 ? p.C1 : p.Cin, C2s = p.Cin - C1s;      // channels of the first / second source
 #pragma unroll
             for (int j = 0; j < FIN_T; ++j) {
-                const int cc = ft + 256 * j;
+                const int cc = ft + 128 * j;
                 const int c = fin_c_lo + (cc < fin_nc ? cc : 0);
                 const bool second = c >= C1s;
                 const unsigned long long ta = (second ? tp2 : tp1) + ((unsigned long long)((long long)b * (second ? C2s : C1s) + (second ? c - C1s : c))) * (BC_GN_TOT_WORDS * 8);
                 const unsigned long long* t = reinterpret_cast<const unsigned long long*>(ta);
                 asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dwordx4 %2, %3, off offset:32"
                              : "=&v"(fq[j][0]), "=&v"(fq[j][1]), "=&v"(fq[j][2]) : "v"(t) : "memory");
-                const int i = ft + 256 * j;                               // table entry (channel fin_k_lo + i) this thread writes
+                const int i = ft + 128 * j;                               // table entry (channel fin_k_lo + i) this thread writes
                 const int ci = fin_k_lo + (i < nch * 64 ? i : 0);
                 asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(fg[j]), "=&v"(fb[j]) : "v"(p.a_gamma + ci), "v"(p.a_beta + ci) : "memory");
             }
@@ -303,7 +313,10 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             // the totals have landed (younger: this wave's ring group 0)
 #define BC_FIN_TIE(j) "+v"(fq[j][0]), "+v"(fq[j][1]), "+v"(fq[j][2])
             asm volatile("s_waitcnt vmcnt(%12)" : BC_FIN_TIE(0), BC_FIN_TIE(1), BC_FIN_TIE(2), BC_FIN_TIE(3) : "n"(G) : "memory");
+            asm volatile("s_waitcnt vmcnt(%12)" : BC_FIN_TIE(4), BC_FIN_TIE(5), BC_FIN_TIE(6), BC_FIN_TIE(7) : "n"(G) : "memory");
             asm volatile("s_waitcnt vmcnt(%8)" : "+v"(fg[0]), "+v"(fg[1]), "+v"(fg[2]), "+v"(fg[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3])
+                         : "n"(G) : "memory");
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(fg[4]), "+v"(fg[5]), "+v"(fg[6]), "+v"(fg[7]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]), "+v"(fb[7])
                          : "n"(G) : "memory");
 #undef BC_FIN_TIE
         }
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             if (!STG) {
 #pragma unroll
                 for (int j = 0; j < FIN_T; ++j) {
-                    const int cc = ft + 256 * j;
+                    const int cc = ft + 128 * j;
                     if (cc < fin_nc) {
                         double s_, q_;
                         auto w64 = [](unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); };
@@ -339,9 +352,9 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             stamp(11);
-            if (!STG) {   // eight lanes per group: 32 groups per pass of the four finalize waves, fixed summation order
+            if (!STG) {   // eight lanes per group: 16 groups per pass of the two finalize waves, fixed summation order
                 const int sub = ft & 7;
-                for (int gi = fin_g_lo + (ft >> 3); gi < fin_g_hi; gi += 32) {
+                for (int gi = fin_g_lo + (ft >> 3); gi < fin_g_hi; gi += 16) {
                     double s_ = 0.0, q_ = 0.0;
                     for (int cj = sub; cj < fin_cpg; cj += 8) {
                         s_ += scr[((gi - fin_g_lo) * fin_cpg + cj) * 2];
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 float* abt = reinterpret_cast<float*>(smem + OFF_AB);
 #pragma unroll
                 for (int j = 0; j < FIN_T; ++j) {
-                    const int i = ft + 256 * j;
+                    const int i = ft + 128 * j;
                     if (i < nch * 64) {
                         const int gi = (int)fdiv((unsigned)(fin_k_lo + i), g.wr_cpg) - fin_g_lo;
                         const float a = stat[gi * 2 + 1] * fg[j];
@@ -381,84 +394,11 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             }
             stamp(13);
             // (no barrier here: the table is read behind the "raw rows visible" barrier below)
-        } else if (AFFINE == 2) {
-            // GroupNorm finalize for the groups overlapping this workgroup's channels [k_lo, k_hi), from the statistics totals (six
-            // words per channel, order-independent integer sums: bc_common.h), while the first halo rows and weight fragments are in
-            // flight.  Scratch behind the loop's LDS (the halo images are already being written).
-            const int cpg = p.Cin / p.a_groups;
-            const int k_lo = c_begin * 64, k_hi = k_lo + nch * 64;
-            const int g_lo = k_lo / cpg, g_hi = min(p.a_groups, (k_hi + cpg - 1) / cpg);
-            const int c_lo = g_lo * cpg, nc = g_hi * cpg - c_lo;
-            // gamma / beta of this thread's first two channels are requested FIRST: fetched behind the second barrier they were a
-            // third exposed memory round trip of the prologue
-            float gpre[2] = {0.f, 0.f}, bpre[2] = {0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (tid + 512 * j < nch * 64) {
-                    gpre[j] = p.a_gamma[k_lo + tid + 512 * j];
-                    bpre[j] = p.a_beta[k_lo + tid + 512 * j];
-                }
-            double* scr = reinterpret_cast<double*>(smem + OFF_FIN);           // [nc][2] = (sum, sum of squares) per channel
-            for (int cc = tid; cc < nc; cc += 512) {
-                const int c = c_lo + cc;
-                const bool second = p.A2 != nullptr && c >= p.C1;
-                const int Cs = second ? p.Cin - p.C1 : (p.A2 ? p.C1 : p.Cin);
-                const unsigned long long* t = (second ? p.a_tot2 : p.a_tot1) + ((size_t)b * Cs + (second ? c - p.C1 : c)) * BC_GN_TOT_WORDS;
-                double s, q;
-                bc_gn_tot_read(t, s, q);
-                scr[cc * 2] = s;
-                scr[cc * 2 + 1] = q;
-            }
-            __syncthreads();
-            float* stat = reinterpret_cast<float*>(scr + nc * 2);             // [groups][2] = (mean, rstd)
-            {   // eight lanes per group: 64 groups per pass of the workgroup, fixed summation order
-                const int sub = tid & 7;
-                for (int gi = g_lo + (tid >> 3); gi < g_hi; gi += 64) {
-                    double s = 0.0, q = 0.0;
-                    for (int cj = sub; cj < cpg; cj += 8) {
-                        s += scr[((gi - g_lo) * cpg + cj) * 2];
-                        q += scr[((gi - g_lo) * cpg + cj) * 2 + 1];
-                    }
-#pragma unroll
-                    for (int o = 4; o > 0; o >>= 1) {
-                        s += __shfl_xor(s, o);
-                        q += __shfl_xor(q, o);
-                    }
-                    const double n = (double)g.div_rpb.d * cpg;
-                    const double mean = s / n;
-                    double var = q / n - mean * mean;
-                    if (var < 0.0) var = 0.0;
-                    if (sub == 0) {
-                        stat[(gi - g_lo) * 2] = (float)mean;
-                        stat[(gi - g_lo) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.a_eps));
-                    }
-                }
-            }
-            __syncthreads();
-            float* abt = reinterpret_cast<float*>(smem + OFF_AB);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = tid + 512 * j;
-                if (i < nch * 64) {
-                    const int gi = (k_lo + i) / cpg - g_lo;
-                    const float a = stat[gi * 2 + 1] * gpre[j];
-                    abt[i * 2] = a;
-                    abt[i * 2 + 1] = bpre[j] - stat[gi * 2] * a;
-                }
-            }
-            for (int i = tid + 1024; i < nch * 64; i += 512) {
-                const int c = k_lo + i;
-                const int gi = c / cpg - g_lo;
-                const float a = stat[gi * 2 + 1] * p.a_gamma[c];
-                abt[i * 2] = a;
-                abt[i * 2 + 1] = p.a_beta[c] - stat[gi * 2] * a;
-            }
-            __syncthreads();                                              // (the scratch overlaps the epilogue vectors staged next)
         }
         if (AFFINE == 1) {   // affine table of the chunk range (bc_gn_finalize ran) -> LDS
             const float4* src = reinterpret_cast<const float4*>(p.a_affine + ((size_t)b * p.Cin + (size_t)c_begin * 64) * 2);
             float4* dst = reinterpret_cast<float4*>(smem + OFF_AB);
-            for (int i = tid; i < nch * 32; i += 512) dst[i] = src[i];
+            for (int i = tid; i < nch * 32; i += 256) dst[i] = src[i];
         }
         BC_WREG_LOAD_GROUP(1, wb)
         BC_WREG_LOAD_GROUP(2, wb)
@@ -525,7 +465,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                               "+v"(ring[kx * G + G - 1]) : "n"(N) : "memory");                                                          \
     else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ring[kx * G]), "+v"(ring[kx * G + 1]), "+v"(ring[kx * G + 2]), "+v"(ring[kx * G + 3]),       \
                       "+v"(ring[kx * G + 4]), "+v"(ring[kx * G + G - 1]) : "n"(N) : "memory");
-                constexpr int D = STG ? 6 : 0;
+                constexpr int D = STG ? NSL : 0;
                 if (more || kx == 0) { BC_WREG_WAIT(2 * G + D) }
                 else if (kx == 1) { BC_WREG_WAIT(G + D) }
                 else { BC_WREG_WAIT(D) }
@@ -582,7 +522,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         // waves (same column group, other K half) hold the same fragment layout: each sends the half of its accumulators the OTHER one
         // finalises (K half 0: pixel rows 0-3, K half 1: rows 4-7) as 16-byte fragments, adds what it receives, and writes its own four
         // pixel rows of the row-major tile.
-        char* xch = smem + tile0 * 8192;                          // [row tile 8][tile NT][lane 64] x 16 bytes per column group
+        char* xch = smem + tile0l * 8192;                         // [row tile 8][tile NT][lane 64] x 16 bytes per column group
         const int i_keep = kg * 4, i_send = 4 - i_keep;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
@@ -599,7 +539,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 fin[ii][t] = (kg ? acc[4 + ii][t] : acc[ii][t]) + o;
             }
         __syncthreads();                                          // every fragment has been read: the tile may overwrite the exchange area
-        const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
+        const int er = (lane >> 4) * 4, ec = tile0l * 16 + (lane & 15);
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -613,14 +553,14 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     stamp(4);
 
     // ------------------------------------------------------------------------------------------------ epilogue (as conv_halo.hip)
-    // row-major pass: 24 rows x 20 eight-column chunks per sweep (480 of the 512 threads)
-    const int col8 = tid % 20, row0 = tid / 20;
-    const bool act = tid < 480;
+    // row-major pass: 25 rows x 10 eight-column chunks per sweep (250 of the 256 threads)
+    const int col8 = tid % 10, row0 = tid / 10;
+    const bool act = tid < SWEEP * 10;
     const int rpb = (int)g.div_rpb.d;
     if (p.splitk > 1) {
         if (act) {
             float* slab = p.slab + (size_t)split * p.M * p.N;
-            for (int row = row0; row < HBM; row += 24) {
+            for (int row = row0; row < HBM; row += SWEEP) {
                 const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
                 const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
                 const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
@@ -649,13 +589,13 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             cs[j] = (p.colscale ? p.colscale[n_first + j] : 1.0f) * alpha;
         }
         const float ab = p.alpha_bstride > 0 ? batch_alpha(g, b) : 1.0f;
-        constexpr int NR = 6;                                       // rows row0 + 24 k < 128
+        constexpr int NR = 6;                                       // rows row0 + 25 k < 128
         uint4 rr[NR], rr2[NR];
         int mrow[NR];
         bool has2[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int row = row0 + 24 * k;
+            const int row = row0 + SWEEP * k;
             const int py = ty0 + (row >> 4), px = tx0 + (row & 15);
             mrow[k] = b * rpb + py * W + px;
             has2[k] = false;
@@ -671,7 +611,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-            const int row = row0 + 24 * k;
+            const int row = row0 + SWEEP * k;
             if (row >= HBM) continue;
             const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
             const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
@@ -721,7 +661,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         }
     }
     if (p.gn_tot) {
-        float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
+        float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [25][80][2], behind the tile
         if (act) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -733,7 +673,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         if (tid < HBN) {
             float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 24; ++r) {
+            for (int r = 0; r < SWEEP; ++r) {
                 s += scr[(r * HBN + tid) * 2];
                 q += scr[(r * HBN + tid) * 2 + 1];
             }
@@ -743,81 +683,34 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     stamp(5);
 }
 
-// out[frag stream] <- w[N][9 * Cin] (k = (ky * 3 + kx) * Cin + c, the layout of every other 3x3 path): one thread per 16-byte lane slot
-__global__ void conv_wreg_pack_kernel(const h16* __restrict__ w, int N, int Cin, h16* __restrict__ out) {
-    const long long total = (long long)N * 9 * Cin / 8;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int nchunks = Cin / 64;
-    const long long per_ntile = (long long)20 * nchunks * 9 * 64;           // lane slots per 160-column block
-    const int ntile = (int)(idx / per_ntile);
-    long long rem = idx - (long long)ntile * per_ntile;
-    // stream order inside a block: (group, K half) streams of nchunks * 9 * NT fragments, starting at (2 * tile0 + kg * NT) tile-streams
-    const long long per_tile_stream = (long long)nchunks * 9 * 64;          // lane slots of one tile column and K half
-    const int ts = (int)(rem / per_tile_stream);                             // 0..19 = 2 * tile0 + kg * NT + (position inside the wave stream)
-    int grp, tile0, NT;
-    if (ts < 6) { grp = 0; tile0 = 0; NT = 3; }
-    else if (ts < 10) { grp = 1; tile0 = 3; NT = 2; }
-    else if (ts < 14) { grp = 2; tile0 = 5; NT = 2; }
-    else { grp = 3; tile0 = 7; NT = 3; }
-    (void)grp;
-    const long long in_grp = rem - (long long)2 * tile0 * per_tile_stream;  // lane slot inside the group's two wave streams
-    const long long per_wave = per_tile_stream * NT;
-    const int kg = (int)(in_grp / per_wave);
-    long long s = in_grp - (long long)kg * per_wave;                         // lane slot inside the wave stream
-    const int lane = (int)(s & 63);
-    s >>= 6;                                                                 // fragment index = ((chunk * 3 + kx) * 3 + ky) * NT + t
-    const int t = (int)(s % NT);
-    s /= NT;
-    const int ky = (int)(s % 3);
-    s /= 3;
-    const int kx = (int)(s % 3);
-    const int chunk = (int)(s / 3);
-    const int n = ntile * HBN + (tile0 + t) * 16 + (lane & 15);
-    const long long k = (long long)(ky * 3 + kx) * Cin + chunk * 64 + kg * 32 + 8 * (lane >> 4);
-    *reinterpret_cast<uint4*>(out + idx * 8) = *reinterpret_cast<const uint4*>(w + (long long)n * 9 * Cin + k);
-}
-
 }  // namespace
 
-extern "C" int bc_conv_wreg_pack(const bc_half* w, int N, int Cin, bc_half* out, bc_stream stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    BC_CHECK_ARG(w && out && N > 0 && N % HBN == 0 && Cin > 0 && Cin % 64 == 0, "bc_conv_wreg_pack: N %% 160 == 0 and Cin %% 64 == 0 (N=%d Cin=%d)", N, Cin);
-    BC_CHECK_ARG(((uintptr_t)w % 16 == 0) && ((uintptr_t)out % 16 == 0) && w != out, "bc_conv_wreg_pack: 16-byte aligned, out of place");
-    const long long total = (long long)N * 9 * Cin / 8;
-    hipLaunchKernelGGL(conv_wreg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const h16*>(w), N, Cin,
-                       reinterpret_cast<h16*>(out));
-    BC_CHECK_LAUNCH();
-    return 0;
+// 1 = this launch fits the half-CU kernel (<= 14 chunks per workgroup; in-prologue finalize over <= 1024 channels), 0 = 8-wave kernel
+int bc_conv_wreg4_eligible(const BcGemm& p, int cps) {
+    if (cps > MAX_CH) return 0;
+    if (p.a_tot1) {
+        if (!(p.a_groups > 0) || p.Cin % p.a_groups) return 0;
+        if (cps * 64 + 2 * (p.Cin / p.a_groups) > FIN_MAX_CH) return 0;
+    }
+    return 1;
 }
 
-int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
+int bc_conv_wreg4_launch(GemmArgs& g, hipStream_t stream) {
     BcGemm& p = g.p;
-    {   // half-CU workgroups (conv_wreg4.hip) where the launch fits them: BC_WREG4=1 all eligible launches, =2 only unsplit ones
-        const char* w4e = getenv("BC_WREG4");                   // (read per launch: the tests switch it inside one process)
-        const int w4 = w4e ? atoi(w4e) : 0;
-        if (w4) {
-            const int nch_ = p.Cin / 64;
-            const int sk_ = std::max(1, std::min(p.splitk, nch_));
-            const int cps_ = bc_ceil_div(nch_, sk_);
-            if (bc_conv_wreg4_eligible(p, cps_) && (w4 == 1 || bc_ceil_div(nch_, cps_) == 1)) return bc_conv_wreg4_launch(g, stream);
-        }
-    }
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;
-    static const int fin_slow = getenv("BC_WREG_FIN_SLOW") ? 0x100 : 0;        // diagnostics: the round-4 in-prologue finalize (every wave, three __syncthreads)
-    g.halo_dbg = fin_slow;
+    g.halo_dbg = 0;
     g.halo_stamps = nullptr;
     int sk = std::max(1, std::min(p.splitk, g.halo_nch));
     g.halo_cps = bc_ceil_div(g.halo_nch, sk);
     p.splitk = bc_ceil_div(g.halo_nch, g.halo_cps);
-    BC_CHECK_ARG(g.halo_cps <= MAX_CH, "bc_gemm(wreg conv): %d channel chunks per split exceed %d (raise splitk)", g.halo_cps, MAX_CH);
+    BC_CHECK_ARG(bc_conv_wreg4_eligible(p, g.halo_cps), "bc_gemm(wreg4 conv): %d channel chunks per split / the GroupNorm span do not fit the half-CU kernel", g.halo_cps);
     BC_CHECK_ARG(p.splitk == 1 || p.slab != nullptr, "bc_gemm(wreg conv): splitk=%d needs a slab", p.splitk);
     const int B = p.M / (p.Hout * p.Wout);
     BC_CHECK_ARG((long long)p.M * std::max(p.lda, p.lda2) < 2147483647LL, "bc_gemm(wreg conv): activation of %d pixels x stride %d exceeds 32-bit element offsets",
                  p.M, std::max(p.lda, p.lda2));
-    dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
+    dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);           // (two half-block workgroups per 160-column block of the weight streams)
     g.wr_plane = make_fastdiv(grid.x * grid.y);
     g.wr_gx = make_fastdiv(grid.x);
     g.wr_gy = make_fastdiv(grid.y);
@@ -827,7 +720,7 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     {
         static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
         static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
-        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && grid.x >= 4);
+        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && p.N / 160 >= 4);     // (as the 8-wave kernel decides)
     }
     // BC_WREG_STAMPS=1 (diagnostics; synchronises the stream after every launch): where the cycles of a three-tile wave and of a staging wave go
     static const bool want_stamps = getenv("BC_WREG_STAMPS") != nullptr;
@@ -870,23 +763,22 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
             }
         }
     } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
+    if (getenv("BC_WREG4_TRACE"))
+        fprintf(stderr, "[wreg4] M=%d N=%d Cin=%d C1=%d A2=%d Hv=%d Wv=%d Hin=%d sk=%d cps=%d grid=(%u,%u,%u) nband=%d tot=%d aff=%d R=%d R2=%d rowvec=%d idx=%d\n", p.M, p.N, p.Cin, p.C1,
+                p.A2 != nullptr, p.Hv, p.Wv, p.Hin, p.splitk, g.halo_cps, grid.x, grid.y, grid.z, g.nband, p.a_tot1 != nullptr, p.a_affine != nullptr, p.R != nullptr,
+                p.R2 != nullptr, p.rowvec != nullptr, p.rowvec_idx != nullptr);
     static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
     if (p.a_tot1) {
         BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && (!p.A2 || p.a_tot2),
-                     "bc_gemm(wreg conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
-        const int cpg = p.Cin / p.a_groups;
-        BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && p.a_groups * 8 <= 1024,
-                     "bc_gemm(wreg conv): channel span %d per workgroup too wide for the in-kernel GroupNorm finalize (max %d): use "
-                     "bc_gn_finalize + a_affine or raise splitk", g.halo_cps * 64 + 2 * cpg, FIN_MAX_CH);
-        BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_wreg_kernel<2>), LDS_TOTAL_FIN));
-        const int lds_fin = std::max(LDS_TOTAL, OFF_FIN + (g.halo_cps * 64 + 2 * cpg) * 16 + 1024);    // (scratch for this span only)
-        hipLaunchKernelGGL((conv_wreg_kernel<2>), grid, dim3(512), lds_fin, stream, g);
+                     "bc_gemm(wreg4 conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
+        BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_wreg4_kernel<2>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg4_kernel<2>), grid, dim3(256), LDS_TOTAL, stream, g);
     } else if (p.a_affine) {
-        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_wreg_kernel<1>), LDS_TOTAL));
-        hipLaunchKernelGGL((conv_wreg_kernel<1>), grid, dim3(512), LDS_TOTAL, stream, g);
+        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_wreg4_kernel<1>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg4_kernel<1>), grid, dim3(256), LDS_TOTAL, stream, g);
     } else {
-        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_wreg_kernel<0>), LDS_TOTAL));
-        hipLaunchKernelGGL((conv_wreg_kernel<0>), grid, dim3(512), LDS_TOTAL, stream, g);
+        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_wreg4_kernel<0>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg4_kernel<0>), grid, dim3(256), LDS_TOTAL, stream, g);
     }
     BC_CHECK_LAUNCH();
     return 0;
