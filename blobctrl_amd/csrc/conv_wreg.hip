@@ -793,16 +793,6 @@ extern "C" int bc_conv_wreg_pack(const bc_half* w, int N, int Cin, bc_half* out,
 
 int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     BcGemm& p = g.p;
-    {   // half-CU workgroups (conv_wreg4.hip) where the launch fits them: BC_WREG4=1 all eligible launches, =2 only unsplit ones
-        const char* w4e = getenv("BC_WREG4");                   // (read per launch: the tests switch it inside one process)
-        const int w4 = w4e ? atoi(w4e) : 0;
-        if (w4) {
-            const int nch_ = p.Cin / 64;
-            const int sk_ = std::max(1, std::min(p.splitk, nch_));
-            const int cps_ = bc_ceil_div(nch_, sk_);
-            if (bc_conv_wreg4_eligible(p, cps_) && (w4 == 1 || bc_ceil_div(nch_, cps_) == 1)) return bc_conv_wreg4_launch(g, stream);
-        }
-    }
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;

@@ -314,9 +314,6 @@ bool bc_gemm_probe_hit();
 int bc_conv_halo_launch(bcg::GemmArgs& g, hipStream_t stream);
 // conv_wreg.hip: the same convolution with the weights streamed into VGPRs from a packed fragment stream (BC_TILE_WREG).
 int bc_conv_wreg_launch(bcg::GemmArgs& g, hipStream_t stream);
-// conv_wreg4.hip: the same convolution as half-CU workgroups (4 waves, 128 pixels x 80 channels, <= 80 KiB of LDS: two per CU)
-int bc_conv_wreg4_eligible(const BcGemm& p, int chunks_per_split);
-int bc_conv_wreg4_launch(bcg::GemmArgs& g, hipStream_t stream);
 // gemm_wreg.hip: small-M projections with the weights streamed into VGPRs (BC_TILE_GW*).
 int bc_gemm_wreg_nt(int tile_cfg);
 int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg);

@@ -233,6 +233,8 @@ class TrunkPlan:
 
         def packed(kind, zname=None, nsplit=1):
             key = (p, kind, zname, nsplit)
+            if os.environ.get("BC_ALIAS_WEIGHTS"):            # (diagnostics: weights.py _ALIAS)
+                key = (Cc, kind, zname is not None, nsplit)
             if key not in cache:
                 cache[key] = pack_rowchain(pw, p, kind, zname, nsplit)
             return cache[key]

@@ -44,15 +44,31 @@ def main():
         seg.run(s, side)
     base = timeit(lambda: run(full))
     print(f"full step: {base:.3f} ms")
-    groups = {"attention": ("attention",), "groupnorm": ("groupnorm", "groupnorm_fused_stats", "gn_finalize"), "layernorm": ("layernorm",),
-              "gn_finalize only": ("gn_finalize",), "transformer (all but attention)": ("layernorm", "ff", "qkv", "attn_out"),
-              "self-attn L0 only": ("attention@8192",), "everything but conv3x3": ("attention", "groupnorm", "groupnorm_fused_stats",
-              "gn_finalize", "layernorm", "ff", "qkv", "attn_out", "conv1x1", "zero_conv"),
-              "ff": ("ff",), "conv3x3+conv_in+up/down": ("conv3x3", "conv_in", "upsample", "downsample", "conv_out"),
-              "qkv+attn_out": ("qkv", "attn_out"), "conv1x1": ("conv1x1",), "zero_conv": ("zero_conv",), "temb": ("temb",)}
-    for name, ks in groups.items():
-        off = [i for i, m in enumerate(full.meta)
-               if m["kind"] in ks or ("attention@8192" in ks and m["kind"] == "attention" and m["shape"][3] == 8192 and m["shape"][4] == 8192)]
+    # (round 5) predicates over the launch metadata: by op kind, by queue, by level (rows of the output), by kernel
+    rows = lambda m: (m.get("shape") or (None, 0))[1] if m["kind"] != "attention" else 0
+    variant = lambda m: m.get("variant") or ""
+    groups = {
+        "BlobNet queue (everything on stream 1)": lambda m: m["sid"] == 1,
+        "attention": lambda m: m["kind"] == "attention",
+        "attention D=40 (8192 tokens)": lambda m: m["kind"] == "attention" and m["shape"][2] == 40,
+        "attention D=80 / 160": lambda m: m["kind"] == "attention" and m["shape"][2] in (80, 160),
+        "row-chain (all)": lambda m: m["kind"] in ("rowchain", "rowchain_sum"),
+        "row-chain 320 channels": lambda m: m["kind"] == "rowchain" and m["shape"][2] == 320,
+        "row-chain 640 channels (+ sum)": lambda m: m["kind"] in ("rowchain", "rowchain_sum") and m["shape"][2] == 640,
+        "conv3x3 (ResBlock convolutions)": lambda m: m["kind"] == "conv3x3",
+        "conv3x3 at 64 x 128": lambda m: m["kind"] == "conv3x3" and rows(m) in (16384, 8192),
+        "conv3x3 at 32 x 64": lambda m: m["kind"] == "conv3x3" and rows(m) in (4096, 2048),
+        "conv3x3 at 16 x 32 and 8 x 16": lambda m: m["kind"] == "conv3x3" and rows(m) in (1024, 512, 256, 128),
+        "up / down-sample convolutions, conv_in / out": lambda m: m["kind"] in ("upsample", "downsample", "conv_in", "conv_out"),
+        "gemm_wreg projections (1280-channel levels)": lambda m: "gemm_wreg" in variant(m),
+        "feed-forward of the 1280-channel levels": lambda m: m["kind"] == "ff",
+        "1x1 convolutions (shortcuts, proj_in / out)": lambda m: m["kind"] == "conv1x1",
+        "zero-convs": lambda m: m["kind"] == "zero_conv",
+        "GroupNorm passes + statistics": lambda m: m["kind"] in ("groupnorm", "groupnorm_fused_stats", "gn_finalize", "gn_stats", "memset"),
+    }
+    out = {}
+    for name, pred in groups.items():
+        off = [i for i, m in enumerate(full.meta) if m["kind"] not in ("event_record", "event_wait", "assemble", "cfg_step") and pred(m)]
         for i in off:
             full.enable(i, False)
         full.release()
@@ -60,9 +76,14 @@ def main():
         torch.cuda.synchronize()
         full.capture(s, side)
         t = timeit(lambda: run(full))
-        print(f"without {name:26s} ({len(off):3d} launches): {t:7.3f} ms  -> marginal cost {base - t:6.3f} ms", flush=True)
+        out[name] = dict(launches=len(off), step_ms_without=round(t, 3), marginal_ms=round(base - t, 3))
+        print(f"without {name:46s} ({len(off):3d} launches): {t:7.3f} ms  -> marginal cost {base - t:6.3f} ms", flush=True)
         for i in off:
             full.enable(i, True)
+    if os.environ.get("ABLATE_DUMP"):
+        import json
+        with open(os.environ["ABLATE_DUMP"], "w") as f:
+            json.dump(dict(full_step_ms=round(base, 3), without=out), f, indent=1)
     full.release()
     full.capture(s, side)
 
