@@ -1,7 +1,6 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh > gpurun_out/r5_profile_round.log 2>&1; tail -5 gpurun_out/r5_profile_round.log
-ls gpurun_out/prof | head
-CP_DUMP=gpurun_out/r5_cp.json python tools/critical_path.py > gpurun_out/r5_critical_path.txt 2>&1; head -4 gpurun_out/r5_critical_path.txt
-CT_DUMP=gpurun_out/r5_ct.json python tools/concurrent_timeline.py > gpurun_out/r5_concurrent_timeline.txt 2>&1; head -3 gpurun_out/r5_concurrent_timeline.txt
+timeout 900 python -m pytest tests/test_conv_halo_gpu.py tests/test_vae_gpu.py -x -q 2>&1 | tail -2
+bash tools/ab_bench.sh gpurun_out/ab9 "BC_WREG_NT=0" "BC_X=0" "BC_WREG_NT=1"
+python tools/conv_repeat.py > gpurun_out/r5_conv_repeat.txt 2>&1; grep -c "0 of" gpurun_out/r5_conv_repeat.txt; grep -v "0 of\|amdgpu" gpurun_out/r5_conv_repeat.txt | head -3
