@@ -71,8 +71,7 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 template <int V> using IC = std::integral_constant<int, V>;
 
 // AFFINE: 0 = plain convolution, 1 = affine table from global memory (bc_gn_finalize ran), 2 = GroupNorm finalize in the prologue
-// WNT: non-temporal weight loads (launches whose weight fragments are read by few workgroups: the low-resolution levels)
-template <int AFFINE, bool WNT>
+template <int AFFINE>
 __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BcGemm& p = g.p;
@@ -247,12 +246,10 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         u32x4v ring[3 * G];
         const unsigned lane16 = lane * 16;
         // fragments [GX * G, GX * G + G) of the chunk at BASE (wave-uniform); 13-bit immediate: one scalar base per four fragments
-        // (WNT: the weight ring's loads carry the non-temporal hint - see the launcher)
 #define BC_WREG_LOAD_GROUP(GX, BASE)                                                                                                  \
     _Pragma("unroll") for (int f = 0; f < G; ++f) {                                                                                   \
         const h16* b4 = (BASE) + (((GX) * G + f) & ~3) * 512;                                                                          \
-        if constexpr (WNT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(ring[(GX) * G + f]) : "v"(lane16), "s"(b4), "n"((((GX) * G + f) & 3) * 1024) : "memory"); \
-        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ring[(GX) * G + f]) : "v"(lane16), "s"(b4), "n"((((GX) * G + f) & 3) * 1024) : "memory"); \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ring[(GX) * G + f]) : "v"(lane16), "s"(b4), "n"((((GX) * G + f) & 3) * 1024) : "memory"); \
     }
         const h16* wb = reinterpret_cast<const h16*>(p.W) + ((long long)ntile * 20 + 2 * tile0 + kg * NT) * g.halo_nch * per_chunk +
                         (long long)c_begin * NT * per_chunk;     // wave-uniform stream pointer (chunk cl)
@@ -863,23 +860,7 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
             }
         }
     } report{stream, nwg_s, g.halo_stamps, p, g.halo_cps};
-    // Non-temporal weight loads where few workgroups share a weight fragment (the pixel tiles of the launch: grid.y <= 8 = the 16 x 32 and
-    // 8 x 16 levels at batch 1).  MI355X_MICROARCH "nt-weights": a once-read stream loaded nt does not displace what L2 / the memory-side cache
-    // hold for the others; measured alone (tools/conv_probe.py, cold): 8 x 16 1280->1280 46.6 -> 42.6 us, 16 x 32 63.0 -> 61.8, but 64 x 128
-    // 49.5 -> 50.9 (every XCD re-reads those weights 32 times) and 9.27 vs 9.21 ms per step with nt everywhere - hence by grid.
-    static const int nt_env = getenv("BC_WREG_NT") ? atoi(getenv("BC_WREG_NT")) : -1;      // -1 auto, 0 never, 1 always (experiments)
-    const bool nt = nt_env >= 0 ? nt_env != 0 : grid.y <= 8;
-    static std::atomic<unsigned long long> set_a[2], set_p[2], set_f[2];
-#define BC_WREG_LAUNCH(AFF, SET, LDSB)                                                                                          \
-    do {                                                                                                                        \
-        if (nt) {                                                                                                               \
-            BC_CHECK_HIP(bc_set_max_lds(SET[1], reinterpret_cast<const void*>(&conv_wreg_kernel<AFF, true>), LDSB##_MAX));      \
-            hipLaunchKernelGGL((conv_wreg_kernel<AFF, true>), grid, dim3(512), LDSB, stream, g);                                \
-        } else {                                                                                                                \
-            BC_CHECK_HIP(bc_set_max_lds(SET[0], reinterpret_cast<const void*>(&conv_wreg_kernel<AFF, false>), LDSB##_MAX));     \
-            hipLaunchKernelGGL((conv_wreg_kernel<AFF, false>), grid, dim3(512), LDSB, stream, g);                               \
-        }                                                                                                                       \
-    } while (0)
+    static std::atomic<unsigned long long> set_a{0}, set_p{0}, set_f{0};
     if (p.a_tot1) {
         BC_CHECK_ARG(p.a_gamma && p.a_beta && p.a_groups > 0 && p.Cin % p.a_groups == 0 && (!p.A2 || p.a_tot2),
                      "bc_gemm(wreg conv): in-kernel GroupNorm finalize needs a_gamma, a_beta, a_groups | Cin and the partials of every source");
@@ -887,17 +868,16 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
         BC_CHECK_ARG(g.halo_cps * 64 + 2 * cpg <= FIN_MAX_CH && p.a_groups * 8 <= 1024,
                      "bc_gemm(wreg conv): channel span %d per workgroup too wide for the in-kernel GroupNorm finalize (max %d): use "
                      "bc_gn_finalize + a_affine or raise splitk", g.halo_cps * 64 + 2 * cpg, FIN_MAX_CH);
+        BC_CHECK_HIP(bc_set_max_lds(set_f, reinterpret_cast<const void*>(&conv_wreg_kernel<2>), LDS_TOTAL_FIN));
         const int lds_fin = std::max(LDS_TOTAL, OFF_FIN + (g.halo_cps * 64 + 2 * cpg) * 16 + 1024);    // (scratch for this span only)
-        constexpr int lds_fin_MAX = LDS_TOTAL_FIN;
-        BC_WREG_LAUNCH(2, set_f, lds_fin);
+        hipLaunchKernelGGL((conv_wreg_kernel<2>), grid, dim3(512), lds_fin, stream, g);
     } else if (p.a_affine) {
-        constexpr int lds_plain = LDS_TOTAL, lds_plain_MAX = LDS_TOTAL;
-        BC_WREG_LAUNCH(1, set_a, lds_plain);
+        BC_CHECK_HIP(bc_set_max_lds(set_a, reinterpret_cast<const void*>(&conv_wreg_kernel<1>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg_kernel<1>), grid, dim3(512), LDS_TOTAL, stream, g);
     } else {
-        constexpr int lds_plain = LDS_TOTAL, lds_plain_MAX = LDS_TOTAL;
-        BC_WREG_LAUNCH(0, set_p, lds_plain);
+        BC_CHECK_HIP(bc_set_max_lds(set_p, reinterpret_cast<const void*>(&conv_wreg_kernel<0>), LDS_TOTAL));
+        hipLaunchKernelGGL((conv_wreg_kernel<0>), grid, dim3(512), LDS_TOTAL, stream, g);
     }
-#undef BC_WREG_LAUNCH
     BC_CHECK_LAUNCH();
     return 0;
 }

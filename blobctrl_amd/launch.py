@@ -496,14 +496,7 @@ class Recorder:
         FAST = {1: "256, 128, 4, 2, 3", 2: "128, 128, 2, 2, 3", 3: "128, 128, 2, 2, 2", 4: "256, 64, 4, 1, 2", 5: "256, 64, 4, 1, 3",
                 6: "128, 64, 2, 2, 3", 7: "64, 64, 2, 2, 4"}
         if cfg in (_lib.TILE_HALO, _lib.TILE_WREG):
-            aff = 2 if g.a_tot1 else 1 if g.a_affine else 0
-            if cfg == _lib.TILE_WREG:
-                # (csrc/conv_wreg.hip's launcher: non-temporal weight loads where <= 8 pixel tiles share a weight fragment)
-                nt_env = os.environ.get("BC_WREG_NT")
-                nt = (int(nt_env) != 0) if nt_env is not None else (M // 128) <= 8
-                rp = f"conv_wreg_kernel<{aff}, {'true' if nt else 'false'}>"
-            else:
-                rp = f"conv_halo_kernel<{aff}>"
+            rp = ("conv_wreg_kernel" if cfg == _lib.TILE_WREG else "conv_halo_kernel") + f"<{2 if g.a_tot1 else 1 if g.a_affine else 0}>"
         elif cfg in _lib.GW_TILES:
             rp = f"gemm_wreg_kernel<{_lib.GW_TILES[cfg]}, {10 if _lib.GW_TILES[cfg] == 5 else 20}>"
         elif fast:
