@@ -60,7 +60,10 @@ def test_halo_conv_plain(rec, tile, B, H, W, Cin, Cout, sk):
 @pytest.mark.parametrize("finalize", ["launch", "in_kernel"])
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout,sk,silu", [(2, 16, 16, 128, 0, 160, 1, True), (1, 8, 32, 64, 128, 320, 1, True),
                                                        (2, 8, 16, 320, 320, 160, 2, True), (1, 16, 32, 128, 0, 160, 1, False),
-                                                       (1, 8, 16, 640, 320, 160, 3, True)])
+                                                       (1, 8, 16, 640, 320, 160, 3, True),
+                                                       # a 1280-channel span in ONE workgroup: wider than the counted-wait finalize of
+                                                       # conv_wreg.hip takes (1024 channels) - its round-4 form, every wave, three barriers
+                                                       (1, 8, 16, 1280, 0, 160, 1, True)])
 def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, Cout, sk, silu, finalize, monkeypatch):
     """GroupNorm statistics from a standalone pass -> bc_gn_finalize -> affine applied in the halo staging (zero padding AFTER the
     activation), two channel-concatenated sources, and the whole ResBlock epilogue: bias + time-embedding row vector + residual +
