@@ -70,6 +70,8 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
     BlobNet right-half residual + GroupNorm partials of the output."""
     from blobctrl_amd import _lib
     from blobctrl_amd.weights import pack_conv3x3
+    if tile == "halo" and finalize == "in_kernel" and C1 + C2 > 1024 and sk == 1:
+        pytest.skip("conv_halo.hip re-reduces partial tables in its prologue only for narrow spans; the recorder falls back to a finalize launch")
     Cin, G = C1 + C2, 8
     x1 = g(1, B, C1, H, W) * 1.7 + 0.3
     x2 = g(4, B, C2, H, W) * 0.6 - 0.2 if C2 else None
