@@ -70,8 +70,8 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
     BlobNet right-half residual + GroupNorm partials of the output."""
     from blobctrl_amd import _lib
     from blobctrl_amd.weights import pack_conv3x3
-    if tile == "halo" and finalize == "in_kernel" and C1 + C2 > 1024 and sk == 1:
-        pytest.skip("conv_halo.hip re-reduces partial tables in its prologue only for narrow spans; the recorder falls back to a finalize launch")
+    # (conv_halo.hip finalizes in its prologue only for narrow spans: for the 1280-channel case the recorder falls back to a finalize launch there)
+    halo_falls_back = tile == "halo" and C1 + C2 > 1024 and sk == 1
     Cin, G = C1 + C2, 8
     x1 = g(1, B, C1, H, W) * 1.7 + 0.3
     x2 = g(4, B, C2, H, W) * 0.6 - 0.2 if C2 else None
@@ -94,7 +94,7 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
                        splitk=sk, a_act=_lib.ACT_SILU if silu else _lib.ACT_NONE, rowvec=h(temb), ld_rowvec=Cout,
                        R=nhwc(R), ldr=Cout, R2=nhwc(R2), ldr2=Cout, r2_xmin=W - H if W > H else 0, r2_bmod=1, out_w=W, want_gn=True,
                        **kw)
-        if finalize == "in_kernel":
+        if finalize == "in_kernel" and not halo_falls_back:
             assert "gnfin" in rec.seg.meta[-1]["variant"], rec.seg.meta[-1]["variant"]
         return out, rec.tots[out.data_ptr()]
     out, part = run(rec, fn)
