@@ -331,7 +331,7 @@ class TrunkPlan:
         def proj(a_t, wname, N, K, cfg, ln=None, bias=True, extra=(), **kw):
             for c in (cfg, G128, G320, G256):                 # (the preferred workgroup shape, else one that divides N and the split point)
                 bn = 64 * _lib.GW_TILES[c]
-                if N % bn == 0 and kw.get("n_t0", 0) % bn == 0 and rec.lib.bc_gemm_wreg_eligible(M, N, K, 0, c):
+                if N % bn == 0 and kw.get("n_t0", 0) % bn == 0 and rec.lib.bc_gemm_wreg_eligible(M, N, K, kw.get("C1", 0), c):
                     cfg = c
                     break
             w, cs, b = pw.gw(wname + ".weight", cfg, ln=ln, bias=(wname + ".bias") if bias else None, extra=extra)
@@ -366,6 +366,14 @@ class TrunkPlan:
         # (64 x 128 workgroups everywhere: two fit a CU - 80 KiB of LDS each - and measure best at every shape of these levels, e.g.
         #  LayerNorm + GEGLU [1024 x 10240 x 1280] 51.7 us against 53.5 / 54.8 for the 256- / 320-column workgroups: tools/gw_probe.py)
         g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G128, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
+        if not os.environ.get("BC_NO_FF2_PROJ_OUT") and not os.environ.get("BC_NO_GW_FF2") and rec.lib.bc_gemm_wreg_eligible(M, Cc, 5 * Cc, 4 * Cc, G128):
+            # ff.net.2 + residual + proj_out as ONE two-source GEMM over [g | h] with the weight [P F2 | P] made at pack time
+            # (weights.ff2_proj_out): at these levels a launch on the UNet's queue costs ~40 us INSIDE the step - three times what it
+            # takes alone (tools/ablate_probe.py: the six attn2.to_q launches 0.245 ms) - and this one is pure algebra
+            k = pw.ff2_proj_out(p)
+            out = proj(g, k, Cc, 5 * Cc, G128, A2=h, C1=4 * Cc, lda=4 * Cc, lda2=Cc, R=x.t, ldr=Cc, kind="ff", rows_per_batch=HW, want_gn=True,
+                       **self._r2(r2, x.H, x.W))
+            return Act(out, Cc, x.H, x.W), None
         if not os.environ.get("BC_NO_GW_FF2"):
             # ff.net.2 (K = 4C) unsplit on gemm_wreg: the same step time as the LDS-DMA tiles with split-K 3 (9.42 vs 9.42 ms, same box,
             # two rounds), without their 15.7 MB of fp32 slabs and the reducer launch

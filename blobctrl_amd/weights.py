@@ -142,6 +142,21 @@ class PackedTrunk:
             cache[ck] = (pack_gemm_wreg(w, nt), cs, b)
         return cache[ck]
 
+    def ff2_proj_out(self, p: str) -> str:
+        """`ff.net.2` and `proj_out` of the Transformer2D block `p` as ONE weight (round 5): proj_out(ff.net.2(g) + b2 + h2) + bpo =
+        [P F2 | P] . [g | h2] + (P b2 + bpo) - the two projections are consecutive linear maps with only the residual add between them
+        (attention.py:530-541 `ff_output + hidden_states`, transformer_2d.py:516-523 `proj_out`), so the product is made once, in
+        fp32, when the weights are packed, and the step runs one two-source GEMM (K = 4C + C) instead of two dependent launches.
+        Returns the key of the merged matrix [C][5C] (its bias under key + ".bias")."""
+        k = p + "ff2_proj_out"
+        if k + ".weight" not in self.h:
+            bp = p + "transformer_blocks.0."
+            P = self.h[p + "proj_out.weight"].float()
+            F2 = self.h[bp + "ff.net.2.weight"].float()
+            self.h[k + ".weight"] = torch.cat([P @ F2, P], 1).half().contiguous()
+            self.f[k + ".bias"] = (P @ self.f[bp + "ff.net.2.bias"].float() + self.f[p + "proj_out.bias"].float()).contiguous()
+        return k
+
     def wreg(self, key: str) -> str:
         """Key of the BC_TILE_WREG fragment stream of the packed 3x3 weight `key` (made on first use, kept beside the matrix)."""
         k2 = key + "_wreg"

@@ -132,6 +132,8 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     if mode == "rowchain_tail":
         assert any("out_ff/2" in v for v in variants) and any("out_tail" in v for v in variants), variants
     if mode == "gw":
+        # (round 5) ff.net.2 + residual + proj_out run as ONE two-source GEMM with the pack-time product [P F2 | P]: K = 5C
+        assert any(m["kind"] == "ff" and m["shape"][3] == 5 * p["C"] for m in rec.seg.meta), [m["shape"] for m in rec.seg.meta if m["kind"] == "ff"]
         assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
         assert not any(k.startswith("groupnorm") for k in kinds) and sum("_gn" in v for v in variants) == 1, (kinds, variants)
     _run(seg)

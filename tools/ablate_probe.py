@@ -62,6 +62,9 @@ def main():
         "up / down-sample convolutions, conv_in / out": lambda m: m["kind"] in ("upsample", "downsample", "conv_in", "conv_out"),
         "gemm_wreg projections (1280-channel levels)": lambda m: "gemm_wreg" in variant(m),
         "feed-forward of the 1280-channel levels": lambda m: m["kind"] == "ff",
+        "attn2.to_q of the 1280-channel blocks (UNet)": lambda m: m["kind"] == "qkv" and (m.get("shape") or ("",))[0] == "gw_ln",
+        "cross-attention launches (77 keys, D = 160)": lambda m: m["kind"] == "attention" and m["shape"][4] == 77,
+        "split-K convolutions only (16 x 32, 8 x 16) - reducers included": lambda m: m["kind"] == "conv3x3" and "splitk" in variant(m),
         "1x1 convolutions (shortcuts, proj_in / out)": lambda m: m["kind"] == "conv1x1",
         "zero-convs": lambda m: m["kind"] == "zero_conv",
         "GroupNorm passes + statistics": lambda m: m["kind"] in ("groupnorm", "groupnorm_fused_stats", "gn_finalize", "gn_stats", "memset"),
