@@ -416,7 +416,11 @@ class Recorder:
                 # more than one that fills the chip: 192 / 3 instead of round 2's 256 / 2 - the UNet's 32 x 64 convolutions (128 pixel x
                 # column tiles) now run unsplit, the 8 x 16 level in 5 instead of 10 splits - is 9.53 -> 9.29 ms per step (same box,
                 # two rounds; 128 ... 192 within 0.05 ms of each other, 224: 9.56, 384: 9.79).
-                target = int(os.environ.get("BC_HALO_CTAS", "192" if tile_cfg == _lib.TILE_WREG else "256"))
+                # Round 5, re-swept on the final kernels (two boxes, two rounds each, ms per step): 192: 9.386 / 9.382 and 9.160 / 9.148;
+                # 144: 9.354 / 9.339; 128: 9.323 / 9.330 and 9.081 / 9.087; 112: 9.070 / 9.049; 96: 9.474 / 9.493 - the UNet's 16 x 32
+                # convolutions in 2 instead of 3 splits, BlobNet's in 4 instead of 6 (fewer slabs for the reducer); batch 2: 15.58 / 15.74
+                # vs 15.85 / 15.78; batch 8 and 768^2 batch 4 unchanged (52.8 / 52.7 vs 52.7 / 52.6; 80.5 / 80.4 vs 80.5 / 80.4).
+                target = int(os.environ.get("BC_HALO_CTAS", "128" if tile_cfg == _lib.TILE_WREG else "256"))
                 min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "3" if tile_cfg == _lib.TILE_WREG else "2"))
                 # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the 64 x 128
                 # BlobNet and 32 x 64 UNet convolutions run as one pass instead of two K halves + a reducer: 13 reducer launches and
