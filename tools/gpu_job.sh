@@ -1,6 +1,6 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-bash tools/sweep_batch.sh gpurun_out/sw_b8 "--batch 8" "BC_X=0" "BC_HALO_CTAS=128"
-bash tools/sweep_batch.sh gpurun_out/sw_768 "--res 768 --batch 4" "BC_X=0" "BC_HALO_CTAS=128"
-bash tools/sweep_batch.sh gpurun_out/sw_b2b "--batch 2" "BC_X=0" "BC_HALO_CTAS=128"
+python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm_wreg" 2>&1 | tail -5
+BC_GW_PREFER=64 python -m pytest tests/test_blocks_gpu.py -q -x 2>&1 | tail -3
+bash tools/ab_bench.sh gpurun_out/ab16 "BC_X=0" "BC_GW_PREFER=64"
