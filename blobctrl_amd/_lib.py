@@ -43,6 +43,7 @@ class BcGemm(C.Structure):
         ("a_gamma", C.c_void_p), ("a_beta", C.c_void_p), ("a_groups", C.c_int), ("a_eps", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("C_t", C.c_void_p), ("ldc_t", C.c_int), ("n_t0", C.c_int),
+        ("w_bstride", C.c_longlong), ("vec_bstride", C.c_int), ("sm_group", C.c_int), ("sm_valid", C.c_int), ("sm_keep", C.c_int),
     ]
 
 
@@ -104,6 +105,8 @@ _SIGNATURES = {
     "bc_rowchain_sum": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bc_rowchain_kv_frags": (C.c_longlong, [C.c_int]),
     "bc_rowchain_pack_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bc_ctx_fold": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bc_rowchain_midx": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     # ---- plan runtime (plan.hip)
@@ -148,7 +151,7 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
        "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23, "bc_memset_zero": 24,
-       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26, "bc_rowchain_sum": 27}
+       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26, "bc_rowchain_sum": 27, "bc_ctx_fold": 28}
 OP_SIGNAL, OP_WAIT = 20, 21
 CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL, CHAIN_MIDX, CHAIN_OUT_FFP = 0, 1, 2, 3, 4, 5, 6
 GN_TOT_WORDS = 6                      # 64-bit words per (image, channel) of a GroupNorm statistics table (include/blobctrl_hip.h)

@@ -477,11 +477,16 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         BC_CHECK_ARG(p.N % 64 == 0, "bc_gemm: GEGLU needs N%%64==0 (got %d)", p.N);
         g.n_out = p.N / 2;
     }
+    if (p.sm_group > 0) {                             // softmax epilogue: sm_keep of every sm_group columns are written
+        BC_CHECK_ARG(p.sm_keep > 0 && p.sm_keep <= p.sm_group && p.N % p.sm_group == 0, "bc_gemm: bad sm_group / sm_keep (%d / %d, N=%d)", p.sm_group, p.sm_keep, p.N);
+        g.n_out = p.N / p.sm_group * p.sm_keep;
+    }
     if (p.R) BC_CHECK_ARG(p.ldr >= g.n_out, "bc_gemm: ldr too small");
     if (p.R2) BC_CHECK_ARG(p.ldr2 >= g.n_out && p.r2_bmod > 0, "bc_gemm: bad R2 params");
     if (p.rowvec) BC_CHECK_ARG(p.ld_rowvec >= p.N, "bc_gemm: ld_rowvec too small");
     const bool gw = bc_gemm_wreg_nt(p.tile_cfg) != 0;
     BC_CHECK_ARG(gw || (!p.ln_colsum && !p.C_t), "bc_gemm: ln_colsum / C_t need a BC_TILE_GW* configuration");
+    BC_CHECK_ARG(gw || (!p.w_bstride && !p.vec_bstride && !p.sm_group), "bc_gemm: w_bstride / vec_bstride / sm_group need a BC_TILE_GW* configuration");
     if (p.out_mode == BC_OUT_F16_T) {
         BC_CHECK_ARG(p.M % p.rows_per_batch == 0 && p.ldc >= p.rows_per_batch, "bc_gemm: transposed output needs M%%rows_per_batch==0, ldc>=rows_per_batch");
     } else {

@@ -23,6 +23,9 @@
 //         rstd_r (acc[r][n] - mean_r colsum[n]) + bias'[n],   colsum[n] = sum_k W'[n][k],  bias' = bias + W beta:
 //     no LayerNorm launch, no normalised activation in HBM;
 //   * q | k | V^T in one launch (BcGemm.C_t): column tiles from n_t0 on are written transposed [B][N - n_t0][ldc_t].
+//   * per-image weight streams (BcGemm.w_bstride) and a row softmax over the workgroup's 128 columns in the epilogue (BcGemm.sm_group: a
+//     64 x 128 workgroup = the keys of one head, padded): the two launches of a cross-attention whose prompt is folded into the weights
+//     once per edit (bc_ctx_fold below) - scores = LN(x) QK^T never leave the launch.
 // XCD placement: consecutive workgroups of an XCD share a COLUMN tile (all its row blocks), so an XCD's L2 fetches each weight
 // stream once.
 #include <stdlib.h>
@@ -97,7 +100,8 @@ __device__ __forceinline__ void gemm_chunk(f32x4v (&acc)[NT][4], WRing<R>& r, co
 template <int BN>
 __device__ __forceinline__ int tile_off(int row, int c0) { return row * BN + (c0 ^ ((row & 7) << 2)); }
 
-template <int NT, int R>
+// SM: the instantiation with the softmax epilogue (BcGemm.sm_group) - its own kernel, so that the projections' one stays as it was
+template <int NT, int R, bool SM = false>
 __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     constexpr int BN = 64 * NT;
     static_assert((NT * GW_KC) % R == 0, "a chunk must consume a whole number of rings");
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     }
 
     WRing<R> ring;
-    ring.p = reinterpret_cast<const uint4*>(p.W) + ((size_t)(jt * 4 + wave) * KS * NT) * 64 + lane;
+    const int wimg = p.w_bstride ? (int)fdiv((unsigned)m0, g.div_rpb) : 0;       // per-image weights: this row block's image
+    ring.p = reinterpret_cast<const uint4*>(p.W + (size_t)wimg * p.w_bstride) + ((size_t)(jt * 4 + wave) * KS * NT) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < R; ++i) ring.f[i] = ring.p[i * 64];
     ring.p += R * 64;
@@ -271,6 +276,58 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     }
     __syncthreads();
 
+    if constexpr (SM) {
+        {
+            // row softmax over the tile's 128 columns (a head's padded keys, the first sm_valid real): four threads per row, 32 columns
+            // each, maximum and sum through the quad; the first sm_keep columns are written, compacted to sm_keep per head
+            const int valid = p.sm_valid, keep = p.sm_keep;
+            const int vimg = p.vec_bstride ? (int)fdiv((unsigned)m0, g.div_rpb) : 0;
+            const float* csp = ln ? p.ln_colsum + (size_t)vimg * p.vec_bstride + n0 : nullptr;
+            const float* bp = p.bias ? p.bias + (size_t)vimg * p.vec_bstride + n0 : nullptr;
+            const int row = tid >> 2, c0 = (tid & 3) * 32;
+            const float mean = ln ? stat[row * 2] : 0.f, rstd = ln ? stat[row * 2 + 1] : 1.f;
+            float v[32];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, c0 + j4 * 4));
+                const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = c0 + j4 * 4 + e;
+                    float x = tv[e];
+                    if (ln) x = rstd * (x - mean * csp[j]);
+                    if (bp) x += bp[j];
+                    x = j < valid ? x : -3.0e38f;
+                    v[j4 * 4 + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                v[j] = (c0 + j) < valid ? exp2f((v[j] - mx) * 1.44269504088896f) : 0.f;
+                sum += v[j];
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const float inv = 1.f / sum;
+            h16* dst = reinterpret_cast<h16*>(p.C) + (size_t)(m0 + row) * p.ldc + jt * keep + c0;
+#pragma unroll
+            for (int j8 = 0; j8 < 4; ++j8) {
+                if (c0 + j8 * 8 < keep) {
+                    uint4 outraw;
+                    h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (h16)(v[j8 * 8 + e] * inv);
+                    bc_st16(dst + j8 * 8, outraw);
+                }
+            }
+            return;
+        }
+    }
     if (p.C_t && n0 >= p.n_t0) {
         // transposed output (V^T for the attention kernel): thread = (column, 8 consecutive tokens) -> one 16-byte store
         const int b = (int)fdiv((unsigned)m0, g.div_rpb);
@@ -364,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     }
 }
 
-template <int NT, int R>
+template <int NT, int R, bool SM = false>
 int launch_gw(const GemmArgs& g, hipStream_t stream) {
     constexpr int BN = 64 * NT;
     // two operand buffers | the fp32 epilogue tile + the LayerNorm statistics behind it (the tile of NT <= 4 leaves room inside the 80 KiB)
@@ -372,9 +429,9 @@ int launch_gw(const GemmArgs& g, hipStream_t stream) {
     static_assert(NT == 5 || 2 * LDS <= 160 * 1024, "two workgroups per CU");
     constexpr int LDS_MAX = LDS + 2560 * 8;                  // + the GroupNorm (a, b) table of up to 2560 channels (one workgroup per CU then)
     static std::atomic<unsigned long long> lds_set{0};
-    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_wreg_kernel<NT, R>), LDS_MAX));
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm_wreg_kernel<NT, R, SM>), LDS_MAX));
     const int grid = (g.p.M / GW_BM) * (g.p.N / BN);
-    hipLaunchKernelGGL((gemm_wreg_kernel<NT, R>), dim3(grid), dim3(256), LDS + (g.p.a_tot1 ? g.p.K * 8 : 0), stream, g);
+    hipLaunchKernelGGL((gemm_wreg_kernel<NT, R, SM>), dim3(grid), dim3(256), LDS + (g.p.a_tot1 ? g.p.K * 8 : 0), stream, g);
     BC_CHECK_LAUNCH();
     return 0;
 }
@@ -394,6 +451,128 @@ __global__ void gw_pack_kernel(const h16* __restrict__ w, int ldw, int N, int K,
     const int n = jt * 64 * NT + wave * 16 * NT + 16 * t + (lane & 15);
     const int k = 32 * s + 8 * (lane >> 4);
     out[idx] = *reinterpret_cast<const uint4*>(w + (size_t)n * ldw + k);
+}
+
+// ---------------------------------------------------------------------------------------------- prompt folded into the weights (bc_ctx_fold)
+constexpr int CF_KEYS = 80;             // keys per head the fold computes (BcGemm.sm_keep of the consumer: columns of the probabilities)
+constexpr int CF_GROUP = 128;           // rows per head in the QK stream (BcGemm.sm_group: one 64 x 128 workgroup per head; rows >= 80 stay zero)
+constexpr int CF_DMAX = 160;            // head width the LDS staging holds
+
+// 16-byte piece of W[n][8 k8 .. + 8] inside a BC_TILE_GW* stream of NT tiles per wave and KS k-steps (gw_pack_kernel's order)
+__device__ __forceinline__ size_t gw_piece(int n, int k8, int NT, int KS) {
+    const int bn = 64 * NT;
+    const int jt = n / bn, r = n - jt * bn;
+    const int wave = r / (16 * NT), r2 = r - wave * 16 * NT;
+    return ((((size_t)(jt * 4 + wave) * KS + (k8 >> 2)) * NT + (r2 >> 4)) * 64) + (k8 & 3) * 16 + (r2 & 15);
+}
+
+// QK[b][(h, j)][c] = scale sum_d k[b][j][h D + d] wq[h D + d][c]: workgroup = (20 keys, head, image), thread = (10 keys, 8 columns c);
+// the column sums of the ROUNDED rows and the bias row scale k . bq come out of the same workgroup (fixed summation order).
+__global__ __launch_bounds__(320) void ctx_fold_qk_kernel(const h16* __restrict__ k, int ldk, int T, int C, int heads, float scale,
+                                                          const h16* __restrict__ wq, const float* __restrict__ bq, uint4* __restrict__ wqk,
+                                                          long long wqk_stride16, float* __restrict__ colsum, float* __restrict__ qbias) {
+    __shared__ float ks[20][CF_DMAX];
+    __shared__ float psum[20][160];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = C / heads, j0 = blockIdx.x * 20;
+    for (int i = tid; i < 20 * D; i += 320) {
+        const int jl = i / D, d = i - jl * D;
+        ks[jl][d] = (j0 + jl) < T ? (float)k[((size_t)b * T + j0 + jl) * ldk + h * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int half = tid / 160, kl = tid - half * 160;
+    const int KS = C / 32, N = heads * CF_GROUP;
+    uint4* out = wqk + (size_t)b * wqk_stride16;
+    float cs[10];
+#pragma unroll
+    for (int jj = 0; jj < 10; ++jj) cs[jj] = 0.f;
+    for (int k8 = kl; k8 < C / 8; k8 += 160) {
+        float acc[10][8];
+#pragma unroll
+        for (int jj = 0; jj < 10; ++jj)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[jj][e] = 0.f;
+        const h16* wp = wq + (size_t)h * D * C + k8 * 8;
+        for (int d = 0; d < D; ++d) {
+            const h16x8 w8 = *reinterpret_cast<const h16x8*>(wp + (size_t)d * C);
+            float wf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[e] = (float)w8[e];
+#pragma unroll
+            for (int jj = 0; jj < 10; ++jj) {
+                const float kv = ks[half * 10 + jj][d];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[jj][e] = fmaf(kv, wf[e], acc[jj][e]);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 10; ++jj) {
+            uint4 raw;
+            h16* o = reinterpret_cast<h16*>(&raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (h16)(acc[jj][e] * scale);
+                cs[jj] += (float)o[e];
+            }
+            out[gw_piece(h * CF_GROUP + j0 + half * 10 + jj, k8, 2, KS)] = raw;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 10; ++jj) psum[half * 10 + jj][kl] = cs[jj];
+    __syncthreads();
+    if (tid < 20) {
+        float s_ = 0.f;
+        for (int i = 0; i < 160; ++i) s_ += psum[tid][i];
+        float bv = 0.f;
+        for (int d = 0; d < D; ++d) bv = fmaf(ks[tid][d], bq[h * D + d], bv);
+        colsum[(size_t)b * N + h * CF_GROUP + j0 + tid] = s_;
+        qbias[(size_t)b * N + h * CF_GROUP + j0 + tid] = bv * scale;
+    }
+}
+
+// VO[b][n][(h, j)] = sum_d wo[n][h D + d] vt[b][h D + d][j]: workgroup = (256 output channels n, head, image), thread = one n, all 80 keys
+__global__ __launch_bounds__(256) void ctx_fold_vo_kernel(const h16* __restrict__ vt, int ldvt, int T, int C, int heads, const h16* __restrict__ wo,
+                                                          uint4* __restrict__ vwo, long long vwo_stride16) {
+    __shared__ __attribute__((aligned(16))) float vs[CF_DMAX][CF_KEYS];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = C / heads;
+    for (int i = tid; i < D * CF_KEYS; i += 256) {
+        const int d = i / CF_KEYS, j = i - d * CF_KEYS;
+        vs[d][j] = j < T ? (float)vt[((size_t)b * C + h * D + d) * ldvt + j] : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (n >= C) return;
+    float acc[CF_KEYS];
+#pragma unroll
+    for (int j = 0; j < CF_KEYS; ++j) acc[j] = 0.f;
+    const h16* wp = wo + (size_t)n * C + h * D;
+    for (int d8 = 0; d8 < D; d8 += 8) {
+        const h16x8 w8 = *reinterpret_cast<const h16x8*>(wp + d8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float wv = (float)w8[e];
+            const float4* vr = reinterpret_cast<const float4*>(vs[d8 + e]);
+#pragma unroll
+            for (int j4 = 0; j4 < CF_KEYS / 4; ++j4) {
+                const float4 v4 = vr[j4];
+                acc[4 * j4] = fmaf(wv, v4.x, acc[4 * j4]);
+                acc[4 * j4 + 1] = fmaf(wv, v4.y, acc[4 * j4 + 1]);
+                acc[4 * j4 + 2] = fmaf(wv, v4.z, acc[4 * j4 + 2]);
+                acc[4 * j4 + 3] = fmaf(wv, v4.w, acc[4 * j4 + 3]);
+            }
+        }
+    }
+    uint4* out = vwo + (size_t)b * vwo_stride16;
+    const int KS = heads * CF_KEYS / 32;
+#pragma unroll
+    for (int j8 = 0; j8 < CF_KEYS / 8; ++j8) {
+        uint4 raw;
+        h16* o = reinterpret_cast<h16*>(&raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)acc[j8 * 8 + e];
+        out[gw_piece(n, h * (CF_KEYS / 8) + j8, 2, KS)] = raw;
+    }
 }
 
 }  // namespace
@@ -417,6 +596,17 @@ int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg) {
     }
     if (p.act != BC_ACT_NONE && p.act != BC_ACT_GEGLU && p.act != BC_ACT_GELU && p.act != BC_ACT_SILU && p.act != BC_ACT_QUICK_GELU) return 0;
     if (p.ln_colsum && p.A2) return 0;               // (the statistics cover one source)
+    if (p.w_bstride || p.vec_bstride) {               // per-image weights: a row block lies inside one image; streams 16-byte aligned
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (p.w_bstride < 0 || p.w_bstride % 8 || p.vec_bstride < 0 || rpb % GW_BM || p.M % rpb) return 0;
+        if (p.vec_bstride && (!p.sm_group || p.vec_bstride < p.N)) return 0;       // (per-image bias / colsum: the softmax epilogue only)
+    }
+    if (p.sm_group) {                                 // softmax epilogue: the 64 x 128 workgroup = one group
+        if (nt != 2 || p.sm_group != 64 * nt || p.sm_valid <= 0 || p.sm_valid > p.sm_keep || p.sm_keep > p.sm_group || p.sm_keep % 8 ||
+            p.ldc < p.N / p.sm_group * p.sm_keep)
+            return 0;
+        if (p.act != BC_ACT_NONE || p.R || p.R2 || p.colscale || p.gn_tot || p.alpha_dev || p.alpha != 1.0f || p.C_t || p.a_tot1 || p.A2) return 0;
+    }
     if (p.C_t) {
         const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
         if (p.n_t0 <= 0 || p.n_t0 % (64 * nt) || p.n_t0 >= p.N || rpb % GW_BM || p.M % rpb || p.ldc_t < rpb || p.ldc_t % 8 ||
@@ -432,7 +622,7 @@ int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg) {
 
 int bc_gemm_wreg_launch(const GemmArgs& g, hipStream_t stream) {
     switch (g.cfg) {
-        case BC_TILE_GW64x128: return launch_gw<2, 20>(g, stream);
+        case BC_TILE_GW64x128: return g.p.sm_group ? launch_gw<2, 20, true>(g, stream) : launch_gw<2, 20>(g, stream);
         case BC_TILE_GW64x256: return launch_gw<4, 20>(g, stream);
         case BC_TILE_GW64x320: return launch_gw<5, 10>(g, stream);
         default: bc_set_error("bc_gemm: not a BC_TILE_GW* configuration (%d)", g.cfg); return 1;
@@ -459,6 +649,25 @@ extern "C" int bc_gemm_wreg_pack(const bc_half* w, int ldw, int N, int K, int ti
     const long long total = (long long)N * K / 8;
     hipLaunchKernelGGL(gw_pack_kernel, dim3(bc_ceil_div(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const h16*>(w), ldw, N, K, nt, reinterpret_cast<uint4*>(out));
+    BC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bc_ctx_fold(const bc_half* k, int ldk, const bc_half* vt, int ldvt, int B, int T, int channels, int heads, float scale,
+                           const bc_half* wq, const float* bq, const bc_half* wo, bc_half* wqk, float* qk_colsum, float* qk_bias, bc_half* vwo,
+                           bc_stream stream) {
+    BC_CHECK_ARG(k && vt && wq && bq && wo && wqk && qk_colsum && qk_bias && vwo, "bc_ctx_fold: null argument");
+    BC_CHECK_ARG(B > 0 && heads > 0 && T > 0 && T <= CF_KEYS && channels > 0 && channels % (8 * heads) == 0 && channels / heads <= CF_DMAX &&
+                 channels % 320 == 0 && (heads * CF_KEYS) % 320 == 0 && ldk >= channels && ldvt >= T,
+                 "bc_ctx_fold: needs T <= 80, channels %% 320 == 0, head width %% 8 == 0 and <= 160, 80 heads %% 320 == 0 (B=%d T=%d C=%d heads=%d)",
+                 B, T, channels, heads);
+    const long long s_qk = bc_gemm_wreg_stream_elems(heads * CF_GROUP, channels), s_vo = bc_gemm_wreg_stream_elems(channels, heads * CF_KEYS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ctx_fold_qk_kernel, dim3(CF_KEYS / 20, heads, B), dim3(320), 0, st, reinterpret_cast<const h16*>(k), ldk, T, channels, heads,
+                       scale, reinterpret_cast<const h16*>(wq), bq, reinterpret_cast<uint4*>(wqk), s_qk / 8, qk_colsum, qk_bias);
+    BC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ctx_fold_vo_kernel, dim3(bc_ceil_div(channels, 256), heads, B), dim3(256), 0, st, reinterpret_cast<const h16*>(vt), ldvt, T,
+                       channels, heads, reinterpret_cast<const h16*>(wo), reinterpret_cast<uint4*>(vwo), s_vo / 8);
     BC_CHECK_LAUNCH();
     return 0;
 }

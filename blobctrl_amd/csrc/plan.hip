@@ -93,6 +93,9 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
             return bc_rowchain_pack_kv(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), I(6), MP(bc_half, 7), s);
         case BC_OP_ROWCHAIN_SUM:
             return bc_rowchain_sum(I(0), I(1), I(2), CP(bc_half, 3), I(4), MP(bc_half, 5), MP(unsigned long long, 6), MP(bc_half, 7), s);
+        case BC_OP_CTX_FOLD:
+            return bc_ctx_fold(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), I(6), I(7), F(8), CP(bc_half, 9), CP(float, 10), CP(bc_half, 11),
+                               MP(bc_half, 12), MP(float, 13), MP(float, 14), MP(bc_half, 15), s);
         case BC_OP_GN_APPLY:
             return bc_gn_apply(CP(bc_half, 0), I(1), CP(bc_half, 2), I(3), I(4), I(5), CP(float, 6), I(7), MP(bc_half, 8), s);
         case BC_OP_LAYERNORM:

@@ -16,9 +16,10 @@ namespace bcplan {
 
 constexpr int kMaxStreams = 8;
 const uint32_t kMagic = 0x4E4C5042u;   // "BPLN"
-const uint32_t kVersion = 4;           // 2: BcGemm grew ln_colsum / C_t, GroupNorm statistics totals; 3: + BC_OP_ROWCHAIN_MIDX / _PACK_KV (round 4);
-                                       // 4: + BC_OP_ROWCHAIN_SUM, BC_CHAIN_OUT_FFP (round 5)
-const uint32_t kOldestReadable = 2;    // (an older file holds a subset of the current version's records)
+const uint32_t kVersion = 5;           // 2: BcGemm grew ln_colsum / C_t, GroupNorm statistics totals; 3: + BC_OP_ROWCHAIN_MIDX / _PACK_KV (round 4);
+                                       // 4: + BC_OP_ROWCHAIN_SUM, BC_CHAIN_OUT_FFP; 5: BcGemm grew w_bstride / vec_bstride / sm_group / sm_valid,
+                                       //    + BC_OP_CTX_FOLD (round 5)
+const uint32_t kOldestReadable = 5;    // (the records hold BcGemm by value: a file of another layout is refused by the size check below anyway)
 
 // argument kinds of the recordable entry points (stream argument excluded): p = device pointer, i = int, f = float, l = long long
 inline const char* op_signature(int op) {
@@ -50,6 +51,7 @@ inline const char* op_signature(int op) {
         case BC_OP_ROWCHAIN_MIDX: return "iiipppppifppf";
         case BC_OP_ROWCHAIN_PACK_KV: return "pipiiiip";
         case BC_OP_ROWCHAIN_SUM: return "iiipippp";
+        case BC_OP_CTX_FOLD: return "pipiiiiifppppppp";
         default: return nullptr;
     }
 }

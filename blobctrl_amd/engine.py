@@ -317,6 +317,12 @@ class TrunkPlan:
                 return cfg
         return 0
 
+    def ctx_fold_ok(self, Cc, T):
+        """The cross-attention of a block as two per-image projections (bc_ctx_fold): for the widths transformer_gw takes; 8 heads x 80 kept
+        keys = K of the second projection (% 320).  BC_NO_CTX_FOLD: to_q + bc_attention + to_out."""
+        return (Cc % 320 == 0 and Cc not in (320, 640) and self.heads == 8 and T <= 80 and (Cc // self.heads) % 8 == 0 and Cc // self.heads <= 160
+                and not os.environ.get("BC_NO_CTX_FOLD") and not os.environ.get("BC_NO_GW"))
+
     def transformer_gw(self, p, x: Act, r2=None):
         """One Transformer2D block of the 1280-channel levels on gemm_wreg.hip: the three LayerNorms are folded into the projections
         behind them (no LayerNorm launch, no normalised activation in HBM), q | k | V^T come out of ONE launch: 15 launches -> 11."""
@@ -356,7 +362,21 @@ class TrunkPlan:
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
                       scale, q_off=0, k_off=Cc)
         h = proj(a, bp + "attn1.to_out.0", Cc, Cc, G128, R=h, ldr=Cc, kind="attn_out")
-        if pw.has_cross:
+        folded = getattr(self, "ctx_folded", {}).get(bp) if pw.has_cross else None
+        if folded is not None and rec.lib.bc_gemm_wreg_eligible(M, 128 * self.heads, Cc, 0, G128) and rec.lib.bc_gemm_wreg_eligible(M, Cc, 80 * self.heads, 0, G128):
+            # cross-attention with the prompt folded into per-image weights, once per edit: softmax(LN2(h) QK^T) in one launch (a 64 x 128
+            # workgroup = one head's keys, padded; the scores never leave it), then the 80 kept probabilities per head x VO + bias + residual
+            wqk, cs, qb, vwo = folded
+            T = self.ctx_kv[bp][2]
+            N, Np = 128 * self.heads, 80 * self.heads
+            pr = rec.empty(M, Np)
+            rec.gemm(A=h, W=wqk, M=M, N=N, K=Cc, out=pr, ldc=Np, bias=qb, tile_cfg=G128, ln_colsum=cs, rows_per_batch=HW, w_bstride=wqk.shape[1],
+                     vec_bstride=N, sm_group=128, sm_valid=T, sm_keep=80, kind="xattn")
+            out = rec.empty(M, Cc)
+            rec.gemm(A=pr, W=vwo, M=M, N=Cc, K=Np, out=out, bias=pw.f[bp + "attn2.to_out.0.bias"], tile_cfg=G128, R=h, ldr=Cc, rows_per_batch=HW,
+                     w_bstride=vwo.shape[1], kind="xattn")
+            h = out
+        elif pw.has_cross:
             q = proj(h, bp + "attn2.to_q", Cc, Cc, G128, ln=bp + "norm2", bias=False, kind="qkv")
             ck, cvt, T, ldc_vt = self.ctx_kv[bp]
             a = rec.empty(M, Cc)
@@ -431,7 +451,7 @@ class TrunkPlan:
         """Cross-attention K / V^T of the (step-invariant) prompt embeddings, once per edit
         (attention.py:504-510; SURVEY Appendix A 'step-invariant => precompute once per edit')."""
         rec, pw, B = self.rec, self.pw, self.B
-        self.ctx_kv, self.ctx_kvs = {}, {}
+        self.ctx_kv, self.ctx_kvs, self.ctx_folded = {}, {}, {}
         Dc = ctx.shape[-1]
         ldvt = (T + 63) // 64 * 64
         for k in [k for k in pw.h if k.endswith("attn2.to_k.weight")]:
@@ -446,6 +466,11 @@ class TrunkPlan:
             # blocks the row-chain takes with 8 heads and <= 80 context tokens: K / V^T also as the fragment streams of CHAIN_MIDX
             if (Cc in (320, 640) and self.heads == 8 and T <= 80 and not os.environ.get("BC_NO_MIDX") and not os.environ.get("BC_NO_ROWCHAIN")):
                 self.ctx_kvs[bp] = rec.rowchain_kv_stream(ck, cvt, B, T, Cc, ldvt)
+            # blocks on gemm_wreg.hip (the 1280-channel levels): the prompt folded into attn2's weights (bc_ctx_fold) - to_q + attention +
+            # to_out become two projections with per-image weights
+            if self.ctx_fold_ok(Cc, T):
+                wq, bq, wo = pw.ctx_fold_weights(bp)
+                self.ctx_folded[bp] = rec.ctx_fold(ck, cvt, B, T, Cc, ldvt, self.heads, (Cc // self.heads) ** -0.5, wq, bq, wo)
 
     # ------------------------------------------------------------------------------------------- per-edit weight collapse
     def record_collapse(self, feat16: torch.Tensor):

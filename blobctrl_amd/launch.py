@@ -359,10 +359,11 @@ class Recorder:
              conv=None, bias=None, rowvec=None, ld_rowvec=0, rowvec_idx=None, rowvec_step=0, rows_per_batch=0, act=_lib.ACT_NONE, colscale=None,
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None,
-             a_affine=None, a_act=_lib.ACT_NONE, a_gn=None, ln_colsum=None, ln_eps=1e-5, C_t=None, ldc_t=0, n_t0=0):
+             a_affine=None, a_act=_lib.ACT_NONE, a_gn=None, ln_colsum=None, ln_eps=1e-5, C_t=None, ldc_t=0, n_t0=0,
+             w_bstride=0, vec_bstride=0, sm_group=0, sm_valid=0, sm_keep=0):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
-        n_out = N // 2 if act == _lib.ACT_GEGLU else N
+        n_out = N // 2 if act == _lib.ACT_GEGLU else (N // sm_group * sm_keep if sm_group else N)
         g = BcGemm()
         g.A = A.data_ptr() + a_offset * A.element_size()
         g.A2 = ptr(A2)
@@ -393,6 +394,7 @@ class Recorder:
         g.ldc = ldc if ldc is not None else (n_t0 if C_t is not None else n_out)
         g.ln_colsum, g.ln_eps = ptr(ln_colsum), ln_eps
         g.C_t, g.ldc_t, g.n_t0 = ptr(C_t), ldc_t, n_t0
+        g.w_bstride, g.vec_bstride, g.sm_group, g.sm_valid, g.sm_keep = w_bstride, vec_bstride, sm_group, sm_valid, sm_keep
         # mirror of the C-side fast-path eligibility (bc_gemm)
         fast = K % 64 == 0
         mode = "dense"
@@ -459,7 +461,8 @@ class Recorder:
             # small-M projection with the weights streamed into VGPRs (gemm_wreg.hip); W is the stream packed for this configuration
             assert not conv and a_affine is None and splitk in (None, 1) and rowvec is None
             cfg, sk, bm, bn = tile_cfg, 1, 64, 64 * _lib.GW_TILES[tile_cfg]
-            fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "") + ("_gn" if a_gn is not None else "")
+            fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "") + ("_gn" if a_gn is not None else "") + \
+                ("_softmax" if sm_group else "") + ("_wimg" if w_bstride else "")
             if a_gn is not None:          # GroupNorm(x) -> projection: finalize in the kernel's prologue from the statistics totals of x
                 t1, _ = self.gn_sources(a_gn["x1"], a_gn["C1"], None, 0, a_gn["B"], a_gn["HW"])
                 g.a_tot1 = ptr(t1)
@@ -502,7 +505,7 @@ class Recorder:
         if cfg in (_lib.TILE_HALO, _lib.TILE_WREG):
             rp = ("conv_wreg_kernel" if cfg == _lib.TILE_WREG else "conv_halo_kernel") + f"<{2 if g.a_tot1 else 1 if g.a_affine else 0}>"
         elif cfg in _lib.GW_TILES:
-            rp = f"gemm_wreg_kernel<{_lib.GW_TILES[cfg]}, {10 if _lib.GW_TILES[cfg] == 5 else 20}>"
+            rp = f"gemm_wreg_kernel<{_lib.GW_TILES[cfg]}, {10 if _lib.GW_TILES[cfg] == 5 else 20}, {'true' if sm_group else 'false'}>"
         elif fast:
             ups_ = bool(conv) and (conv.get("Hv", conv["Hin"]), conv.get("Wv", conv["Win"])) != (conv["Hin"], conv["Win"])
             rp = f"gemm_fast_kernel<{FAST[cfg]}, {'true' if conv else 'false'}, {'true' if ups_ else 'false'}>"
@@ -643,6 +646,22 @@ class Recorder:
         self._op("bc_rowchain_pack_kv", (ck, Cc, cvt, ldvt, B, T, Cc, out), "pack_kv", variant="rowchain_pack_kv_kernel",
                  shape=("pack_kv", B, T, Cc), bytes_=2 * (2 * B * T * Cc) + out.numel() * 2, rocprof=f"rowchain_pack_kv_kernel<{Cc}>")
         return out
+
+    def ctx_fold(self, ck, cvt, B, T, Cc, ldvt, heads, scale, wq, bq, wo):
+        """The prompt of an edit folded into the cross-attention weights of one block (bc_ctx_fold, include/blobctrl_hip.h): returns
+        (wqk [B][stream], qk_colsum [B][128 heads], qk_bias [B][128 heads], vwo [B][stream]); recorded where the context is projected."""
+        N = 128 * heads
+        s_qk, s_vo = self.lib.bc_gemm_wreg_stream_elems(N, Cc), self.lib.bc_gemm_wreg_stream_elems(Cc, 80 * heads)
+        wqk, vwo = self.zeros(B, s_qk), self.zeros(B, s_vo)               # (zeros: the tail the register ring reads past the end)
+        cs, qb = self.zeros(B, N, dtype=torch.float32), self.zeros(B, N, dtype=torch.float32)
+        refs = (ck, cvt, wq, bq, wo, wqk, cs, qb, vwo)
+        self.keep.append(refs)
+        for t in refs:
+            self.register(t)
+        self._op("bc_ctx_fold", (ck, Cc, cvt, ldvt, B, T, Cc, heads, scale, wq, bq, wo, wqk, cs, qb, vwo), "ctx_fold", variant="ctx_fold_kernel",
+                 flops=2 * 2 * B * 80 * heads * Cc * (Cc // heads), shape=("ctx_fold", B, T, Cc), bytes_=2 * (2 * Cc * Cc + B * (N + 80 * heads) * Cc),
+                 rocprof="ctx_fold_qk_kernel")
+        return wqk, cs, qb, vwo
 
     def rowchain_midx(self, Cc, M, rows_per_batch, x, wstream, vec, kvstream, n_ctx, heads, scale, out0, out1, res, ln_eps=1e-5):
         """CHAIN_MID with the block's cross-attention inside (include/blobctrl_hip.h: bc_rowchain_midx): out0 = h1, out1 = attn2's

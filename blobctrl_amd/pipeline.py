@@ -156,6 +156,7 @@ class BlobCtrlEngine:
             # (the K / V^T fragment streams of CHAIN_MIDX are laid out per image too: without the slice both halves fell back to the
             #  unfused MID + attention launches)
             hp.ctx_kvs = {bp: kvs.view(2 * B, -1)[b0:b0 + B].reshape(-1) for bp, kvs in getattr(unet_a, "ctx_kvs", {}).items()}
+            hp.ctx_folded = {bp: tuple(t[b0:b0 + B] for t in f) for bp, f in getattr(unet_a, "ctx_folded", {}).items()}
             hp.tproj, hp.tproj_table = half_time.tproj, half_time.tproj_table
             return hp
 
@@ -211,7 +212,7 @@ class BlobCtrlEngine:
         # ---- step I: UNet only (cond_scale == 0: BlobNet output is multiplied by 0, bn:936-938)
         P.step_inactive = rec.begin("step_inactive")
         unet_i = TrunkPlan(rec, self.unet_w, self.unet_cfg, 2 * B, H, W)
-        unet_i.ctx_kv, unet_i.ctx_kvs = unet_a.ctx_kv, getattr(unet_a, "ctx_kvs", {})
+        unet_i.ctx_kv, unet_i.ctx_kvs, unet_i.ctx_folded = unet_a.ctx_kv, getattr(unet_a, "ctx_kvs", {}), getattr(unet_a, "ctx_folded", {})
         if not temb_per_step:
             unet_i.tproj, unet_i.tproj_table = unet_a.tproj, unet_a.tproj_table
         record_unet(unet_i, None)

@@ -114,6 +114,23 @@ def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.T
     return w2, cs.contiguous(), b2.contiguous()
 
 
+def fold_cross_attention(k: torch.Tensor, vt: torch.Tensor, T: int, heads: int, scale: float, wq: torch.Tensor, bq: torch.Tensor, wo: torch.Tensor):
+    """Host statement of bc_ctx_fold (csrc/gemm_wreg.hip): k [B][T][C] projected context rows, vt [B][C][>= T] its V^T, (wq, bq, wo) =
+    PackedTrunk.ctx_fold_weights.  Returns (QK [B][128 heads][C] fp16 - row 128 h + j = key j of head h, zero from j = T on -, colsum of the
+    rounded rows fp32, bias fp32 [B][128 heads], VO [B][C][80 heads] fp16) as plain matrices - pack_gemm_wreg(QK[b], 2) /
+    pack_gemm_wreg(VO[b], 2) are the streams the kernel writes."""
+    B, _, C = k.shape
+    D = C // heads
+    kh = torch.zeros(B, heads, 128, D, dtype=torch.float32, device=k.device)
+    kh[:, :, :T] = k[:, :T].float().reshape(B, T, heads, D).permute(0, 2, 1, 3)
+    qk = (torch.einsum("bhjd,hdc->bhjc", kh, wq.float().reshape(heads, D, C)) * scale).half().reshape(B, heads * 128, C)
+    qb = (torch.einsum("bhjd,hd->bhj", kh, bq.float().reshape(heads, D)) * scale).reshape(B, heads * 128)
+    vh = torch.zeros(B, heads, D, 80, dtype=torch.float32, device=k.device)
+    vh[..., :T] = vt[:, :, :T].float().reshape(B, heads, D, T)
+    vo = torch.einsum("nhd,bhdj->bnhj", wo.float().reshape(C, heads, D), vh).half().reshape(B, C, heads * 80)
+    return qk, qk.float().sum(-1), qb, vo
+
+
 # BC_ALIAS_WEIGHTS=1 (diagnostics, WRONG results): every weight matrix of a shape shares the first one's storage, so that the step's
 # 3.4 GB of weights shrink to what the Infinity Cache holds - the upper bound of what ANY weight prefetch could buy (tools / DESIGN 9).
 import os as _os
@@ -156,6 +173,16 @@ class PackedTrunk:
             self.h[k + ".weight"] = torch.cat([P @ F2, P], 1).half().contiguous()
             self.f[k + ".bias"] = (P @ self.f[bp + "ff.net.2.bias"].float() + self.f[p + "proj_out.bias"].float()).contiguous()
         return k
+
+    def ctx_fold_weights(self, bp: str):
+        """What bc_ctx_fold multiplies the projected prompt with (block prefix `bp` = "...transformer_blocks.0."): (wq = fp16 of
+        attn2.to_q.weight diag(gamma of norm2) [C][C], bq = to_q.weight . beta of norm2 fp32 [C], wo = attn2.to_out.0.weight [C][C] as stored) -
+        the LayerNorm in front of to_q folded as for BcGemm.ln_colsum (fold_layernorm)."""
+        cache = self.__dict__.setdefault("_ctx_fold", {})
+        if bp not in cache:
+            wq, _, bq = fold_layernorm(self.h[bp + "attn2.to_q.weight"], None, self.f[bp + "norm2.weight"], self.f[bp + "norm2.bias"])
+            cache[bp] = (wq.contiguous(), bq)
+        return cache[bp] + (self.h[bp + "attn2.to_out.0.weight"],)
 
     def wreg(self, key: str) -> str:
         """Key of the BC_TILE_WREG fragment stream of the packed 3x3 weight `key` (made on first use, kept beside the matrix)."""
@@ -297,7 +324,7 @@ class PackedTrunk:
         copies of matrices the arenas also hold in row-major form for the kernels that take that form - other batch sizes, canvases
         the halo kernels do not cover, the diagnostic switches).  Not broadcast: every rank derives its own."""
         n = sum(t.numel() * t.element_size() for k, t in self.h.items() if k.endswith("_wreg"))
-        for cache in (self.__dict__.get("_gw", {}), self.__dict__.get("_rowchain", {})):
+        for cache in (self.__dict__.get("_gw", {}), self.__dict__.get("_rowchain", {}), self.__dict__.get("_ctx_fold", {})):
             for v in cache.values():
                 n += sum(t.numel() * t.element_size() for t in v if torch.is_tensor(t))
         return n

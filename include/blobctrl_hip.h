@@ -119,6 +119,15 @@ typedef struct BcGemm {
     /* ---- BC_TILE_GW* only: a second, TRANSPOSED output for the column tiles n >= n_t0 (q | k row-major into C, V^T for the attention
      *      kernel in the same launch): C_t[(b * (N - n_t0) + n - n_t0) * ldc_t + (m % rows_per_batch)].  NULL = none. ---- */
     void* C_t; int ldc_t, n_t0;
+    /* ---- BC_TILE_GW* only: PER-IMAGE weights (round 5: the cross-attention of the 1280-channel blocks folded over the prompt, see
+     *      bc_ctx_fold): the rows of image b = m / rows_per_batch multiply the stream W + b * w_bstride (bc_half elements; 0 = one
+     *      stream for every row); with vec_bstride != 0 `bias` and `ln_colsum` are per image too ([B][vec_bstride] floats). ---- */
+    long long w_bstride; int vec_bstride;
+    /* ---- BC_TILE_GW64x128 only: row SOFTMAX over each workgroup's 128 columns (sm_group = 128: a head's keys, padded) of which the
+     *      first `sm_valid` are keys; the first `sm_keep` columns (% 8 == 0, >= sm_valid; columns >= sm_valid come out as 0) of every
+     *      group are written as fp16 probabilities, compacted: C[m][(n / 128) * sm_keep + n % 128].  The scores never exist in HBM (fp32
+     *      inside the launch).  0 = none. ---- */
+    int sm_group, sm_valid, sm_keep;
 } BcGemm;
 
 int bc_gemm(const BcGemm* p, bc_stream stream);
@@ -333,6 +342,24 @@ int bc_rowchain_sum(int channels, int M, int rows_per_batch, const bc_half* part
  * and wave, channels / 80 waves).  `wstream` / `vec` are BC_CHAIN_MID's. */
 long long bc_rowchain_kv_frags(int channels);
 int bc_rowchain_pack_kv(const bc_half* k, int ldk, const bc_half* vt, int ldvt, int B, int T, int channels, bc_half* out, bc_stream stream);
+
+/* Cross-attention with the prompt folded into the weights, once per edit (round 5; attention.py:504-510 attn2 of a BasicTransformerBlock,
+ * attention_processor.py:2191-2224): K_h = (ctx W_k)_h and V_h = (ctx W_v)_h of an image are fixed over the edit, so
+ *     softmax(scale LN(x) W_q,h^T K_h^T) V_h W_o,h^T  =  softmax(LN(x) QK_h^T) VO_h^T,   QK_h = scale K_h W_q,h  [T][C],   VO_h = W_o,h V_h^T  [C][T]:
+ * `attn2.to_q` + the 77-key attention + `attn2.to_out` (3 launches, 4 C^2 + 4 T C flops per row) become two projections with per-image
+ * weights (2 launches) - bc_gemm on BC_TILE_GW64x128 with sm_group = 128 / sm_valid = T / sm_keep = 80 and w_bstride / vec_bstride (one
+ * 64 x 128 workgroup per head: 128 QK rows of which the first T are keys, the rest zero), then bc_gemm on BC_TILE_GW64x128 with w_bstride
+ * over the 80 kept probabilities per head (column (h, j) = 80 h + j).
+ *   k   [B][T][ldk] projected context rows, vt [B][C][ldvt] its V^T (what the attention launch read), D = C / heads (% 8 == 0), T <= 80;
+ *   wq  [C][C] = attn2.to_q.weight * diag(gamma of norm2) (fp16), bq [C] = to_q.weight . beta (fp32), wo [C][C] = attn2.to_out.0.weight;
+ *   wqk [B][bc_gemm_wreg_stream_elems(128 heads, C)]: the GW64x128 stream of QK, row (h, j) = 128 h + j (rows of j >= T zero: the
+ *       rows j >= 80 are never written - the caller provides them zeroed);
+ *   qk_colsum / qk_bias [B][128 heads] fp32: sum_c of the fp16-ROUNDED QK row (BcGemm.ln_colsum) / scale K_h . bq_h (BcGemm.bias);
+ *   vwo [B][bc_gemm_wreg_stream_elems(C, 80 heads)]: the GW64x128 stream of VO (columns of keys >= T zero).
+ * fp32 accumulation in a fixed order: the same bytes for the same inputs on every call. */
+int bc_ctx_fold(const bc_half* k, int ldk, const bc_half* vt, int ldvt, int B, int T, int channels, int heads, float scale,
+                const bc_half* wq, const float* bq, const bc_half* wo, bc_half* wqk, float* qk_colsum, float* qk_bias, bc_half* vwo,
+                bc_stream stream);
 int bc_rowchain_midx(int channels, int M, int rows_per_batch, const bc_half* x, const bc_half* res, const bc_half* wstream, const float* vec,
                      const bc_half* kvstream, int n_ctx, float attn_scale, bc_half* out0, bc_half* out1, float ln_eps, bc_stream stream);
 
@@ -386,7 +413,7 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
        BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
-       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_ROWCHAIN_SUM = 27, BC_OP_COUNT = 28 };
+       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_ROWCHAIN_SUM = 27, BC_OP_CTX_FOLD = 28, BC_OP_COUNT = 29 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

@@ -103,12 +103,19 @@ def test_transformer_block(z, name, fused, monkeypatch):
 @pytest.mark.parametrize("name,mode", [("tfm_640_cross", "rowchain"), ("tfm_640_cross", "rowchain_tail"), ("tfm_640_cross", "rowchain_nsplit1"),
                                        ("tfm_640_cross", "unfused"),
                                        ("tfm_640_self_only", "rowchain"), ("tfm_640_self_only", "unfused"),
-                                       ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "unfused"), ("tfm_1280_self_only", "gw")])
+                                       ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "gw_attn"), ("tfm_1280_cross", "unfused"), ("tfm_1280_self_only", "gw")])
 def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     """The block sizes rounds 3 / 4 built kernels for, against the reference's Transformer2DModel: 640 channels
     on a 32 x 64 map at B = 2 (64 row blocks: the row-chain with the block end as OUT_FFP + sum over four workgroups per row block
     (round 5), as OUT_FF + OUT_TAIL over two (round 3), its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
-    in one launch; and the unfused list)."""
+    in one launch, the cross-attention as two projections with the prompt folded into their weights (round 5: bc_ctx_fold; "gw_attn" = to_q +
+    bc_attention + to_out instead); and the unfused list)."""
+    if mode == "gw_attn":
+        monkeypatch.setenv("BC_NO_CTX_FOLD", "1")
+        mode = "gw"
+        folded = False
+    else:
+        folded = mode == "gw" and name == "tfm_1280_cross"
     if mode == "unfused":
         monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
         monkeypatch.setenv("BC_NO_GW", "1")
@@ -136,8 +143,11 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
         assert any(m["kind"] == "ff" and m["shape"][3] == 5 * p["C"] for m in rec.seg.meta), [m["shape"] for m in rec.seg.meta if m["kind"] == "ff"]
         assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
         assert not any(k.startswith("groupnorm") for k in kinds) and sum("_gn" in v for v in variants) == 1, (kinds, variants)
+        # cross-attention: ctx_fold (per edit) + softmax projection + output projection, and only the self-attention left as bc_attention
+        assert (kinds.get("xattn", 0) == 2 and kinds.get("ctx_fold", 0) == 1 and kinds.get("attention", 0) == 1) == folded, kinds
+        assert any("_softmax_wimg" in v for v in variants) == folded, variants
     _run(seg)
-    _check(f"{name} ({mode})", _nchw(out, p["B"]), z[name], p["sub"])
+    _check(f"{name} ({mode}{', prompt folded' if folded else ''})", _nchw(out, p["B"]), z[name], p["sub"])
 
 
 @pytest.mark.parametrize("name", ["up_scale2", "up_explicit_size", "down"])

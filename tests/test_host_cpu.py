@@ -251,7 +251,7 @@ def test_plan_compiles_and_saves_without_a_gpu(tmp_path):
     assert seq == ["step_active"] * 4 + ["step_inactive"] * 2
     raw = open(path, "rb").read()
     magic, version, gsz, nbuf = struct.unpack("<IIII", raw[:16])
-    assert magic == 0x4E4C5042 and version == 4 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
+    assert magic == 0x4E4C5042 and version == 5 and gsz == C.sizeof(_lib.BcGemm) and nbuf > 50
     for name in (b"latents", b"ctx", b"fg_lat", b"bg_lat", b"fg_score", b"bg_score", b"feat16", b"step_idx", b"coef", b"hist"):
         assert name in raw
     P = eng.plan_for(1, 8, 8, 7, TINY["ctx"], 6)
@@ -463,3 +463,38 @@ def test_rowchain_kv_stream_layout_holds_every_context_value_once(C, T):
             ch = slice(80 * w + D * hh, 80 * w + D * (hh + 1))
             assert int((kpart[:, w] != 0).sum()) == B * T * D and float(kpart[:, w].double().sum()) == float(k[:, :, ch].double().sum())
             assert int((vpart[:, w] != 0).sum()) == B * T * D and float(vpart[:, w].double().sum()) == float(vt[:, ch, :T].double().sum())
+
+
+def test_prompt_folded_into_the_cross_attention_weights_is_the_same_attention():
+    """weights.fold_cross_attention (the host statement of bc_ctx_fold): softmax(LN(x) QK^T + bias) VO^T over the padded keys of each head
+    IS to_out(attention(to_q(LN(x)), K, V)) (attention.py:491-510, attention_processor.py:2191-2224) - up to the fp16 rounding of QK / VO -
+    and padded keys hold zeros, so masking them in the softmax is the whole of the padding's effect."""
+    from blobctrl_amd.weights import fold_cross_attention, fold_layernorm
+    torch.manual_seed(3)
+    B, T, C, heads, rows = 2, 13, 64, 4, 9
+    D = C // heads
+    x = torch.randn(B, rows, C) * 1.5 + 0.2
+    k, v = torch.randn(B, T, C), torch.randn(B, T, C)
+    Wq, Wo = torch.randn(C, C) / C ** 0.5, torch.randn(C, C) / C ** 0.5
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    scale = D ** -0.5
+    wq, _, bq = fold_layernorm(Wq, None, gamma, beta)
+    vt = torch.zeros(B, C, 16)
+    vt[:, :, :T] = v.transpose(1, 2)
+    qk, cs, qb, vo = fold_cross_attention(k, vt, T, heads, scale, wq, bq, Wo)
+    assert qk.shape == (B, heads * 128, C) and vo.shape == (B, C, heads * 80) and cs.shape == qb.shape == (B, heads * 128)
+    assert float(qk.view(B, heads, 128, C)[:, :, T:].abs().max()) == 0.0 and float(vo.view(B, C, heads, 80)[..., T:].abs().max()) == 0.0
+    # the folded form, as the two launches compute it
+    mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    s = rstd * (x @ qk.float().transpose(1, 2) - mean * cs[:, None, :]) + qb[:, None, :]
+    s = s.view(B, rows, heads, 128)
+    s[..., T:] = float("-inf")
+    p = torch.softmax(s, -1)[..., :80].reshape(B, rows, heads * 80)        # (the launch writes the first 80 probabilities of a head)
+    got = p @ vo.float().transpose(1, 2)
+    # the reference form
+    q = (torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) @ Wq.t()).view(B, rows, heads, D).permute(0, 2, 1, 3)
+    kh, vh = (t.view(B, T, heads, D).permute(0, 2, 1, 3) for t in (k, v))
+    a = (torch.softmax(q @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, rows, C)
+    ref = a @ Wo.t()
+    assert float((got - ref).abs().max()) < 1e-2 * float(ref.abs().max())

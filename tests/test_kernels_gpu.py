@@ -842,3 +842,92 @@ def test_gemm_wreg_pack_matches_host_packing(rec):
     assert lib.bc_gemm_wreg_eligible(1000, 1280, 1280, 0, _lib.TILE_GW64x128) == 0      # M % 64
     assert lib.bc_gemm_wreg_eligible(1024, 1280, 1024, 0, _lib.TILE_GW64x128) == 0      # K % 320
     assert lib.bc_gemm_wreg_eligible(1024, 1280, 2560, 1280, _lib.TILE_GW64x320) == 1
+
+
+def _ctx_fold_case(B=2, T=77, Cc=1280, heads=8):
+    """Seeded stand-ins for a block's projected prompt and its attn2 weights (SD-1.5's 1280-channel block: 8 heads of 160)."""
+    k, v = g(31, B, T, Cc) * 1.2, g(32, B, T, Cc)
+    ldvt = 128
+    vt = torch.zeros(B, Cc, ldvt)
+    vt[:, :, :T] = v.permute(0, 2, 1)
+    Wq, Wo = g(33, Cc, Cc) / math.sqrt(Cc), g(34, Cc, Cc) / math.sqrt(Cc)
+    gamma, beta = 1 + 0.2 * g(35, Cc), 0.1 * g(36, Cc)
+    return k, vt, ldvt, Wq, Wo, gamma, beta
+
+
+def test_ctx_fold_matches_its_host_statement(rec):
+    """bc_ctx_fold (the prompt folded into attn2's weights, once per edit) against weights.fold_cross_attention: the two fragment streams
+    within one fp16 ulp of the host's fp32 products (the kernel sums the head width in index order), the column sums exactly those of the
+    ROUNDED rows the kernel wrote, keys >= T zero."""
+    from blobctrl_amd.weights import fold_cross_attention, fold_layernorm, pack_gemm_wreg
+    B, T, Cc, heads = 2, 77, 1280, 8
+    k, vt, ldvt, Wq, Wo, gamma, beta = _ctx_fold_case(B, T, Cc, heads)
+    wq, _, bq = fold_layernorm(Wq.half(), None, gamma, beta)
+    scale = (Cc // heads) ** -0.5
+    got = None
+
+    def go():
+        nonlocal got
+        got = rec.ctx_fold(h(k.reshape(B * T, Cc)), h(vt), B, T, Cc, ldvt, heads, scale, wq.cuda(), bq.cuda(), h(Wo))
+    run(rec, go)
+    wqk, cs, qb, vwo = got
+    qk, cs_ref, qb_ref, vo = fold_cross_attention(k.half(), vt.half(), T, heads, scale, wq, bq, Wo.half())
+    for b in range(B):
+        want_qk, want_vo = pack_gemm_wreg(qk[b], 2).float(), pack_gemm_wreg(vo[b], 2).float()
+        have_qk, have_vo = wqk[b].float().cpu(), vwo[b].float().cpu()
+        assert have_qk.shape == want_qk.shape and have_vo.shape == want_vo.shape
+        # one fp16 ulp of the entry (2^-10 relative) + the fp32 summation-order noise of near-cancelling entries
+        assert float(((have_qk - want_qk).abs() - 1e-3 * want_qk.abs()).max()) < 2e-5, "QK stream"
+        assert float(((have_vo - want_vo).abs() - 1e-3 * want_vo.abs()).max()) < 2e-4, "VO stream"
+    close(qb, qb_ref, rtol=1e-4, atol=1e-5, what="bias row scale K . (Wq beta)")
+    # column sums: of the rows the KERNEL rounded (its own bytes), in fp32
+    rows_qk = torch.zeros(B, heads * 128, Cc)
+    for b in range(B):
+        v2 = wqk[b].float().cpu()[: heads * 128 * Cc].view(heads, 4, Cc // 32, 2, 4, 16, 8)     # [j, wave, s, t, q, r, e]
+        rows_qk[b] = v2.permute(0, 1, 3, 5, 2, 4, 6).reshape(heads * 128, Cc)
+    close(cs, rows_qk.sum(-1), rtol=1e-4, atol=1e-4, what="column sums of the rounded QK rows")
+    pad = rows_qk.view(B, heads, 128, Cc)[:, :, T:]
+    assert float(pad.abs().max()) == 0.0 and float(cs.view(B, heads, 128)[:, :, T:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows", [128, 512])
+def test_cross_attention_as_two_folded_projections(rec, rows):
+    """to_q + 77-key attention + to_out of a 1280-channel block as bc_ctx_fold (per edit) + two bc_gemm launches with per-image weights
+    (softmax over the 128 padded keys of a head in the first one's epilogue, 80 probabilities per head kept) against fp32 torch: LayerNorm -> to_q -> per-head
+    softmax(q k^T / sqrt(d)) v -> to_out + bias + residual (attention.py:491-510, attention_processor.py:2191-2224)."""
+    from blobctrl_amd import _lib
+    from blobctrl_amd.weights import fold_layernorm
+    B, T, Cc, heads = 2, 77, 1280, 8
+    D = Cc // heads
+    M = B * rows
+    k, vt, ldvt, Wq, Wo, gamma, beta = _ctx_fold_case(B, T, Cc, heads)
+    x = g(41, M, Cc) * 1.5 + 0.3
+    bo = g(42, Cc) * 0.2
+    wq, _, bq = fold_layernorm(Wq.half(), None, gamma, beta)
+    scale = D ** -0.5
+    out = None
+
+    def go():
+        nonlocal out
+        wqk, cs, qb, vwo = rec.ctx_fold(h(k.reshape(B * T, Cc)), h(vt), B, T, Cc, ldvt, heads, scale, wq.cuda(), bq.cuda(), h(Wo))
+        N, Np = 128 * heads, 80 * heads
+        xd = h(x)
+        pr = rec.empty(M, Np)
+        rec.gemm(A=xd, W=wqk, M=M, N=N, K=Cc, out=pr, ldc=Np, bias=qb, tile_cfg=_lib.TILE_GW64x128, ln_colsum=cs, rows_per_batch=rows,
+                 w_bstride=wqk.shape[1], vec_bstride=N, sm_group=128, sm_valid=T, sm_keep=80)
+        out = rec.empty(M, Cc)
+        rec.gemm(A=pr, W=vwo, M=M, N=Cc, K=Np, out=out, bias=bo.cuda(), tile_cfg=_lib.TILE_GW64x128, R=xd, ldr=Cc, rows_per_batch=rows,
+                 w_bstride=vwo.shape[1])
+        go.pr = pr
+    run(rec, go)
+    xf = x.half().float()
+    q = (F.layer_norm(xf, (Cc,), gamma, beta, 1e-5) @ Wq.half().float().t()).view(B, rows, heads, D).permute(0, 2, 1, 3)
+    kh = k.half().float().view(B, T, heads, D).permute(0, 2, 1, 3)
+    vh = vt.half().float()[:, :, :T].reshape(B, heads, D, T).permute(0, 1, 3, 2)
+    p = torch.softmax(q @ kh.transpose(-1, -2) * scale, -1)
+    a = (p @ vh).permute(0, 2, 1, 3).reshape(M, Cc)
+    ref = a @ Wo.half().float().t() + bo + xf
+    pr = go.pr.float().cpu().view(B, rows, heads, 80)
+    assert float(pr[..., T:].abs().max()) == 0.0                       # padded keys carry no probability
+    close(pr[..., :T].permute(0, 2, 1, 3), p, rtol=2e-2, atol=2e-3, what="probabilities")
+    close(out, ref, what=f"folded cross-attention, {rows} rows per image")
