@@ -319,8 +319,11 @@ class TrunkPlan:
 
     def ctx_fold_ok(self, Cc, T):
         """The cross-attention of a block as two per-image projections (bc_ctx_fold): for the widths transformer_gw takes; 8 heads x 80 kept
-        keys = K of the second projection (% 320).  BC_NO_CTX_FOLD: to_q + bc_attention + to_out."""
-        return (Cc % 320 == 0 and Cc not in (320, 640) and self.heads == 8 and T <= 80 and (Cc // self.heads) % 8 == 0 and Cc // self.heads <= 160
+        keys = K of the second projection (% 320).  BC_NO_CTX_FOLD: to_q + bc_attention + to_out.
+        Only for the single edit (UNet batch 2 = the CFG pair): every image brings its own 5.9 MB of folded weights per block, and from four
+        images on the shared to_q / to_out weights win (same box, interleaved, ms per step, unfolded vs folded: one edit 9.155 / 9.098 vs 9.097 /
+        9.076; two 15.715 / 15.583 vs 15.755 / 15.750; eight 52.75 / 52.58 vs 52.80 / 52.79; 768^2 x 4 79.85 / 79.61 vs 80.21 / 79.90)."""
+        return (self.B <= int(os.environ.get("BC_CTX_FOLD_MAXB", "2")) and Cc % 320 == 0 and Cc not in (320, 640) and self.heads == 8 and T <= 80 and (Cc // self.heads) % 8 == 0 and Cc // self.heads <= 160
                 and not os.environ.get("BC_NO_CTX_FOLD") and not os.environ.get("BC_NO_GW"))
 
     def transformer_gw(self, p, x: Act, r2=None):

@@ -1,4 +1,5 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-bash tools/gemm256_probe.sh
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
