@@ -1,5 +1,6 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 900 python tools/soak.py 2>&1 | tail -4
+bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
+tail -5 gpurun_out/profile_round.log
