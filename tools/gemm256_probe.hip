@@ -418,7 +418,7 @@ static double run(int M, int N, int K, int reps) {
 }
 
 int main() {
-    const int shapes[][3] = {{512, 512, 512}, {4096, 4096, 4096}, {8192, 8192, 8192}, {16384, 2560, 320}, {16384, 5120, 640}, {4096, 5120, 640}, {32768, 2560, 320}};
+    const int shapes[][3] = {{512, 512, 512}, {4096, 4096, 4096}, {4096, 4096, 4160}, {8192, 8192, 8192}, {8192, 8192, 8256}, {16384, 2560, 320}, {16384, 5120, 640}, {4096, 5120, 640}, {32768, 2560, 320}};
     for (auto& sh : shapes) {
         run<1>(sh[0], sh[1], sh[2], 20);
         run<6>(sh[0], sh[1], sh[2], 20);

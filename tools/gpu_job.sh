@@ -1,5 +1,6 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -c 600 gpurun_out/bench_final.json
+python tools/critical_path.py > gpurun_out/critical_path.txt 2>&1
+python tools/concurrent_timeline.py > gpurun_out/concurrent_timeline.txt 2>&1
+tail -3 gpurun_out/concurrent_timeline.txt
