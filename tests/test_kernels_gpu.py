@@ -586,6 +586,20 @@ def test_bad_arguments_fail_loudly(rec):
     with pytest.raises(_lib.BlobCtrlHipError):
         run(rec, lambda: rec.attention(h(g(1, 1, 8, 24)), h(g(2, 1, 8, 24)), h(g(3, 1, 24, 64)), rec.empty(1, 8, 24), 1, 2, 12,
                                        8, 8, 24, 24, 64, 24, 192, 192, 24 * 64, 192, 1.0))                       # d = 12
+    # per-image weights / the softmax epilogue exist on the BC_TILE_GW* kernels only, and a softmax group is one 64 x 128 workgroup
+    A, W = h(g(1, 128, 640)), h(g(2, 256, 640))
+    with pytest.raises(_lib.BlobCtrlHipError):
+        run(rec, lambda: rec.gemm(A=A, W=W, M=128, N=256, K=640, out=rec.empty(128, 256), w_bstride=256 * 640, rows_per_batch=64))
+    with pytest.raises(_lib.BlobCtrlHipError):
+        run(rec, lambda: rec.gemm(A=A, W=W, M=128, N=256, K=640, out=rec.empty(128, 160), ldc=160, tile_cfg=_lib.TILE_GW64x256, sm_group=128,
+                                  sm_valid=77, sm_keep=80))
+    with pytest.raises(_lib.BlobCtrlHipError):       # T > kept columns
+        run(rec, lambda: rec.gemm(A=A, W=W, M=128, N=256, K=640, out=rec.empty(128, 160), ldc=160, tile_cfg=_lib.TILE_GW64x128, sm_group=128,
+                                  sm_valid=90, sm_keep=80))
+    lib = _lib.load()
+    z = torch.zeros(16, dtype=torch.float16, device="cuda:0")
+    assert lib.bc_ctx_fold(z.data_ptr(), 1280, z.data_ptr(), 128, 1, 81, 1280, 8, 1.0, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                           z.data_ptr(), z.data_ptr(), z.data_ptr(), None) != 0 and b"T <= 80" in lib.bc_last_error()
 
 
 @pytest.mark.parametrize("kind", ["linear", "conv3x3"])
