@@ -417,7 +417,14 @@ static double run(int M, int N, int K, int reps) {
     return tf;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'p') {           // PMC mode: the pipelined kernel and its ablations at one size (tools/gemm256_pmc.sh)
+        run<6>(8192, 8192, 8192, 5);
+        run<7>(8192, 8192, 8192, 5);
+        run<9>(8192, 8192, 8192, 5);
+        run<10>(8192, 8192, 8192, 5);
+        return 0;
+    }
     const int shapes[][3] = {{512, 512, 512}, {4096, 4096, 4096}, {4096, 4096, 4160}, {8192, 8192, 8192}, {8192, 8192, 8256}, {16384, 2560, 320}, {16384, 5120, 640}, {4096, 5120, 640}, {32768, 2560, 320}};
     for (auto& sh : shapes) {
         run<1>(sh[0], sh[1], sh[2], 20);

@@ -1,4 +1,4 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "bad_arguments" 2>&1 | tail -8
+bash tools/gemm256_pmc.sh 2>&1 | tail -70
