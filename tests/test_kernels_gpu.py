@@ -869,12 +869,13 @@ def _ctx_fold_case(B=2, T=77, Cc=1280, heads=8):
     return k, vt, ldvt, Wq, Wo, gamma, beta
 
 
-def test_ctx_fold_matches_its_host_statement(rec):
+@pytest.mark.parametrize("B,T,Cc", [(2, 77, 1280), (1, 17, 640), (3, 80, 1280)])
+def test_ctx_fold_matches_its_host_statement(rec, B, T, Cc):
     """bc_ctx_fold (the prompt folded into attn2's weights, once per edit) against weights.fold_cross_attention: the two fragment streams
     within one fp16 ulp of the host's fp32 products (the kernel sums the head width in index order), the column sums exactly those of the
     ROUNDED rows the kernel wrote, keys >= T zero."""
     from blobctrl_amd.weights import fold_cross_attention, fold_layernorm, pack_gemm_wreg
-    B, T, Cc, heads = 2, 77, 1280, 8
+    heads = 8
     k, vt, ldvt, Wq, Wo, gamma, beta = _ctx_fold_case(B, T, Cc, heads)
     wq, _, bq = fold_layernorm(Wq.half(), None, gamma, beta)
     scale = (Cc // heads) ** -0.5
@@ -904,14 +905,14 @@ def test_ctx_fold_matches_its_host_statement(rec):
     assert float(pad.abs().max()) == 0.0 and float(cs.view(B, heads, 128)[:, :, T:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("rows", [128, 512])
-def test_cross_attention_as_two_folded_projections(rec, rows):
+@pytest.mark.parametrize("rows,T,Cc", [(128, 77, 1280), (512, 77, 1280), (64, 33, 640)])
+def test_cross_attention_as_two_folded_projections(rec, rows, T, Cc):
     """to_q + 77-key attention + to_out of a 1280-channel block as bc_ctx_fold (per edit) + two bc_gemm launches with per-image weights
     (softmax over the 128 padded keys of a head in the first one's epilogue, 80 probabilities per head kept) against fp32 torch: LayerNorm -> to_q -> per-head
     softmax(q k^T / sqrt(d)) v -> to_out + bias + residual (attention.py:491-510, attention_processor.py:2191-2224)."""
     from blobctrl_amd import _lib
     from blobctrl_amd.weights import fold_layernorm
-    B, T, Cc, heads = 2, 77, 1280, 8
+    B, heads = 2, 8
     D = Cc // heads
     M = B * rows
     k, vt, ldvt, Wq, Wo, gamma, beta = _ctx_fold_case(B, T, Cc, heads)
