@@ -1,4 +1,5 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "ctx_fold or folded" 2>&1 | tail -8
+BC_RC_PAIR=7 timeout 900 python -m pytest tests/test_rowchain_gpu.py tests/test_blocks_gpu.py -x -q 2>&1 | tail -5
+bash tools/ab_bench.sh gpurun_out/ab22 "BC_X=0" "BC_RC_PAIR=2" "BC_RC_PAIR=3"
