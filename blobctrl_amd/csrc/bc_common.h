@@ -65,6 +65,31 @@ __device__ __forceinline__ float bc_gelu_f(float x) {
 }
 #endif
 
+// Two GELUs per instruction stream (round 5): the same operations in the same order as bc_gelu_f - bit-identical results - on
+// v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per VALU issue on gfx90a+); the two transcendentals per element stay scalar.  The GEGLU
+// epilogues are VALU-bound (row-chain feed-forward, 320 channels: 26k of a workgroup's 143k cycles before this).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef BC_GELU_LIBM
+__device__ __forceinline__ f32x2 bc_gelu_f2(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 d = __builtin_elementwise_fma((f32x2)(0.3275911f), z, (f32x2)(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 p = __builtin_elementwise_fma(t, (f32x2)(1.061405429f), (f32x2)(-1.453152027f));
+    p = __builtin_elementwise_fma(t, p, (f32x2)(1.421413741f));
+    p = __builtin_elementwise_fma(t, p, (f32x2)(-0.284496736f));
+    p = __builtin_elementwise_fma(t, p, (f32x2)(0.254829592f));
+    const f32x2 poly = t * p;
+    const f32x2 ea = (z * z) * (-1.4426950408889634f);
+    const f32x2 e = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+    const f32x2 erfc = poly * e;
+    const f32x2 w = {x.x >= 0.0f ? 2.0f - erfc.x : erfc.x, x.y >= 0.0f ? 2.0f - erfc.y : erfc.y};
+    return (0.5f * x) * w;
+}
+#else
+__device__ __forceinline__ f32x2 bc_gelu_f2(f32x2 x) { return (f32x2){bc_gelu_f(x.x), bc_gelu_f(x.y)}; }
+#endif
+
 // CLIP's "quick_gelu": x * sigmoid(1.702 x)  (transformers activations.QuickGELUActivation)
 __device__ __forceinline__ float bc_quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 

@@ -207,10 +207,18 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
     }
     if (p.act == BC_ACT_GEGLU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= bc_gelu_f(gt[j] + c.bias_g[j]);
+        for (int j = 0; j < 8; j += 2) {             // (bc_gelu_f2 = bc_gelu_f bit for bit, two elements per VALU issue)
+            const f32x2 gl = bc_gelu_f2((f32x2){gt[j] + c.bias_g[j], gt[j + 1] + c.bias_g[j + 1]});
+            v[j] *= gl.x;
+            v[j + 1] *= gl.y;
+        }
     } else if (p.act == BC_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = bc_gelu_f2((f32x2){v[j], v[j + 1]});
+            v[j] = gl.x;
+            v[j + 1] = gl.y;
+        }
     } else if (p.act == BC_ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);

@@ -782,8 +782,12 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
                 const int hc0 = HPW * wave + 16 * tp + 4 * q;           // hidden unit (inside the chunk) of this lane's first value
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const float v[4] = {(a1[0][mt][0] + bv.x) * bc_gelu_f(a1[1][mt][0] + bg.x), (a1[0][mt][1] + bv.y) * bc_gelu_f(a1[1][mt][1] + bg.y),
-                                        (a1[0][mt][2] + bv.z) * bc_gelu_f(a1[1][mt][2] + bg.z), (a1[0][mt][3] + bv.w) * bc_gelu_f(a1[1][mt][3] + bg.w)};
+                    // (two elements per VALU issue: bc_gelu_f2 = bc_gelu_f bit for bit)
+                    const f32x2 g01 = bc_gelu_f2((f32x2){a1[1][mt][0], a1[1][mt][1]} + (f32x2){bg.x, bg.y});
+                    const f32x2 g23 = bc_gelu_f2((f32x2){a1[1][mt][2], a1[1][mt][3]} + (f32x2){bg.z, bg.w});
+                    const f32x2 v01 = ((f32x2){a1[0][mt][0], a1[0][mt][1]} + (f32x2){bv.x, bv.y}) * g01;
+                    const f32x2 v23 = ((f32x2){a1[0][mt][2], a1[0][mt][3]} + (f32x2){bv.z, bv.w}) * g23;
+                    const float v[4] = {v01.x, v01.y, v23.x, v23.y};
                     *reinterpret_cast<h16x4*>(P + x_off(hc0 >> 5, 16 * mt + m, (hc0 & 31) >> 3) + ((hc0 >> 2) & 1) * 8) = pack4(v);
                 }
                 if (stamps) acc_t[1] += __builtin_amdgcn_s_memtime() - tb;
