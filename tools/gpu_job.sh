@@ -1,11 +1,6 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/bench_final.json"))
-print(d["value"], d["config"]["denoise_step_ms"], d["roofline"]["frac"], d["roofline"]["full_grid_launches"], d["roofline"]["traffic"], d["roofline"]["mfma_busy"])
-print({k:v for k,v in d["configs"].items() if not isinstance(v,(dict,str))})
-print(d["configs"]["script_default"]); print(d["end_to_end"]["edit_ms_end_to_end"], d["cpu_baseline"]["s_per_step"])
-PY
+python bench.py --no-cpu-baseline --no-e2e 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['denoise_step_ms'], {k:v for k,v in d['configs'].items() if not isinstance(v,(dict,str))})"
+python bench.py --no-cpu-baseline --no-e2e --no-configs --scheduler unipc 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('unipc headline', d['config']['denoise_step_ms'])"
+BC_NO_CTX_FOLD=1 python bench.py --no-cpu-baseline --no-e2e --no-configs --scheduler unipc 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('unipc headline nofold', d['config']['denoise_step_ms'])"
