@@ -401,6 +401,15 @@ int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int he
         if (wgs8 >= min8 && Nkv >= 1024 && !causal && !getenv("BC_ATTN_NO8"))
             return launch_attn_nw<D, 8, 1, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
     }
+    if constexpr (D == 80) {
+        // Round 5: the 8-wave form at the 32 x 64 level too (2048 keys; the UNet's launch = 128 workgroups: a K / V^T tile staged once for 256
+        // queries, two waves per SIMD on half the CUs instead of one wave per SIMD on all of them - their MFMA and softmax phases
+        // interleave, and the other queue has the other CUs): six interleaved same-box pairs, ms per step, 4-wave vs 8-wave: 9.122 / 9.071,
+        // 9.086 / 9.082, 9.094 / 9.076, 9.084 / 9.068, 8.937 / 8.887, 8.907 / 8.904.  BC_ATTN_80_4=1: the 4-wave form.
+        static const bool w8 = getenv("BC_ATTN_80_4") == nullptr;
+        if (w8 && Nkv >= 1024 && !causal && Nq % (QW * 8) == 0)
+            return launch_attn_nw<D, 8, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
+    }
     if constexpr (D <= 40) {
         // enough workgroups for 4 per CU and a long key loop: take the 128-VGPR build (4 waves per SIMD)
         const long long wgs = (long long)bc_ceil_div(Nq, QW * 4) * heads * B;
