@@ -14,10 +14,11 @@ A_DENSE, A_CONV3X3 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_F16, OUT_F16_T, OUT_F32 = 0, 1, 2
 TILE_NAMES = ["auto", "256x128", "128x128_s3", "128x128_s2", "256x64_s2", "256x64_s3", "128x64", "64x64", "halo128x160", "wreg128x160",
-              "gw64x128", "gw64x256", "gw64x320"]
+              "gw64x128", "gw64x256", "gw64x320", "g256x256"]
 TILE_HALO = 8
 TILE_WREG = 9
 TILE_GW64x128, TILE_GW64x256, TILE_GW64x320 = 10, 11, 12
+TILE_G256 = 13                       # gemm256.hip: 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups
 GW_TILES = {TILE_GW64x128: 2, TILE_GW64x256: 4, TILE_GW64x320: 5}      # configuration -> 16-column tiles per wave (BN = 64 NT)
 
 
@@ -61,6 +62,7 @@ _SIGNATURES = {
     "bc_gemm_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gemm_wreg_stream_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "bc_gemm_wreg_eligible": (C.c_int, [C.c_int] * 5),
+    "bc_gemm256_eligible": (C.c_int, [C.c_int] * 6),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -507,6 +507,23 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         g.vec_transposed = 0; g.nband = 1;
         return bc_gemm_wreg_launch(g, stream);
     }
+    if (p.tile_cfg == BC_TILE_G256) {
+        BC_CHECK_ARG(bc_gemm256_ok(p), "bc_gemm: BC_TILE_G256 needs dense single-source A, M%%256==0, N%%256==0, K%%128==0, no split-K, fp16 row-major "
+                     "or transposed (bias / alpha only) output (M=%d N=%d K=%d out_mode=%d)", p.M, p.N, p.K, p.out_mode);
+        g.nk = p.K / BK; g.kt_per_split = g.nk; p.splitk = 1;
+        g.div_rpb = make_fastdiv((unsigned)p.rows_per_batch);
+        g.div_outw = make_fastdiv((unsigned)p.out_w);
+        g.div_wout = make_fastdiv(1u);
+        g.cfg = BC_TILE_G256; g.bm = 256; g.bn = 256;
+        auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+        g.vec_epilogue = g.n_out % 8 == 0 && p.ldc % 8 == 0 && al16(p.C) && (!p.R || (p.ldr % 8 == 0 && al16(p.R))) &&
+                         (!p.R2 || (p.ldr2 % 8 == 0 && al16(p.R2))) && (!p.rowvec || p.ld_rowvec % 8 == 0);
+        BC_CHECK_ARG(g.vec_epilogue, "bc_gemm: BC_TILE_G256 needs 16-byte aligned C / R / R2 and widths %% 8 == 0");
+        BC_CHECK_ARG(!p.gn_tot || (p.rows_per_batch % 256 == 0 && p.M % p.rows_per_batch == 0),
+                     "bc_gemm: BC_TILE_G256 with GroupNorm statistics needs rows_per_batch%%256==0 (a tile's rows inside one image)");
+        g.vec_transposed = p.out_mode == BC_OUT_F16_T; g.nband = 0;
+        return bc_gemm256_launch(g, stream);
+    }
     const bool wreg = p.tile_cfg == BC_TILE_WREG;
     const bool halo = p.tile_cfg == BC_TILE_HALO || wreg;
     if (halo) {

@@ -1,0 +1,403 @@
+// Large-M dense GEMM for gfx950 (BC_TILE_G256, round 6): 256 x 256 tiles, 8 waves, the "8-phase" LDS-DMA pipeline, persistent workgroups.
+//
+// Same contract as gemm.hip / gemm_fast.hip (C = epilogue(A . W^T), both operands K-contiguous fp16, fp32 accumulation) for the dense
+// projections that carry the 1280-channel levels once a batch is large (M = B.H.W >= 2048 token rows): the Linear / 1 x 1 convolution
+// layers of diffusers/src/diffusers/models/attention.py:1161-1167 (GEGLU feed-forward), attention_processor.py:2191-2224 (to_q / to_k /
+// to_v / to_out), transformers/transformer_2d.py:479-527 (proj_in / proj_out) and BlobNet's zero-convs (blobctrl/models/blobnet.py:860-864).
+// gemm_fast.hip's best tile (256 x 128, 3-stage LDS-DMA ring, one barrier per k-tile) runs those at 370-670 TFLOP/s (profiles/r6_c3_*);
+// the vendor library on the same box and data does 1351 at 4096^3 (profiles/r5_blas_ceiling.txt).  This kernel: 1257 / 1263 TFLOP/s at
+// 4096^3 / 8192^3 and 900-970 at the network's K = 1280 shapes stand-alone (tools/gemm8p_probe.hip, profiles/r6_gemm8p_probe.txt).
+//
+// Structure (cdna_hip_programming.md section 5 "The 256^2 8-phase template", rebuilt from its description):
+//   * 8 waves = 2 (M halves) x 4 (N quarters); a wave owns 128 x 64 outputs as 8 x 4 accumulator tiles of v_mfma_f32_16x16x32_f16 (128
+//     registers); the product is formed swapped (D^T = W . X^T), so a lane holds 4 consecutive output columns of one row;
+//   * operands go global -> LDS by LDS-DMA in HALF-TILES of 16 KB: per 64-k tile B0, A0, B1, A1, where "0" / "1" is the part every wave
+//     needs in phases {0, 1} / {2, 3} (A: its rows 0-63 / 64-127; B: its columns 0-31 / 32-63).  A wave issues 2 LDS-DMA instructions per
+//     half-tile, one half-tile per phase, SEVEN half-tiles ahead of the phase that first reads it; one counted s_waitcnt vmcnt(6) per k-tile
+//     and raw s_barriers keep 3..7 half-tiles in flight across the barriers;
+//   * the LDS image is made of 1-KiB sub-tiles [16 rows][32 k] - exactly one MFMA operand fragment - with 64-byte rows whose 16-byte chunk
+//     index is XOR-ed with 2 for rows >= 8: every ds_read_b128 of a fragment is conflict-free over the four 16-lane service groups
+//     (MI355X_MICROARCH.md LDS).  LDS-DMA lands lane-linearly, so the swizzle sits on the per-lane SOURCE address;
+//   * a phase = {fragment reads (12 / 4 / 8 / 0) + 2 LDS-DMA issues | s_barrier | 16 MFMAs = one 64 x 32 quadrant over the tile's 64 k |
+//     s_barrier}; the two wave groups (one wave of each on every SIMD) run ONE BARRIER APART, so one group's MFMAs run beside the other
+//     group's reads and DMA issues (the guide's 8-wave ping-pong);
+//   * persistent workgroups (grid = min(tiles, CUs)): an XCD owns a contiguous run of tile ids (4-row grouped order), and the staging
+//     stream simply runs on into the NEXT tile's first seven half-tiles during the last two k-tiles - the next tile's cold-start latency
+//     hides under this tile's epilogue;
+//   * epilogue through a 32-KiB LDS slab beside the staging buffers, 8 passes of 2 x 16 rows x 256 columns: accumulators parked raw
+//     (XOR-swizzled 16-byte chunks: conflict-free both ways), re-read row-major, 8 output columns per thread = gemm_fast's shared
+//     epilogue (bias, GEGLU / GELU / SiLU, scales, residual, BlobNet right-half residual, 16-byte stores, GroupNorm statistics totals);
+//     BC_OUT_F16_T (V^T for the attention kernel) as 16-byte stores along the token axis.
+// Eligibility (bc_gemm256_eligible): dense single-source A, M % 256 == 0, N % 256 == 0, K % 128 == 0, no split-K.
+#include <stdlib.h>
+#include <type_traits>
+#include "gemm_common.h"
+
+using namespace bcg;
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) { __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0); }
+
+constexpr int G_BM = 256, G_BN = 256;
+constexpr int HT = 16384;              // half-tile bytes
+constexpr int KBUF = 4 * HT;           // one k-tile: [B0][A0][B1][A1]
+constexpr int STG_BYTES = 2 * KBUF;    // 128 KiB of staging
+constexpr int SLAB_BYTES = 32768;      // epilogue slab: 32 rows x 256 fp32
+constexpr int G_LDS = STG_BYTES + SLAB_BYTES;
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BAR() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
+
+struct Frags {
+    h16x8 a[4][2];                     // current A sub-block: 4 row tiles x 2 k-steps
+    h16x8 b0[2][2], b1[2][2];          // B sub-blocks: 2 column tiles x 2 k-steps
+};
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+// The four phases of one 64-k tile held in staging buffer B.  MODE 0: every phase stages a half-tile (a1 = source of A1 of the NEXT
+// k-tile; b0n / a0n / b1n = sources of B0 / A0 / B1 of the k-tile after that - possibly the next output tile's); 1: first tile of a
+// draining pair (only phase 0 stages; phase 3 waits for everything); 2: last tile (nothing staged, nothing waited for).
+template <int B, int MODE>
+__device__ __forceinline__ void tile_phases(f32x4 (&acc)[8][4], Frags& f, const char* aB, const char* bB, char* stg, const char* a1, const char* b0n,
+                                            const char* a0n, const char* b1n, unsigned voA, unsigned voB) {
+    constexpr int O = B * KBUF, ON = (B ^ 1) * KBUF;
+    auto mfma = [&](auto ac, auto bc) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SB();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[a * 4 + rt][b * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b ? f.b1[ct][ks] : f.b0[ct][ks], f.a[rt][ks], acc[a * 4 + rt][b * 2 + ct], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // ---- phase 0: B0 + A0 fragments; stage A1 of the next k-tile
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.b0[ct][ks] = *reinterpret_cast<const h16x8*>(bB + O + 0 * HT + ct * 2048 + ks * 1024);
+    SB();
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.a[rt][ks] = *reinterpret_cast<const h16x8*>(aB + O + 1 * HT + rt * 2048 + ks * 1024);
+    SB();
+    if (MODE <= 1) {
+        glds16(a1 + voA, stg + ON + 3 * HT);
+        glds16(a1 + voA + 64, stg + ON + 3 * HT + 1024);
+    }
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the B0 reads have returned: B0's slot is restaged one phase later
+    BAR();
+    mfma(IC<0>{}, IC<0>{});
+    BAR();
+    // ---- phase 1: B1 fragments; stage B0 two k-tiles ahead
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.b1[ct][ks] = *reinterpret_cast<const h16x8*>(bB + O + 2 * HT + ct * 2048 + ks * 1024);
+    SB();
+    if (MODE == 0) {
+        glds16(b0n + voB, stg + O + 0 * HT);
+        glds16(b0n + voB + 64, stg + O + 0 * HT + 1024);
+    }
+    BAR();
+    mfma(IC<0>{}, IC<1>{});
+    BAR();
+    // ---- phase 2: A1 fragments; stage A0 two k-tiles ahead
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.a[rt][ks] = *reinterpret_cast<const h16x8*>(aB + O + 3 * HT + rt * 2048 + ks * 1024);
+    SB();
+    if (MODE == 0) {
+        glds16(a0n + voA, stg + O + 1 * HT);
+        glds16(a0n + voA + 64, stg + O + 1 * HT + 1024);
+    }
+    BAR();
+    mfma(IC<1>{}, IC<1>{});
+    BAR();
+    // ---- phase 3: no reads; stage B1 two k-tiles ahead; the wait that retires the next k-tile
+    if (MODE == 0) {
+        glds16(b1n + voB, stg + O + 2 * HT);
+        glds16(b1n + voB + 64, stg + O + 2 * HT + 1024);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (MODE == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BAR();
+    mfma(IC<1>{}, IC<0>{});
+    BAR();
+}
+
+// tile index -> (row tile, column tile): runs of 4 row tiles walk the columns, so that consecutive ids share operand panels
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 4;
+    const int full = (tiles_m / GM) * GM * tiles_n;
+    if (id < full) {
+        const int grp = id / (GM * tiles_n), r = id - grp * GM * tiles_n;
+        tm = grp * GM + (r % GM);
+        tn = r / GM;
+    } else {                                               // the last tiles_m % 4 row tiles: row-major
+        const int r = id - full;
+        tm = (tiles_m / GM) * GM + r / tiles_n;
+        tn = r % tiles_n;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BcGemm& p = g.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_m = p.M / G_BM, tiles_n = p.N / G_BN, ntiles = tiles_m * tiles_n;
+    // persistent schedule: XCD x (= blockIdx % 8) owns the contiguous run [start, start + cnt) of tile ids; its workgroups (slot = blockIdx / 8)
+    // take the run round-robin, so that the tiles in flight on an XCD are neighbours
+    const int G = gridDim.x;
+    int j, jstep, jend;
+    if (G >= 8) {
+        const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        j = start + (blockIdx.x >> 3);
+        jstep = G >> 3;
+        jend = start + q + (xcd < r ? 1 : 0);
+    } else {
+        j = blockIdx.x; jstep = G; jend = ntiles;
+    }
+    if (j >= jend) return;                                  // (never with the launcher's grid; all waves leave together)
+
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    const long long lda2 = 2ll * p.lda, ldw2 = 2ll * p.ldw;
+    // staging: this wave fills sub-tiles 2 wave, 2 wave + 1 (the two k-steps of one 16-row group) of every half-tile; a lane lands in
+    // (row lane >> 2, chunk lane & 3) of the sub-tile (lane-linear) and fetches the chunk that the read-side swizzle expects there
+    const int srow = lane >> 2;
+    const int skq = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const unsigned voA = (unsigned)(((wave >> 2) * 128 + (wave & 3) * 16 + srow) * lda2 + skq * 16);       // + 64 rows: the "1" half
+    const unsigned voB = (unsigned)(((wave >> 1) * 64 + (wave & 1) * 16 + srow) * ldw2 + skq * 16);        // + 32 rows: the "1" half
+    const long long a_half = 64 * lda2, b_half = 32 * ldw2;
+    char* stg = smem + wave * 2048;
+    // fragment reads: lane (r = lane & 15, kq = lane >> 4) reads chunk kq ^ (2 if r >= 8) of row r
+    const int foff = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);
+    const char* aB = smem + wr * 8192 + foff;
+    const char* bB = smem + wc * 4096 + foff;
+    float* slab = reinterpret_cast<float*>(smem + STG_BYTES);
+
+    int tm, tn;
+    tile_coords(j, tiles_m, tiles_n, tm, tn);
+    const char* cA = Ab + (long long)tm * G_BM * lda2;     // wave-uniform bases of the current tile's operand panels (k = 0)
+    const char* cB = Wb + (long long)tn * G_BN * ldw2;
+    const int T = p.K / BK;                                 // even, >= 2
+    // prologue: half-tiles 0..6 = k-tile 0 (B0 A0 B1 A1), k-tile 1 (B0 A0 B1)
+    glds16(cB + voB, stg + 0 * HT);                    glds16(cB + voB + 64, stg + 0 * HT + 1024);
+    glds16(cA + voA, stg + 1 * HT);                    glds16(cA + voA + 64, stg + 1 * HT + 1024);
+    glds16(cB + b_half + voB, stg + 2 * HT);           glds16(cB + b_half + voB + 64, stg + 2 * HT + 1024);
+    glds16(cA + a_half + voA, stg + 3 * HT);           glds16(cA + a_half + voA + 64, stg + 3 * HT + 1024);
+    glds16(cB + 128 + voB, stg + KBUF + 0 * HT);       glds16(cB + 128 + voB + 64, stg + KBUF + 0 * HT + 1024);
+    glds16(cA + 128 + voA, stg + KBUF + 1 * HT);       glds16(cA + 128 + voA + 64, stg + KBUF + 1 * HT + 1024);
+    glds16(cB + b_half + 128 + voB, stg + KBUF + 2 * HT); glds16(cB + b_half + 128 + voB + 64, stg + KBUF + 2 * HT + 1024);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    BAR();
+
+    f32x4 acc[8][4];
+    Frags f;
+    const bool geglu = p.act == BC_ACT_GEGLU;
+    const bool transposed = p.out_mode == BC_OUT_F16_T;
+    const float alpha = scalar_alpha(p);
+
+    for (;;) {
+        const int jn = j + jstep;
+        const bool has_next = jn < jend;                    // (workgroup-uniform)
+        const char *nA = cA, *nB = cB;
+        int tmn = tm, tnn = tn;
+        if (has_next) {
+            tile_coords(jn, tiles_m, tiles_n, tmn, tnn);
+            nA = Ab + (long long)tmn * G_BM * lda2;
+            nB = Wb + (long long)tnn * G_BN * ldw2;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) BAR();                                 // the second wave group runs one barrier behind the first
+        long long kb = 0;                                   // byte offset of the pair's first k-tile inside a row
+        for (int it = 0; it < T / 2; ++it) {
+            // sources of the k-tiles two and three ahead: this tile's - or, in the last pair, the NEXT tile's k-tiles 0 and 1: the staging
+            // stream runs on across the tile boundary (without a next tile it re-reads this tile's head: 7 half-tiles nobody uses)
+            const bool last = it == T / 2 - 1;              // (uniform)
+            const char* hA = last ? nA : cA + kb + 256;
+            const char* hB = last ? nB : cB + kb + 256;
+            tile_phases<0, 0>(acc, f, aB, bB, stg, cA + a_half + kb + 128, hB, hA, hB + b_half, voA, voB);
+            tile_phases<1, 0>(acc, f, aB, bB, stg, hA + a_half, hB + 128, hA + 128, hB + b_half + 128, voA, voB);
+            kb += 256;
+        }
+        if (wr == 0) BAR();                                 // both groups in step again
+
+        // ------------------------------------------------------------------------------------------------ epilogue of tile (tm, tn)
+        // (lane-derived epilogue addresses come from a laundered thread id: they are tile-invariant, and hoisted out of the tile loop they
+        //  would stay live across the k-loop, where the 192 accumulator + fragment registers leave no room for them)
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+#define tid tid_e
+        const int lane_e = tid_e & 63;
+#define lane lane_e
+        const int m0 = tm * G_BM, n0 = tn * G_BN;
+        const int wrow = wr * 16 + (lane & 15);             // slab row this lane parks into
+        char* wbase = reinterpret_cast<char*>(slab) + wrow * 1024;
+        const int wsw = wrow & 7, wc4 = wc * 16 + (lane >> 4);
+        if (!transposed) {
+            const int TSO = geglu ? G_BN / 2 : G_BN;        // output columns of this tile
+            const int CPR = TSO / 8;                        // 8-column chunks per row: 32 or 16
+            const int col8 = tid & (CPR - 1);
+            const int c_out = col8 * 8;
+            const int n_first = (geglu ? n0 / 2 : n0) + c_out;
+            const int cv = geglu ? (c_out >> 5) * 64 + (c_out & 31) : c_out;      // tile column of the (value) accumulators
+            const int nitem = geglu ? 1 : 2;
+            Cols8 cols;
+            cols8_init(g, cols, n_first, n0 + cv, geglu, alpha);
+            float gs[8], gq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { gs[q] = 0.f; gq[q] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    *reinterpret_cast<f32x4*>(wbase + (((wc4 + (jj >> 1) * 8 + (jj & 1) * 4) ^ wsw) << 4)) = acc[i][jj];
+                __syncthreads();
+                for (int c = 0; c < nitem; ++c) {
+                    const int rl = (tid + 512 * c) / CPR;                          // slab row 0..31
+                    const int m = m0 + (rl >> 4) * 128 + i * 16 + (rl & 15);
+                    const char* rb = reinterpret_cast<const char*>(slab) + rl * 1024;
+                    const int sw = rl & 7, c4 = cv >> 2;
+                    const float4 lo = *reinterpret_cast<const float4*>(rb + ((c4 ^ sw) << 4));
+                    const float4 hi = *reinterpret_cast<const float4*>(rb + (((c4 + 1) ^ sw) << 4));
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (geglu) {
+                        const float4 glo = *reinterpret_cast<const float4*>(rb + (((c4 + 8) ^ sw) << 4));
+                        const float4 ghi = *reinterpret_cast<const float4*>(rb + (((c4 + 9) ^ sw) << 4));
+                        gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
+                        gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
+                    }
+                    epi8_store(g, cols, v, gt, m, gs, gq);
+                }
+                __syncthreads();
+            }
+            if (p.gn_tot) {
+                // per-thread column partials -> lanes with equal col8 inside a wave -> waves (through the slab) -> one atomic add per column
+                for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        gs[q] += __shfl_xor(gs[q], o);
+                        gq[q] += __shfl_xor(gq[q], o);
+                    }
+                }
+                if (lane < CPR) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        slab[((wave * TSO) + c_out + q) * 2] = gs[q];
+                        slab[((wave * TSO) + c_out + q) * 2 + 1] = gq[q];
+                    }
+                }
+                __syncthreads();
+                if (tid < TSO) {
+                    float s = 0.f, q2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        s += slab[(w * TSO + tid) * 2];
+                        q2 += slab[(w * TSO + tid) * 2 + 1];
+                    }
+                    const int b = (int)fdiv((unsigned)m0, g.div_rpb);
+                    bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + tid) * BC_GN_TOT_WORDS, s, q2);
+                }
+                __syncthreads();
+            }
+        } else {
+            // BC_OUT_F16_T: thread = (column, 8 consecutive tokens) -> one 16-byte store into C[(b N + n) ldc + pix]  (bias and alpha only)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    *reinterpret_cast<f32x4*>(wbase + (((wc4 + (jj >> 1) * 8 + (jj & 1) * 4) ^ wsw) << 4)) = acc[i][jj];
+                __syncthreads();
+                for (int c = 0; c < 2; ++c) {
+                    const int item = tid + 512 * c;
+                    const int col = item & 255, ch = item >> 8;                     // ch 0..3: rows 8 ch .. 8 ch + 7 of the slab
+                    const int n = n0 + col;
+                    const int m = m0 + (ch >> 1) * 128 + i * 16 + (ch & 1) * 8;
+                    const float bias = p.bias ? p.bias[n] : 0.f;
+                    uint4 outraw;
+                    h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int rl = ch * 8 + r;
+                        const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(slab) + rl * 1024 + ((((col >> 2) ^ (rl & 7))) << 4) + (col & 3) * 4);
+                        o[r] = (h16)((x + bias) * alpha);
+                    }
+                    const int b = (int)fdiv((unsigned)m, g.div_rpb);
+                    const int pix = m - b * (int)g.div_rpb.d;
+                    bc_st16(reinterpret_cast<h16*>(p.C) + ((size_t)b * g.n_out + n) * p.ldc + pix, outraw);
+                }
+                __syncthreads();
+            }
+        }
+#undef tid
+#undef lane
+        if (!has_next) break;
+        j = jn; tm = tmn; tn = tnn; cA = nA; cB = nB;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the last tile's run-ahead LDS-DMA must have landed before the LDS is given back)
+}
+
+}  // namespace
+
+int bc_gemm256_ok(const BcGemm& p) {
+    if (p.a_mode != BC_A_DENSE || p.A2 || p.splitk > 1) return 0;
+    if (p.M <= 0 || p.M % G_BM != 0 || p.N % G_BN != 0 || p.K % 128 != 0 || p.K < 128) return 0;
+    if (p.a_affine || p.a_tot1 || p.ln_colsum || p.C_t || p.w_bstride || p.vec_bstride || p.sm_group) return 0;
+    if (p.out_mode == BC_OUT_F16_T) {
+        if (p.act != BC_ACT_NONE || p.rowvec || p.colscale || p.R || p.R2 || p.gn_tot || p.alpha_bstride) return 0;
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (rpb % 8 != 0 || p.M % rpb != 0) return 0;
+    } else if (p.out_mode != BC_OUT_F16) {
+        return 0;
+    }
+    // per-lane source offsets are 32-bit: 256 rows of either operand must stay below 4 GiB
+    if (256ll * 2 * std::max(p.lda, p.ldw) >= (1ll << 31)) return 0;
+    return 1;
+}
+
+extern "C" int bc_gemm256_eligible(int M, int N, int K, int out_mode, int rows_per_batch, int want_gn) {
+    BcGemm p = {};
+    p.a_mode = BC_A_DENSE; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.out_mode = out_mode; p.splitk = 1; p.alpha = 1.0f;
+    p.rows_per_batch = rows_per_batch;
+    if (want_gn && (rows_per_batch <= 0 || rows_per_batch % G_BM != 0)) return 0;      // a tile's rows must lie inside one image
+    return bc_gemm256_ok(p);
+}
+
+int bc_gemm256_launch(const GemmArgs& g, hipStream_t stream) {
+    const BcGemm& p = g.p;
+    const int ntiles = (p.M / G_BM) * (p.N / G_BN);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    int grid = std::min(ntiles, cus);
+    if (grid >= 8) grid &= ~7;                              // (the schedule deals whole workgroups to the 8 XCDs)
+    static std::atomic<unsigned long long> lds_set{0};
+    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm256_kernel), G_LDS));
+    hipLaunchKernelGGL(gemm256_kernel, dim3(grid), dim3(512), G_LDS, stream, g);
+    BC_CHECK_LAUNCH();
+    return 0;
+}

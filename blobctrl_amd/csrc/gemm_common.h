@@ -326,3 +326,6 @@ int bc_conv_wreg_launch(bcg::GemmArgs& g, hipStream_t stream);
 int bc_gemm_wreg_nt(int tile_cfg);
 int bc_gemm_wreg_ok(const BcGemm& p, int tile_cfg);
 int bc_gemm_wreg_launch(const bcg::GemmArgs& g, hipStream_t stream);
+// gemm256.hip: large-M dense projections on 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent (BC_TILE_G256).
+int bc_gemm256_ok(const BcGemm& p);
+int bc_gemm256_launch(const bcg::GemmArgs& g, hipStream_t stream);

@@ -120,12 +120,29 @@ class TrunkPlan:
                  bias=pw.f[wname + ".bias"], rows_per_batch=Hout * Wout, kind=kind, want_gn=not out_f32, **kw)
         return Act(out, Cout, Hout, Wout)
 
+    def g256_tile(self, M, N, K, kw):
+        """BC_TILE_G256 (csrc/gemm256.hip: 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups) for a dense
+        single-source projection with enough tiles to fill the chip, else 0 = the planner's LDS-DMA tiles.  Stand-alone on an MI355X
+        (tools/gemm8p_probe.hip, TFLOP/s, gemm_fast's best tile in brackets): [8192 x 10240 x 1280] 903 (673), [8192 x 1280 x 5120]
+        957 (571), [8192 x 3840 x 1280] 968, [8192 x 1280 x 1280] 708 (~450; 160 tiles on 256 CUs), [4096 x 1280 x 1280] 392 (80 tiles:
+        stays on the 256 x 128 tiles) - hence the tile-count threshold (BC_G256_MIN_TILES, default 128)."""
+        if os.environ.get("BC_NO_G256") or kw.get("A2") is not None or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
+            return 0
+        if M % 256 or N % 256 or (M // 256) * (N // 256) < int(os.environ.get("BC_G256_MIN_TILES", "128")):
+            return 0
+        want_gn = 1 if kw.get("want_gn") else 0
+        ok = self.rec.lib.bc_gemm256_eligible(M, N, K, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, want_gn)
+        return _lib.TILE_G256 if ok else 0
+
     def dense(self, x_t, M, K, wname, N, bias=True, out=None, kind="linear", wkey=None, **kw):
         rec, pw = self.rec, self.pw
         act = kw.get("act", _lib.ACT_NONE)
         n_out = N // 2 if act == _lib.ACT_GEGLU else N
         if out is None:
             out = rec.empty(M, n_out)
+        g256 = self.g256_tile(M, N, K, kw)
+        if g256:
+            kw["tile_cfg"] = g256
         rec.gemm(A=x_t, W=pw.h[wkey or (wname + ".weight")], M=M, N=N, K=K, out=out,
                  bias=pw.f[wname + ".bias"] if bias else None, kind=kind, **kw)
         return out

@@ -470,6 +470,11 @@ class Recorder:
                 self.keep.append((t1, a_gn["gamma"], a_gn["beta"]))
                 for t in (t1, a_gn["gamma"], a_gn["beta"]):
                     self.register(t)
+        elif tile_cfg == _lib.TILE_G256:
+            # large-M dense projection on 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups (gemm256.hip)
+            assert not conv and A2 is None and a_affine is None and splitk in (None, 1)
+            cfg, sk, bm, bn = tile_cfg, 1, 256, 256
+            fast, mode = True, "g256"
         else:
             assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO / TILE_WREG"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)
@@ -497,13 +502,15 @@ class Recorder:
         for t in refs:
             self.register(t)
         variant = ("conv_halo_kernel<" if cfg == _lib.TILE_HALO else "conv_wreg_kernel<" if cfg == _lib.TILE_WREG else
-                   "gemm_wreg_kernel<" if cfg in _lib.GW_TILES else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
+                   "gemm_wreg_kernel<" if cfg in _lib.GW_TILES else "gemm256_kernel<" if cfg == _lib.TILE_G256 else "gemm_fast_kernel<" if fast else "gemm_kernel<") + _lib.TILE_NAMES[cfg] + "," + mode + ">" + \
             ("+splitk_reduce" if sk > 1 else "")
         # the instantiation rocprofv3 reports for this launch (csrc/*.hip launchers)
         FAST = {1: "256, 128, 4, 2, 3", 2: "128, 128, 2, 2, 3", 3: "128, 128, 2, 2, 2", 4: "256, 64, 4, 1, 2", 5: "256, 64, 4, 1, 3",
                 6: "128, 64, 2, 2, 3", 7: "64, 64, 2, 2, 4"}
         if cfg in (_lib.TILE_HALO, _lib.TILE_WREG):
             rp = ("conv_wreg_kernel" if cfg == _lib.TILE_WREG else "conv_halo_kernel") + f"<{2 if g.a_tot1 else 1 if g.a_affine else 0}>"
+        elif cfg == _lib.TILE_G256:
+            rp = "gemm256_kernel"
         elif cfg in _lib.GW_TILES:
             rp = f"gemm_wreg_kernel<{_lib.GW_TILES[cfg]}, {10 if _lib.GW_TILES[cfg] == 5 else 20}, {'true' if sm_group else 'false'}>"
         elif fast:

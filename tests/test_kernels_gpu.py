@@ -946,3 +946,90 @@ def test_cross_attention_as_two_folded_projections(rec, rows, T, Cc):
     assert float(pr[..., T:].abs().max()) == 0.0                       # padded keys carry no probability
     close(pr[..., :T].permute(0, 2, 1, 3), p, rtol=2e-2, atol=2e-3, what="probabilities")
     close(out, ref, what=f"folded cross-attention, {rows} rows per image")
+
+
+# ---------------------------------------------------------------------------------------------------- BC_TILE_G256 (gemm256.hip, round 6)
+@pytest.mark.parametrize("mode", ["plain", "geglu", "gelu_alpha", "res_r2_gn", "transposed", "rowscale"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (1024, 512, 256), (9728, 2560, 384)])
+def test_gemm256_modes(rec, mode, M, N, K):
+    """The 256 x 256 / 8-wave / 8-phase LDS-DMA GEMM against fp32 torch on the fp16-rounded operands: every epilogue mode the plan uses it
+    with, at tile counts from 1 (one workgroup, two k-tiles: prologue + drain only) to 360 (persistent workgroups that take a second
+    tile while the first one's epilogue runs; the 9 x 4-row grouped tile order with a ragged last group of 2 row tiles)."""
+    from blobctrl_amd import _lib
+    if M == 9728 and mode not in ("plain", "res_r2_gn", "geglu"):
+        pytest.skip("the large case runs the three modes that differ in the persistent epilogue")
+    B = 2 if M % 512 == 0 else 1
+    rows = M // B
+    A = g(1, M, K) * 1.3 + 0.2
+    W = g(2, N, K) / math.sqrt(K)
+    b = g(3, N)
+    x = A.half().float()
+    ref = x @ W.half().float().t() + b
+    kw, n_out, out = {}, N, None
+    if mode == "geglu":
+        r4 = ref.view(M, N // 64, 2, 32)
+        ref = (r4[:, :, 0] * F.gelu(r4[:, :, 1])).reshape(M, N // 2)
+        n_out = N // 2
+        kw.update(act=_lib.ACT_GEGLU)
+    if mode == "gelu_alpha":
+        ref = F.gelu(ref) * 0.7
+        kw.update(act=_lib.ACT_GELU, alpha=0.7)
+    if mode == "res_r2_gn":
+        R, R2 = g(7, M, N), g(8, 1, rows, N)
+        Wd, xmin = 16, 8                                            # canvas rows / 16 x 16, residual added on the right half
+        ref = ref + R.half().float()
+        msk = (torch.arange(rows) % Wd >= xmin).float()[None, :, None]
+        ref = (ref.view(B, rows, N) + R2.half().float() * msk).view(M, N)
+        kw.update(R=h(R), ldr=N, R2=h(R2), ldr2=N, r2_xmin=xmin, r2_bmod=1, out_w=Wd, rows_per_batch=rows, want_gn=rows % 256 == 0)
+    if mode == "rowscale":
+        tab = torch.tensor([9.0] * B + [0.7, 1.3][:B]).cuda()             # row 1 of a [steps][B] table
+        idx = torch.tensor([1], dtype=torch.int32).cuda()
+        sc = torch.tensor([0.7, 1.3])[:B].repeat_interleave(rows)[:, None]
+        ref = ref * 2.0 * sc
+        kw.update(alpha=2.0, alpha_dev=tab, alpha_idx=idx, alpha_bstride=B, rows_per_batch=rows)
+    if mode == "transposed":
+        ldc = rows + 64
+        out = torch.zeros(B, N, ldc, dtype=torch.float16, device="cuda")
+        kw.update(out_mode=_lib.OUT_F16_T, ldc=ldc, rows_per_batch=rows)
+        ref = ref.view(B, rows, N).permute(0, 2, 1)
+    assert rec.lib.bc_gemm256_eligible(M, N, K, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, 1 if kw.get("want_gn") else 0)
+    res = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=out if out is not None else rec.empty(M, n_out), bias=b.cuda(),
+                                    tile_cfg=_lib.TILE_G256, **kw))
+    assert rec.seg.meta[-1]["rocprof"] == "gemm256_kernel"
+    if mode == "transposed":
+        close(res[:, :, :rows], ref, what=f"gemm256 transposed {M}x{N}x{K}")
+        assert float(res[:, :, rows:].abs().max()) == 0.0
+    else:
+        close(res, ref, what=f"gemm256 {mode} {M}x{N}x{K}")
+    if kw.get("want_gn"):
+        from blobctrl_amd.launch import decode_gn_tot
+        o = res.float().cpu().view(B, rows, N)
+        want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+        close(decode_gn_tot(rec.tots[res.data_ptr()]), want, rtol=1e-4, atol=1e-2 * max(1.0, rows / 256), what="gemm256 GroupNorm statistics")
+
+
+def test_gemm256_replays_are_bit_identical_and_equal_the_lds_dma_tiles(rec):
+    """Race screen for the counted-vmcnt / raw-barrier pipeline (a read placed one phase early passes whenever the DMA happens to land
+    first): 12 replays of a 640-tile launch under changing cache state give the same bits, and those bits equal gemm_fast's 256 x 128
+    tile (same MFMA accumulation order per output: k ascending in steps of 32 vs 16 - so equal to fp32 rounding, not bit for bit)."""
+    from blobctrl_amd import _lib
+    M, N, K = 4096, 10240, 1280
+    A, W, b = g(11, M, K), g(12, N, K) / math.sqrt(K), g(13, N)
+    Ad, Wd, bd = h(A), h(W), b.cuda()
+    o1, o2 = rec.empty(M, N // 2), rec.empty(M, N // 2)
+    seg = rec.begin("g256_replay")
+    rec.gemm(A=Ad, W=Wd, M=M, N=N, K=K, out=o1, bias=bd, act=_lib.ACT_GEGLU, tile_cfg=_lib.TILE_G256)
+    rec.gemm(A=Ad, W=Wd, M=M, N=N, K=K, out=o2, bias=bd, act=_lib.ACT_GEGLU, tile_cfg=1)
+    s = torch.cuda.current_stream().cuda_stream
+    seg.run(s)
+    torch.cuda.synchronize()
+    first = o1.clone()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for i in range(12):
+        o1.zero_()
+        if i % 3 == 0:
+            junk.fill_(i)                                           # evict L2 / Infinity Cache: another arrival order of the half-tiles
+        seg.run(s)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, first), f"replay {i} differs"
+    close(o1, o2, rtol=2e-3, what="gemm256 vs gemm_fast 256x128")

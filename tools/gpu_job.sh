@@ -1,11 +1,15 @@
 #!/bin/bash
 # Scratch driver for one gpurun call (edited per call).
 cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+python bench.py --batch 8 --steps 1 --warmup 1 --denoise-steps 10 --no-cpu-baseline --no-e2e --no-configs --table > gpurun_out/t8.json 2> gpurun_out/t8.err
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/bench_final.json"))
-print(d["value"], d["config"]["denoise_step_ms"], d["roofline"]["frac"], d["roofline"]["full_grid_launches"], d["roofline"]["traffic"], d["roofline"]["mfma_busy"], d["roofline"]["avg_launch_us"])
-print({k:v for k,v in d["configs"].items() if not isinstance(v,(dict,str))})
-print(d["configs"]["script_default"]["edit_ms_end_to_end"], d["configs"]["script_default"]["denoise_step_ms"], d["end_to_end"]["edit_ms_end_to_end"], d["cpu_baseline"]["s_per_step"])
+s=open('gpurun_out/t8.err').read()
+i=s.index('{\n "by_kernel"')
+d,_=json.JSONDecoder().raw_decode(s[i:])
+for k,v in d['by_kernel'].items():
+    if v['ms']>0.1: print(f"{k[:60]:60s} n={v['launches']:4d} ms={v['ms']:.3f} TF={v['tflops']}")
+for r in d['top_shapes']:
+    if 'gemm' in r['variant']:
+        print(f"{r['kind']:10s} {r['variant'][:44]:44s} {str(r['shape']):40s} n={r['launches']:3d} us={1e3*r['ms']/r['launches']:.1f} TF={r['tflops']}")
 PY
