@@ -70,6 +70,7 @@ _SIGNATURES = {
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p]),
     "bc_memset_zero": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "bc_dup_halves": (C.c_int, [C.c_void_p, C.c_longlong] * 6 + [C.c_void_p]),
     "bc_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p]),
     "bc_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -153,7 +154,7 @@ OPS = {"bc_gemm": 0, "bc_gn_stats": 1, "bc_gn_finalize": 2, "bc_gn_apply_fused":
        "bc_timestep_embedding_table": 10, "bc_cfg_scheduler_step": 11, "bc_embed_tokens": 12, "bc_softmax_rows": 13,
        "bc_patchify": 14, "bc_add_cls_pos": 15, "bc_silu": 16, "bc_nchw_to_nhwc_f16": 17, "bc_nhwc_to_nchw": 18,
        "bc_gaussian_sample": 19, "bc_rowchain": 22, "bc_assemble_input_im2col": 23, "bc_memset_zero": 24,
-       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26, "bc_rowchain_sum": 27, "bc_ctx_fold": 28}
+       "bc_rowchain_midx": 25, "bc_rowchain_pack_kv": 26, "bc_rowchain_sum": 27, "bc_ctx_fold": 28, "bc_dup_halves": 29}
 OP_SIGNAL, OP_WAIT = 20, 21
 CHAIN_IN, CHAIN_MID, CHAIN_OUT, CHAIN_OUT_FF, CHAIN_OUT_TAIL, CHAIN_MIDX, CHAIN_OUT_FFP = 0, 1, 2, 3, 4, 5, 6
 GN_TOT_WORDS = 6                      # 64-bit words per (image, channel) of a GroupNorm statistics table (include/blobctrl_hip.h)

@@ -309,7 +309,37 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, long l
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = z;
 }
 
+// bc_dup_halves: up to six buffers [2][bytes_k]; the first half of each is copied over its second half (16-byte accesses)
+struct DupArgs { uint4* p[6]; long long n16[6]; };
+__global__ __launch_bounds__(256) void dup_halves_kernel(const DupArgs a) {
+    uint4* __restrict__ p = a.p[blockIdx.y];
+    const long long n = a.n16[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[n + i] = p[i];
+}
+
 }  // namespace
+
+extern "C" int bc_dup_halves(void* p0, long long b0, void* p1, long long b1, void* p2, long long b2, void* p3, long long b3, void* p4, long long b4,
+                             void* p5, long long b5, bc_stream stream_) {
+    void* ps[6] = {p0, p1, p2, p3, p4, p5};
+    const long long bs[6] = {b0, b1, b2, b3, b4, b5};
+    DupArgs a;
+    int n = 0;
+    long long most = 0;
+    for (int k = 0; k < 6; ++k) {
+        if (!ps[k] || bs[k] <= 0) continue;
+        BC_CHECK_ARG(bs[k] % 16 == 0 && ((uintptr_t)ps[k] % 16) == 0, "bc_dup_halves: buffer %d needs a 16-byte aligned pointer and half size", k);
+        a.p[n] = reinterpret_cast<uint4*>(ps[k]);
+        a.n16[n] = bs[k] / 16;
+        most = std::max(most, a.n16[n]);
+        ++n;
+    }
+    BC_CHECK_ARG(n > 0, "bc_dup_halves: nothing to copy");
+    const int blocks = (int)std::min<long long>((most + 255) / 256, 1024);
+    hipLaunchKernelGGL(dup_halves_kernel, dim3(blocks, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
+    BC_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int bc_gn_stats(const bc_half* x, int C, int B, int HW, unsigned long long* tot, bc_stream stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

@@ -86,6 +86,7 @@ int launch_rec(BcPlan* pl, Rec& r, hipStream_t* streams, int nstreams) {
             return bc_gn_apply_fused(CP(unsigned long long, 0), I(1), CP(unsigned long long, 2), I(3), CP(bc_half, 4), CP(bc_half, 5), I(6),
                                      I(7), I(8), F(9), CP(float, 10), CP(float, 11), I(12), MP(bc_half, 13), s);
         case BC_OP_MEMSET_ZERO: return bc_memset_zero(P(0), L(1), s);
+        case BC_OP_DUP_HALVES: return bc_dup_halves(P(0), L(1), P(2), L(3), P(4), L(5), P(6), L(7), P(8), L(9), P(10), L(11), s);
         case BC_OP_ROWCHAIN_MIDX:
             return bc_rowchain_midx(I(0), I(1), I(2), CP(bc_half, 3), CP(bc_half, 4), CP(bc_half, 5), CP(float, 6), CP(bc_half, 7), I(8), F(9),
                                     MP(bc_half, 10), MP(bc_half, 11), F(12), s);

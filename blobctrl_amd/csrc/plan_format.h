@@ -52,6 +52,7 @@ inline const char* op_signature(int op) {
         case BC_OP_ROWCHAIN_PACK_KV: return "pipiiiip";
         case BC_OP_ROWCHAIN_SUM: return "iiipippp";
         case BC_OP_CTX_FOLD: return "pipiiiiifppppppp";
+        case BC_OP_DUP_HALVES: return "plplplplplpl";
         default: return nullptr;
     }
 }

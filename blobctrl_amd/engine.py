@@ -166,8 +166,8 @@ class TrunkPlan:
         return Act(out, x.C + C2, x.H, x.W)
 
     # ------------------------------------------------------------------------------------------- blocks
-    def resnet(self, p, x: Act, skip: Optional[Act], Cout, r2=None):
-        """resnet.py:320-373 on (x [, skip]) = torch.cat([x, skip], 1)."""
+    def resnet(self, p, x: Act, skip: Optional[Act], Cout, r2=None, out=None):
+        """resnet.py:320-373 on (x [, skip]) = torch.cat([x, skip], 1).  `out`: the caller's output buffer."""
         pw = self.pw
         Cin = x.C + (skip.C if skip is not None else 0)
         off, n = pw.temb_slices[p]
@@ -190,7 +190,7 @@ class TrunkPlan:
         else:
             assert skip is None and Cin == Cout
             sc = x
-        return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2)
+        return self.gn_conv(h, None, p + "norm2", 1e-5, p + "conv2", Cout, R=sc, r2=r2, **({"out": out} if out is not None else {}))
 
     def rowchain_ok(self, Cc, M, HW, p=""):
         """The fused row-chain kernels (csrc/rowchain.hip) take this block: 320 or 640 channels, 64-row blocks inside one image, and
@@ -234,11 +234,15 @@ class TrunkPlan:
             return False
         return not self.cfg.is_blobnet or bool(os.environ.get("BC_FFP_BLOB"))
 
-    def transformer_rowchain(self, p, x: Act, r2=None, zero=None):
+    def transformer_rowchain(self, p, x: Act, r2=None, zero=None, fan_out=None):
         """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
         LayerNorm -> q | k | V^T ; attention ; [to_out + residual -> LayerNorm -> attn2.to_q ; cross-attention ;] to_out + residual ->
         LayerNorm -> GEGLU feed-forward -> proj_out + x (+ BlobNet residual) [-> zero-conv].  `zero` = (name, alpha, alpha_dev,
-        alpha_idx, alpha_bstride): BlobNet's zero-conv of the block output, returned as second value."""
+        alpha_idx, alpha_bstride): BlobNet's zero-conv of the block output, returned as second value.
+        `fan_out` = (x_full, extra) - the CFG-invariant prefix (record_forward): self.B is HALF the UNet batch and x lives in the first
+        half of x_full [2 self.B][HW][C]; everything up to the self-attention runs on that half, one bc_dup_halves fans h0, the attention
+        output, x and `extra` (a list of (tensor, bytes of one half)) out to the image pairs, and the block goes on at 2 self.B from
+        the launch that first sees the prompt (attn2: attention.py:504-510)."""
         from .weights import pack_rowchain
         rec, pw, B = self.rec, self.pw, self.B
         Cc, HW = x.C, x.H * x.W
@@ -263,12 +267,20 @@ class TrunkPlan:
         vt = rec.zeros(B, Cc, ldvt)
         # (the block's head on the column-tiled gemm_wreg projections - all CUs - instead of one 64-row workgroup per row block was
         #  measured at the UNet's 640-channel level: 9.25 vs 9.13 ms per step, slower - the 64-CU launch leaves the chip to BlobNet)
-        h0, qk = rec.empty(M, Cc), rec.empty(M, 2 * Cc)
+        mult = 2 if fan_out is not None else 1
+        h0_all, a_all = rec.empty(mult * M, Cc), rec.empty(mult * M, Cc)
+        h0, qk = h0_all[:M], rec.empty(M, 2 * Cc)
         w, v = packed(_lib.CHAIN_IN)
         rec.rowchain(_lib.CHAIN_IN, Cc, M, HW, x.t, w, v, h0, out1=qk, out2=vt, ldvt=ldvt, **gnkw)
-        a = rec.empty(M, Cc)
+        a = a_all[:M]
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc, Cc * ldvt, HW * Cc,
                       scale, q_off=0, k_off=Cc)
+        if fan_out is not None:
+            x_full, extra = fan_out
+            half = M * Cc * 2
+            rec.dup_halves([(h0_all, half), (a_all, half), (x_full, half)] + list(extra))
+            B, M = 2 * B, 2 * M
+            h0, a, x = h0_all, a_all, Act(x_full, Cc, x.H, x.W)
         h = h0
         if pw.has_cross:
             h1 = rec.empty(M, Cc)
@@ -532,19 +544,34 @@ class TrunkPlan:
         self.tproj_table = (t_idx, B * pw.temb_total)
 
     # ------------------------------------------------------------------------------------------- forward
-    def conv_in_dense(self, x_in: torch.Tensor, wkey, r2=None):
+    def conv_in_dense(self, x_in: torch.Tensor, wkey, r2=None, out=None, gn_tot_out=None):
         """conv_in on the im2col operand [B][H*W][128] (round 3): K = 72 is outside the LDS-DMA GEMM's fast path (the register-staged
         kernel took 41 us per launch for 2.4 GFLOP); as a dense K = 128 GEMM it is one of the ordinary 1x1-convolution launches."""
         pw, H, W = self.pw, self.H, self.W
         Cout = self.cfg.block_out_channels[0]
         M = self.B * H * W
-        out = self.rec.empty(self.B, H * W, Cout)
+        if out is None:
+            out = self.rec.empty(self.B, H * W, Cout)
         self.rec.gemm(A=x_in, W=pw.h[wkey], M=M, N=Cout, K=128, out=out, bias=pw.f["conv_in.bias"], rows_per_batch=H * W, kind="conv_in",
-                      want_gn=True, **self._r2(r2, H, W))
+                      want_gn=True, gn_tot_out=gn_tot_out, **self._r2(r2, H, W))
         return Act(out, Cout, H, W)
 
+    def cfg_prefix_ok(self, cfg_pairs, im2col):
+        """The CFG-invariant prefix of the UNet runs once per image PAIR (round 6).  Both classifier-free-guidance images enter the UNet
+        identical (pipe:1031 `torch.cat([latents] * 2)`, the same BlobNet residuals, the same timestep: pipe:1071-1076) and the prompt first
+        enters at attn2 of down_blocks.0.attentions.0 (attention.py:504-510), so conv_in, the residual add, down_blocks.0.resnets.0 and
+        that block's GroupNorm -> proj_in -> norm1 -> attn1 are the same arithmetic on the same numbers for images b and b + B: 125 of the
+        step's 5578 GFLOP at 512^2, half of one 8192-token self-attention among them.  They are recorded at batch B; one bc_dup_halves
+        launch fans the four tensors that later launches read per image out to the pairs.  Results are bit-identical to the plain plan
+        (every kernel on the path is per-image deterministic: tests/test_fullsize_gpu.py).  BC_NO_CFG_PREFIX=1: the plain plan."""
+        cfg = self.cfg
+        if not cfg_pairs or cfg.is_blobnet or self.B % 2 or not im2col or os.environ.get("BC_NO_CFG_PREFIX") or len(cfg.block_out_channels) < 2:
+            return False
+        Cc, HW = cfg.block_out_channels[0], self.H * self.W
+        return self.pw.has_cross and Cc in (320, 640) and self.rowchain_ok(Cc, (self.B // 2) * HW, HW, "down_blocks.0.attentions.0.")
+
     def record_forward(self, x_in: torch.Tensor, residuals: Optional[Residuals] = None, zero_scale=None,
-                       signal_residuals: bool = False, eps_out: Optional[torch.Tensor] = None, im2col: bool = False):
+                       signal_residuals: bool = False, eps_out: Optional[torch.Tensor] = None, im2col: bool = False, cfg_pairs: bool = False):
         """x_in: [B, H*W, pad8(in_channels)] fp16, or with `im2col` the [B, H*W, 128] operand of bc_assemble_input_im2col.  UNet: returns eps fp32 [B, H*W, out_channels].
         BlobNet: returns Residuals (zero-conv outputs times `zero_scale` = (alpha, alpha_dev, alpha_idx[, alpha_bstride]);
         alpha_bstride = B selects per-image scales alpha_dev[step * B + image] for a batch of independent requests)."""
@@ -602,19 +629,46 @@ class TrunkPlan:
             conv_in = lambda r2=None: self.conv_in_dense(x_in, wkey, r2)
         else:
             conv_in = lambda r2=None: self.conv3x3(x, conv_in_name, boc[0], r2=r2, kind="conv_in")
-        if residuals is not None and W == H:
-            # square canvas: `sample = sample + r` rebinds, skip #0 stays WITHOUT the residual (unet_2d_condition.py:1213-1217)
-            skip0 = conv_in()
-            h = conv_in(pop(res_d))
+        prefix = self.cfg_prefix_ok(cfg_pairs, im2col)       # `cfg_pairs`: images b and b + B / 2 of x_in are identical (the CFG pair)
+        if prefix:
+            # ---- the CFG-invariant prefix at HALF the batch (cfg_prefix_ok): conv_in, residual add, down_blocks.0.resnets.0 and the head of
+            # down_blocks.0.attentions.0 up to its self-attention; full-size buffers whose first half the half-batch launches write
+            Bf, Bh, rec = self.B, self.B // 2, self.rec
+            skip_full, hres_full = rec.empty(Bf, H * W, boc[0]), rec.empty(Bf, H * W, boc[0])
+            skip_tot = rec.new_tot(Bf, boc[0])               # skip #0's GroupNorm statistics (read by up_blocks.3.resnets.2 per image)
+            self.B = Bh
+            try:
+                xh = x_in[:Bh]
+                if residuals is not None and W == H:           # (the two canvas cases as below)
+                    skip0 = self.conv_in_dense(xh, wkey, None, out=skip_full[:Bh], gn_tot_out=skip_tot[:Bh])
+                    h = self.conv_in_dense(xh, wkey, pop(res_d))
+                else:
+                    h = self.conv_in_dense(xh, wkey, pop(res_d), out=skip_full[:Bh], gn_tot_out=skip_tot[:Bh])
+                r = pop(res_d)
+                h = self.resnet("down_blocks.0.resnets.0.", h, None, boc[0], r2=None, out=hres_full[:Bh])
+                half = Bh * H * W * boc[0] * 2
+                h, _ = self.transformer_rowchain("down_blocks.0.attentions.0.", h, r2=r, zero=None,
+                                                 fan_out=(hres_full, [(skip_full, half), (skip_tot, skip_tot[:Bh].numel() * 8)]))
+            finally:
+                self.B = Bf
+            rec.tots[skip_full.data_ptr()] = skip_tot
+            skips = [Act(skip_full, boc[0], H, W), h]
         else:
-            # wide canvas: in-place slice add aliases the tuple element => skip #0 carries the residual (:1219)
-            h = conv_in(pop(res_d))
-            skip0 = h
-        skips = [skip0]
-        feats_d.append(h)
+            if residuals is not None and W == H:
+                # square canvas: `sample = sample + r` rebinds, skip #0 stays WITHOUT the residual (unet_2d_condition.py:1213-1217)
+                skip0 = conv_in()
+                h = conv_in(pop(res_d))
+            else:
+                # wide canvas: in-place slice add aliases the tuple element => skip #0 carries the residual (:1219)
+                h = conv_in(pop(res_d))
+                skip0 = h
+            skips = [skip0]
+            feats_d.append(h)
         for i in range(nb):
             has_attn = i < nb - 1
             for j in range(cfg.layers_per_block):
+                if prefix and i == 0 and j == 0:
+                    continue                                   # (recorded above)
                 r = pop(res_d)
                 h = self.resnet(f"down_blocks.{i}.resnets.{j}.", h, None, boc[i], r2=None if has_attn else r)
                 pre = None

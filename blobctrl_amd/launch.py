@@ -339,6 +339,19 @@ class Recorder:
         ch[1] += (n + 31) // 32 * 32        # (256-byte aligned tables)
         return view
 
+    def dup_halves(self, items):
+        """bc_dup_halves: `items` = up to six (tensor laid out [2][...], bytes of one half); the first half of each is copied over
+        its second half in one launch (the CFG-invariant prefix of the UNet fanned out to the image pair, engine.record_forward)."""
+        assert 0 < len(items) <= 6
+        args = []
+        for t, nbytes in items:
+            assert nbytes % 16 == 0 and t.numel() * t.element_size() >= 2 * nbytes
+            args += [t, nbytes]
+        args += [None, 0] * (6 - len(items))
+        self.keep.append(tuple(t for t, _ in items))
+        total = sum(b for _, b in items)
+        self._op("bc_dup_halves", tuple(args), "dup_halves", variant="dup_halves_kernel", shape=("dup_halves", total), bytes_=2 * total)
+
     # ------------------------------------------------------------------ GEMM family
     def plan_gemm(self, M, N, K, fast, mode, tile_cfg=0, splitk=None):
         """(tile_cfg, splitk, bm, bn) for a GEMM: tuning table first, then the library's cost model (bc_gemm_plan)."""
@@ -360,7 +373,7 @@ class Recorder:
              alpha=1.0, alpha_dev=None, alpha_idx=None, alpha_bstride=0, R=None, ldr=0, R2=None, ldr2=0, r2_xmin=0, r2_bmod=1,
              out_w=0, splitk=None, kind="gemm", a_offset=0, w_offset=0, out_offset=0, want_gn=False, tile_cfg=0, ldw=None,
              a_affine=None, a_act=_lib.ACT_NONE, a_gn=None, ln_colsum=None, ln_eps=1e-5, C_t=None, ldc_t=0, n_t0=0,
-             w_bstride=0, vec_bstride=0, sm_group=0, sm_valid=0, sm_keep=0):
+             w_bstride=0, vec_bstride=0, sm_group=0, sm_valid=0, sm_keep=0, gn_tot_out=None):
         """Record one bc_gemm.  `conv` = dict(Cin, Hin, Win, Hv, Wv, Hout, Wout, stride) for the 3x3 gather mode.
         Pointer offsets are in ELEMENTS of the respective tensor."""
         n_out = N // 2 if act == _lib.ACT_GEGLU else (N // sm_group * sm_keep if sm_group else N)
@@ -490,7 +503,9 @@ class Recorder:
             slab_rows = bm if sk == 1 else 32            # (a workgroup's rows must lie inside one image)
             if vec and (fast or sk > 1) and N % 4 == 0 and rpb % slab_rows == 0 and M % rpb == 0 and \
                     not os.environ.get("BC_GEMM_TILE"):
-                part = self.new_tot(M // rpb, n_out)
+                # (gn_tot_out: the caller's table - the first half of a [2 B'] table that bc_dup_halves fans out afterwards)
+                part = gn_tot_out if gn_tot_out is not None else self.new_tot(M // rpb, n_out)
+                assert tuple(part.shape[:2]) == (M // rpb, n_out)
                 g.gn_tot = part.data_ptr()
                 self.tots[g.C] = part
 

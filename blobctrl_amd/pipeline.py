@@ -181,7 +181,7 @@ class BlobCtrlEngine:
                 rec.wait(joined)
                 eps = P.eps_all
             else:
-                eps = plan.record_forward(P.unet_in, residuals, im2col=P.unet_im2col)
+                eps = plan.record_forward(P.unet_in, residuals, im2col=P.unet_im2col, cfg_pairs=True)   # (images b and b + B: the CFG pair)
             P.eps = eps
             rec.call("bc_cfg_scheduler_step", eps, P.latents, P.coef, P.step_idx, P.hist, -1.0, B, h, w, P.eps_guided, 1,
                      kind="cfg_step")

@@ -210,6 +210,13 @@ int bc_gn_apply_fused(const unsigned long long* tot1, int C1, const unsigned lon
 /* Zero `bytes` bytes at `ptr` (both multiples of 16) with a kernel on the caller's stream (a kernel node when captured): zeroes the
  * statistics totals at the head of a segment. */
 int bc_memset_zero(void* ptr, long long bytes, bc_stream stream);
+/* Up to six buffers laid out [2][bytes_k] (16-byte aligned, bytes_k % 16 == 0; null / 0 = unused slot): the first half of each is
+ * copied over its second half, one launch.  Round 6: the CFG-invariant prefix of the UNet (pipe:1031 `torch.cat([latents] * 2)`: both
+ * classifier-free-guidance images enter the UNet identical, the prompt first enters at attn2 of down_blocks.0.attentions.0,
+ * attention.py:504-510) is computed for ONE image per pair; this op fans its four activations (skip #0, the ResBlock output, the
+ * Transformer2D's h0 and self-attention output) and skip #0's GroupNorm statistics totals out to the pair. */
+int bc_dup_halves(void* p0, long long bytes0, void* p1, long long bytes1, void* p2, long long bytes2, void* p3, long long bytes3,
+                  void* p4, long long bytes4, void* p5, long long bytes5, bc_stream stream);
 
 /* Row softmax in place on fp16 [rows][cols] (fp32 maths): the single-head, head_dim-512 attention of the VAE mid block is run
  * as GEMM (QK^T) -> softmax -> GEMM (PV)  (attention_processor.py:2216 with heads = 1). */
@@ -424,7 +431,7 @@ enum { BC_OP_GEMM = 0, BC_OP_GN_STATS = 1, BC_OP_GN_FINALIZE = 2, BC_OP_GN_APPLY
        BC_OP_TIMESTEP_EMBEDDING_TABLE = 10, BC_OP_CFG_SCHEDULER_STEP = 11, BC_OP_EMBED_TOKENS = 12, BC_OP_SOFTMAX_ROWS = 13,
        BC_OP_PATCHIFY = 14, BC_OP_ADD_CLS_POS = 15, BC_OP_SILU = 16, BC_OP_NCHW_TO_NHWC_F16 = 17, BC_OP_NHWC_TO_NCHW = 18,
        BC_OP_GAUSSIAN_SAMPLE = 19, BC_OP_SIGNAL = 20 /* arg: event id */, BC_OP_WAIT = 21 /* arg: event id */, BC_OP_ROWCHAIN = 22, BC_OP_ASSEMBLE_IM2COL = 23,
-       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_ROWCHAIN_SUM = 27, BC_OP_CTX_FOLD = 28, BC_OP_COUNT = 29 };
+       BC_OP_MEMSET_ZERO = 24, BC_OP_ROWCHAIN_MIDX = 25, BC_OP_ROWCHAIN_PACK_KV = 26, BC_OP_ROWCHAIN_SUM = 27, BC_OP_CTX_FOLD = 28, BC_OP_DUP_HALVES = 29, BC_OP_COUNT = 30 };
 typedef struct BcPlanBuffer {
     const char* name;        /* "" for anonymous workspace; named buffers are found again with bc_plan_buffer */
     const void* address;     /* the address the launch records were built against */

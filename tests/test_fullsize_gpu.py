@@ -76,3 +76,44 @@ def test_full_size_two_step_loop_vs_oracle(full):
     err = np.abs(out - ref).max() / np.abs(ref).max()
     print(f"full-size 2-step loop: final latents max-abs/scale {err:.3e}, PSNR {psnr(out, ref):.1f} dB")
     assert err < 1e-2 and psnr(out, ref) > 40.0
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_cfg_invariant_prefix_equals_the_plain_plan(full, batch, monkeypatch):
+    """Round 6: conv_in, the residual add, down_blocks.0.resnets.0 and the head of down_blocks.0.attentions.0 up to its self-attention
+    run once per CFG image pair (engine.cfg_prefix_ok; the two images are identical until the prompt enters at attn2).  One denoise step
+    through the plan with and without it: the UNet's eps of EVERY image agrees to fp16 rounding (measured 2e-3 of scale; not bit for bit:
+    at half the batch the planner picks other tiles for conv_in, whose workgroups round their fp32 GroupNorm partial sums over other row
+    counts - the last bits of the statistics differ), the plan really is the shorter one (123.5 GFLOP per image pair and step less, one
+    bc_dup_halves launch), and the loop fixtures of the REAL reference (test_fullsize_loop_gpu.py) run through the prefix by default."""
+    import bench
+    from blobctrl_amd.pipeline import BlobCtrlEngine
+    from blobctrl_amd.splat import splat_features
+    h = w = 64
+    inp = bench.synth_inputs(h, w, batch=batch)
+    score = splat_features(**inp["blob"], score_size=(h, w), return_d_score=True, device="cuda:0")
+    eps, lat, flops, kinds = [], [], [], []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("BC_NO_CFG_PREFIX", "1")
+        pipe = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
+        out = pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=1, guidance_scale=7.5, latents=inp["latents"])
+        P = pipe.plan_for(batch, h, w, 77, 768, 1)
+        torch.cuda.synchronize()
+        eps.append(P.eps_active.float().cpu().view(2 * batch, -1))
+        lat.append(out.float().cpu())
+        flops.append((P.step_active.flops, P.step_inactive.flops))
+        kinds.append(P.step_active.kinds.get("dup_halves", 0))
+        del pipe
+    assert torch.isfinite(eps[0]).all() and kinds == [1, 0]
+    worst = 0.0
+    for img in range(2 * batch):
+        a, b = eps[0][img].numpy(), eps[1][img].numpy()
+        worst = max(worst, np.abs(a - b).max() / np.abs(b).max())
+        assert psnr(a, b) > 55.0
+    err_lat = (lat[0] - lat[1]).abs().max().item() / lat[1].abs().max().item()
+    saved = (flops[1][0] - flops[0][0]) / 1e9 / batch
+    print(f"CFG-invariant prefix, batch {batch}: eps max-abs/scale vs the plain plan {worst:.3e}, latents after the step {err_lat:.3e}; "
+          f"{saved:.1f} GFLOP per image pair and step less ({flops[1][0] / 1e12:.3f} -> {flops[0][0] / 1e12:.3f} TFLOP per active step)")
+    assert worst < 5e-3 and err_lat < 5e-3
+    assert 110.0 < saved < 140.0 and flops[1][1] - flops[0][1] == flops[1][0] - flops[0][0]

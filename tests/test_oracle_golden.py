@@ -185,3 +185,44 @@ def test_time_embedding_vs_reference_fixture(golden_dir):
     cfg = nets.NetConfig(in_channels=4)
     for i, ti in enumerate(BLOCK_TIMESTEPS):
         np.testing.assert_allclose(nets.time_embed(sd, ti, 1, cfg).numpy()[0], z["time_emb"][i], rtol=1e-4, atol=1e-4)
+
+
+def test_cfg_pair_is_bit_equal_until_the_first_cross_attention():
+    """Property behind the engine's CFG-invariant prefix (blobctrl_amd/engine.py cfg_prefix_ok): the reference feeds the UNet
+    `torch.cat([latents] * 2)` (pipeline_blobnet.py:1031) with the same timestep and the same BlobNet residuals for both halves, and
+    the prompt first enters at attn2 of down_blocks.0.attentions.0 (attention.py:504-510).  In the oracle's statement of those layers the
+    two halves are therefore bit-equal up to and including attn1's residual add, norm2 and attn2.to_q - and differ right behind attn2."""
+    import torch.nn.functional as F
+    from oracle import nets
+    from tests.common import TINY, g, tiny_cfgs, tiny_weights
+    usd, _ = tiny_weights()
+    ucfg, _ = tiny_cfgs()
+    B, h, w = 2, 8, 16
+    lat = g(41, B, ucfg.in_channels, h, w)
+    x = torch.cat([lat, lat], 0)
+    ctx = g(42, 2 * B, 7, TINY["ctx"])                                   # different prompts for every image
+    add = g(43, B, ucfg.block_out_channels[0], h, h).repeat(2, 1, 1, 1)
+    emb = nets.time_embed(usd, torch.tensor(500), 2 * B, ucfg)
+    hh = F.conv2d(x, usd["conv_in.weight"], usd["conv_in.bias"], padding=1)
+    hh = nets.add_right(hh, add)
+    hh = nets.resnet_block(usd, "down_blocks.0.resnets.0.", hh, emb, ucfg.norm_num_groups)
+    p = "down_blocks.0.attentions.0."
+    C = hh.shape[1]
+    t = F.group_norm(hh, ucfg.norm_num_groups, usd[p + "norm.weight"], usd[p + "norm.bias"], 1e-6)
+    t = F.conv2d(t, usd[p + "proj_in.weight"], usd[p + "proj_in.bias"]).permute(0, 2, 3, 1).reshape(2 * B, h * w, C)
+    bp = p + "transformer_blocks.0."
+    n = F.layer_norm(t, (C,), usd[bp + "norm1.weight"], usd[bp + "norm1.bias"], 1e-5)
+    t1 = nets.attention(usd, bp + "attn1.", n, None, ucfg.num_heads) + t
+    n2 = F.layer_norm(t1, (C,), usd[bp + "norm2.weight"], usd[bp + "norm2.bias"], 1e-5)
+    q = F.linear(n2, usd[bp + "attn2.to_q.weight"])
+    for name, v in (("ResBlock output", hh), ("attn1 + residual", t1), ("attn2.to_q", q)):
+        assert torch.equal(v[:B], v[B:]), f"{name}: the CFG halves differ"
+    t2 = nets.attention(usd, bp + "attn2.", n2, ctx, ucfg.num_heads) + t1
+    assert not torch.equal(t2[:B], t2[B:])
+    # and the composition above IS the oracle's block: transformer_2d on the same input gives the same bits as going on from t2
+    n3 = F.layer_norm(t2, (C,), usd[bp + "norm3.weight"], usd[bp + "norm3.bias"], 1e-5)
+    hg = F.linear(n3, usd[bp + "ff.net.0.proj.weight"], usd[bp + "ff.net.0.proj.bias"])
+    val, gate = hg.chunk(2, dim=-1)
+    t3 = F.linear(val * F.gelu(gate), usd[bp + "ff.net.2.weight"], usd[bp + "ff.net.2.bias"]) + t2
+    out = F.conv2d(t3.reshape(2 * B, h, w, C).permute(0, 3, 1, 2).contiguous(), usd[p + "proj_out.weight"], usd[p + "proj_out.bias"]) + hh
+    assert torch.equal(out, nets.transformer_2d(usd, p, hh, ctx, ucfg.num_heads, ucfg.norm_num_groups))
