@@ -264,6 +264,15 @@ def other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, denoise_steps, scheduler):
         assert torch.isfinite(o).all()
         return (time.perf_counter() - t0) / edits
 
+    # (the other scheduler FIRST: behind the C3 / C5 blocks - five seconds of full-chip load - the same two edits read up to 10 % slower)
+    other = "unipc" if scheduler == "ddim" else "ddim"
+    eng = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=other)
+    i1 = synth_inputs(64, 64)
+    d1 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in i1.items()}
+    s1 = splat_features(**i1["blob"], score_size=(64, 64), return_d_score=True, device=str(dev))
+    dt = timed(lambda: eng(d1["prompt"], d1["fg"], d1["bg"], s1, d1["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
+                           latents=d1["latents"], blobnet_conditioning_scale=1.0))
+    out[f"{other}_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
     rb = make_request_batch(list(range(8)), 64, 64, dev)
     dt = timed(lambda: pipe(rb["prompt"], rb["fg"], rb["bg"], rb["score"], rb["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
                             latents=rb["latents"], blobnet_conditioning_scale=rb["strength"]))
@@ -281,17 +290,16 @@ def other_configs(pipe, pw_u, pw_b, ucfg, bcfg, dev, denoise_steps, scheduler):
     out["c5_768_batch4_images_per_s"] = round(4 / dt, 4)
     fl5 = pipe.plan_for(4, h5, h5, 77, 768, denoise_steps).step_active.flops
     out["c5_frac_of_peak"] = round(fl5 * denoise_steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)
-    other = "unipc" if scheduler == "ddim" else "ddim"
-    eng = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=other)
-    i1 = synth_inputs(64, 64)
-    d1 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in i1.items()}
-    s1 = splat_features(**i1["blob"], score_size=(64, 64), return_d_score=True, device=str(dev))
-    dt = timed(lambda: eng(d1["prompt"], d1["fg"], d1["bg"], s1, d1["dino"], num_inference_steps=denoise_steps, guidance_scale=7.5,
-                           latents=d1["latents"], blobnet_conditioning_scale=1.0))
-    out[f"{other}_ms_per_step"] = round(dt / denoise_steps * 1e3, 3)
     out["note"] = (f"1 warm-up + 2 timed edits each, {denoise_steps} steps, guidance window [0,1], CFG 7.5; c3 / c5 with the "
                    f"{scheduler.upper()} scheduler of the headline run; ms per denoise step of the WHOLE batch")
     return out
+
+
+def plan_variants(plan):
+    """Launches per kernel instantiation (rocprofv3 names) of one BlobNet-active step of the plan."""
+    import collections
+    c = collections.Counter((m.get("rocprof") or m.get("variant") or m["kind"]) for m in plan.step_active.meta if m["kind"] not in ("event_record", "event_wait"))
+    return dict(sorted(c.items(), key=lambda kv: -kv[1]))
 
 
 def metric_name(args):
@@ -338,11 +346,13 @@ def _profile_doc(pattern, res, batch):
     for fn in files:
         with open(fn) as f:
             docs.append((fn, json.load(f)))
+    # (round 6: summaries exist for several workloads - r6_c3_* batch 8, r6_c5_* 768^2 batch 4, r6_b2_* batch 2; a summary states its own)
+    docs = [fd for fd in docs if (fd[1].get("res", 512), fd[1].get("batch", 1)) == (res, batch)]
+    if not docs:
+        return None, f"no profiles/*{pattern} measured at {res}x{res} batch {batch}"
     match = [fd for fd in docs if fd[1].get("csrc_sha") == csrc_sha()]
     fn, doc = (match or docs)[-1]                      # the summary measured on THESE kernel sources, else the newest round's (refused below)
     name = os.path.relpath(fn, REPO)
-    if (res, batch) != (512, 1):
-        return None, f"{name} was measured at 512x512 batch 1, this run is {res}x{res} batch {batch}"
     if doc.get("csrc_sha") != csrc_sha():
         return None, f"{name} was measured on kernel sources {doc.get('csrc_sha', '(unrecorded)')}, this run is {csrc_sha()}"
     return (name, doc), None
@@ -474,6 +484,64 @@ def roofline(pipe, plan, res=512, batch=1):
                 avg_launch_us=round(a["ms"] * 1e3 / a["n"], 2), flops_per_launch=a["flops"] / a["n"],
                 step_ms_event_sum=round(total_ms, 3), event_overhead_us=round(overhead_ms * 1e3, 2)), \
         dict(by_kernel=table, top_shapes=detail)
+
+
+# Reference readings of the two calibration probes (the box profiles/r6_bench_final.json was taken on): a box's speed index is the mean
+# of its two ratios to these
+CAL_REF = {"gemm_8192_tflops": 1263.0, "attn_l0_us": 170.0}
+
+
+def box_calibration(dev, seconds=1.0):
+    """the pool's boxes read 8.95-9.47 ms for ONE build (device-to-device clock / power spread), so a driver line
+    from one box cannot resolve a 1 % change.  Two fixed probes, ~1 s each, BEFORE the timed region on the same device: the 8192^3 fp16 GEMM
+    on csrc/gemm256.hip (MFMA-dense, power-limited: tracks the clock the part holds) and the UNet's L0 self-attention shape (2 x 8 heads x 8192^2
+    tokens, D = 40) on csrc/attention.hip (the step's largest single launch).  `speed_index` = mean of (gemm TFLOP/s / reference) and
+    (reference attention us / attention us); `denoise_step_ms_normalised` = the measured step x speed_index - what the reference box would
+    read.  The raw figure stays the headline."""
+    import ctypes as C
+    from blobctrl_amd import _lib
+    from blobctrl_amd.launch import Recorder
+    lib = _lib.load()
+    rec = Recorder(dev)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    n = 8192
+    A = (torch.randn(n, n, generator=gen) * 0.5).half().to(dev)
+    W = (torch.randn(n, n, generator=gen) * 0.02).half().to(dev)
+    seg_g = rec.begin("cal_gemm")
+    rec.gemm(A=A, W=W, M=n, N=n, K=n, out=rec.empty(n, n), tile_cfg=_lib.TILE_G256)
+    B, heads, d, N = 2, 8, 40, 8192
+    qk = (torch.randn(B * N, 2 * heads * d, generator=gen)).half().to(dev)
+    vt = (torch.randn(B, heads * d, N, generator=gen)).half().to(dev)
+    seg_a = rec.begin("cal_attn")
+    C_ = heads * d
+    rec.attention(qk, qk, vt, rec.empty(B * N, C_), B, heads, d, N, N, 2 * C_, 2 * C_, N, C_, N * 2 * C_, N * 2 * C_, C_ * N, N * C_, d ** -0.5, q_off=0, k_off=C_)
+    s = torch.cuda.current_stream(dev).cuda_stream
+
+    def time_seg(seg, budget):
+        for _ in range(3):
+            seg.run(s)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps, spent, best = 0, 0.0, []
+        while spent < budget:
+            e0.record()
+            for _ in range(10):
+                seg.run(s)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / 10
+            best.append(ms)
+            spent += ms * 10e-3
+            reps += 10
+        best.sort()
+        return best[len(best) // 2], reps
+    g_ms, g_reps = time_seg(seg_g, seconds)
+    a_ms, a_reps = time_seg(seg_a, seconds)
+    rec.close()
+    out = {"gemm_8192_tflops": round(2.0 * n ** 3 / (g_ms * 1e-3) / 1e12, 1), "attn_l0_us": round(a_ms * 1e3, 1),
+           "reference": CAL_REF, "launches": [g_reps, a_reps]}
+    out["speed_index"] = round(0.5 * (out["gemm_8192_tflops"] / CAL_REF["gemm_8192_tflops"] + CAL_REF["attn_l0_us"] / out["attn_l0_us"]), 4)
+    return out
 
 
 def end_to_end(pw_u, pw_b, ucfg, bcfg, dev, res, denoise_steps, reps=3, batch=1):
@@ -637,6 +705,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (splat + DINOv2 + CLIP + VAE + loop) timing")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C5 / other-scheduler timings (`configs` block of the line)")
     ap.add_argument("--table", action="store_true", help="print the per-kernel event-time table to stderr")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the ~2 s box calibration probes in front of the timed region")
     ap.add_argument("--requests", type=int, default=0,
                     help="BASELINE configs[3]: this many independent edit requests in total, sharded round-robin over the ranks "
                          "(dist.shard_requests) and run `--batch` at a time as per-request batches; 0 = `--steps` edits per rank")
@@ -680,6 +749,12 @@ def main():
     pw_u = bdist.broadcast_packed(build_unet, dev)          # rank 0 packs, RCCL broadcast over xGMI to the others
     pw_b = bdist.broadcast_packed(build_blob, dev)
     t_weights = time.perf_counter() - t0
+    cal = None
+    if rank == 0 and not args.no_calibration:
+        try:
+            cal = box_calibration(dev)
+        except Exception as e:                                                  # noqa: BLE001  (optional detail: must not lose the line)
+            cal = {"error": f"{type(e).__name__}: {e}"[:300]}
     pipe = BlobCtrlEngine(pw_u, pw_b, ucfg, bcfg, device=str(dev), scheduler=args.scheduler)
     inp = synth_inputs(h, w, batch=args.batch)
     inp_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}     # inputs resident in HBM
@@ -772,8 +847,19 @@ def main():
                    "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and tdist.get_backend() == "nccl" else None),
                    "nranks_seen": len(ranks), "weights_sha16": wsha,
                    "ranks": ranks, "distinct_devices": len({(r["local_device"], r["pci_bdf"]) for r in ranks}),
-                   "weights_s": weights_s},
+                   "weights_s": weights_s,
+                   # which plan this line measured: planner options that differ from their defaults (BC_PLAN,
+                   # blobctrl_amd/options.py) and the launches per kernel instantiation of ONE BlobNet-active step
+                   # plan / whole-edit-graph cache traffic of this rank's engine over warm-up + timed region: a --requests run must show ONE
+                   # recorded plan and ONE captured graph however many per-request batches it replayed
+                   "plan_cache": dict(pipe.cache_stats),
+                   "plan": {"options_non_default": plan.options_non_default, "launches_per_active_step": len(plan.step_active.meta),
+                            "variants": plan_variants(plan)}},
     }
+    if cal is not None:
+        line["box_calibration"] = cal
+        if "speed_index" in cal:
+            line["config"]["denoise_step_ms_normalised"] = round(line["config"]["denoise_step_ms"] * cal["speed_index"], 4)
     # The headline numbers above are complete.  Everything below is optional detail: a failure there is recorded in the line, it must
     # not lose the line.
     def guarded(key, fn):

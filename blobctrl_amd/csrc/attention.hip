@@ -397,17 +397,16 @@ int launch_attn(const h16* Q, const h16* K, const h16* Vt, h16* O, int B, int he
         const long long wgs8 = (long long)bc_ceil_div(Nq, QW * 8) * heads * B;
         // Round 3: from ONE 8-wave workgroup per CU (was two): BlobNet's batch-1 self-attention at the 64 x 128 level (256 such
         // workgroups) then stages every K / V^T tile once per 256 queries too - step 10.59 -> 10.49 ms (same box, two rounds).
-        static const long long min8 = getenv("BC_ATTN_MIN8") ? atoll(getenv("BC_ATTN_MIN8")) : 256;
-        if (wgs8 >= min8 && Nkv >= 1024 && !causal && !getenv("BC_ATTN_NO8"))
+        static const bool no8 = getenv("BC_ATTN_NO8") != nullptr;      // (the 4-wave form for every grid: tests run both on one shape)
+        if (wgs8 >= 256 && Nkv >= 1024 && !causal && !no8)
             return launch_attn_nw<D, 8, 1, 4>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
     }
     if constexpr (D == 80) {
         // Round 5: the 8-wave form at the 32 x 64 level too (2048 keys; the UNet's launch = 128 workgroups: a K / V^T tile staged once for 256
         // queries, two waves per SIMD on half the CUs instead of one wave per SIMD on all of them - their MFMA and softmax phases
         // interleave, and the other queue has the other CUs): six interleaved same-box pairs, ms per step, 4-wave vs 8-wave: 9.122 / 9.071,
-        // 9.086 / 9.082, 9.094 / 9.076, 9.084 / 9.068, 8.937 / 8.887, 8.907 / 8.904.  BC_ATTN_80_4=1: the 4-wave form.
-        static const bool w8 = getenv("BC_ATTN_80_4") == nullptr;
-        if (w8 && Nkv >= 1024 && !causal && Nq % (QW * 8) == 0)
+        // 9.086 / 9.082, 9.094 / 9.076, 9.084 / 9.068, 8.937 / 8.887, 8.907 / 8.904.
+        if (Nkv >= 1024 && !causal && Nq % (QW * 8) == 0)
             return launch_attn_nw<D, 8, 1>(Q, K, Vt, O, B, heads, Nq, Nkv, ldq, ldk, ldvt, ldo, qbs, kbs, vbs, obs, scale, causal, stream);
     }
     if constexpr (D <= 40) {

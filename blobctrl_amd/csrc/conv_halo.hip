@@ -494,8 +494,15 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;
+#ifdef BC_DIAGNOSTICS
+    // ablation bits of the kernel (1 no weight DMA, 2 no halo path, 4 no MFMA, 8 no fragment reads, 16 no barriers, 32 no transform, 64 no
+    // raw DMA): WRONG results by design, so they exist only in a library built with -DBC_DIAGNOSTICS (round 6: no switch that can break
+    // correctness is reachable from a production import)
     static const int dbg_env = getenv("BC_HALO_DBG") ? atoi(getenv("BC_HALO_DBG")) : 0;
     g.halo_dbg = dbg_env;
+#else
+    g.halo_dbg = 0;
+#endif
     int sk = std::max(1, std::min(p.splitk, g.halo_nch));
     g.halo_cps = bc_ceil_div(g.halo_nch, sk);
     p.splitk = bc_ceil_div(g.halo_nch, g.halo_cps);
@@ -504,12 +511,14 @@ int bc_conv_halo_launch(GemmArgs& g, hipStream_t stream) {
     const int B = p.M / (p.Hout * p.Wout);
     dim3 grid(p.N / HBN, B * g.halo_tpi, p.splitk);
     {
-        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
-        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
-        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && grid.x >= 4);
+        g.nband = (double)p.N * 9 > (double)p.M && grid.x >= 4;        // (threshold ratio 1: 0.25 and 4 measured worse)
     }
-    // BC_HALO_STAMPS=1 (diagnostics; synchronises the stream after every launch): where a workgroup's cycles go
+    // in-kernel cycle stamps of this (fallback) kernel: -DBC_DIAGNOSTICS builds only (BC_HALO_STAMPS=1; synchronises the stream)
+#ifdef BC_DIAGNOSTICS
     static const bool want_stamps = getenv("BC_HALO_STAMPS") != nullptr;
+#else
+    const bool want_stamps = false;
+#endif
     static unsigned long long* stamp_buf = nullptr;
     const size_t nwg_s = (size_t)grid.x * grid.y * grid.z;
     g.halo_stamps = nullptr;

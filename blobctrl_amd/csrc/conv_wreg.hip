@@ -796,8 +796,7 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     g.halo_tx = p.Wout / TW;
     g.halo_tpi = g.halo_tx * (p.Hout / TH);
     g.halo_nch = p.Cin / 64;
-    static const int fin_slow = getenv("BC_WREG_FIN_SLOW") ? 0x100 : 0;        // diagnostics: the round-4 in-prologue finalize (every wave, three __syncthreads)
-    g.halo_dbg = fin_slow;
+    g.halo_dbg = 0;                                  // (bit 0x100 = the round-4 in-prologue finalize: kept in the kernel for reference, not selectable)
     g.halo_stamps = nullptr;
     int sk = std::max(1, std::min(p.splitk, g.halo_nch));
     g.halo_cps = bc_ceil_div(g.halo_nch, sk);
@@ -815,9 +814,7 @@ int bc_conv_wreg_launch(GemmArgs& g, hipStream_t stream) {
     g.wr_tx = make_fastdiv((unsigned)g.halo_tx);
     g.wr_cpg = make_fastdiv((unsigned)(p.a_tot1 && p.a_groups > 0 ? p.Cin / p.a_groups : 1));
     {
-        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
-        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
-        g.nband = nband_env >= 0 ? nband_env : ((double)p.N * 9 > ratio * (double)p.M && grid.x >= 4);
+        g.nband = (double)p.N * 9 > (double)p.M && grid.x >= 4;        // (threshold ratio 1: 0.25 and 4 measured worse)
     }
     // BC_WREG_STAMPS=1 (diagnostics; synchronises the stream after every launch): where the cycles of a three-tile wave and of a staging wave go
     static const bool want_stamps = getenv("BC_WREG_STAMPS") != nullptr;

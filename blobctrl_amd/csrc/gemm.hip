@@ -570,8 +570,7 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     auto aligned16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     g.vec_epilogue = p.out_mode == BC_OUT_F16 && g.n_out % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                      (!p.R || (p.ldr % 8 == 0 && aligned16(p.R))) && (!p.R2 || (p.ldr2 % 8 == 0 && aligned16(p.R2)));
-    static const bool no_vec_t = getenv("BC_NO_VEC_T") != nullptr;
-    g.vec_transposed = !no_vec_t && p.out_mode == BC_OUT_F16_T && p.rows_per_batch % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
+    g.vec_transposed = p.out_mode == BC_OUT_F16_T && p.rows_per_batch % 8 == 0 && p.ldc % 8 == 0 && aligned16(p.C) &&
                        p.act == BC_ACT_NONE && !p.rowvec && !p.colscale && !p.R && !p.R2;
     if (p.gn_tot) {
         // (a workgroup's rows must belong to one image: its statistics go to that image's totals)

@@ -306,10 +306,8 @@ int launch_fast(const GemmArgs& g_in, hipStream_t stream) {
     dim3 grid(bc_ceil_div(p.N, BN), bc_ceil_div(p.M, BM), p.splitk);
     {
         // operand bytes one split touches: activation rows (a convolution's nine taps re-read the same pixels) vs weights
-        static const int nband_env = getenv("BC_NBAND") ? atoi(getenv("BC_NBAND")) : -1;      // -1 auto, 0 / 1 forced (experiments)
         const double a_bytes = (double)p.M * (CONV ? p.Cin : p.K) / p.splitk, w_bytes = (double)p.N * p.K / p.splitk;
-        static const double ratio = getenv("BC_NBAND_RATIO") ? atof(getenv("BC_NBAND_RATIO")) : 1.0;
-        g.nband = nband_env >= 0 ? nband_env : (w_bytes > ratio * a_bytes && grid.x >= 8);
+        g.nband = w_bytes > a_bytes && grid.x >= 8;              // (threshold ratio 1: 0.25 and 4 measured worse, forced column bands +0.15 ms: DESIGN 3.1)
     }
     dim3 block(64 * WM * WN);
     size_t lds = std::max<size_t>((size_t)NS * (BM + BN) * 128, (size_t)BN * (BM + 4) * 4);   // stages | epilogue tile (| transposed, padded)

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 from .launch import Recorder
+from .options import opt
 from .weights import PackedTrunk, pad8
 
 
@@ -74,7 +75,7 @@ class TrunkPlan:
 
     def halo_ok(self, Cin, C1, Cout, H, W):
         """The LDS-resident input-halo convolution with the fused GroupNorm prologue (conv_halo.hip) can run this layer."""
-        return not os.environ.get("BC_NO_HALO") and bool(self.rec.lib.bc_conv_halo_eligible(Cin, C1, Cout, H, W, H, W, 1))
+        return opt("halo") and bool(self.rec.lib.bc_conv_halo_eligible(Cin, C1, Cout, H, W, H, W, 1))
 
     def conv3x3(self, x: Act, wname, Cout, stride=1, up_to=None, rowvec=None, R=None, r2=None, out_f32=False,
                 kind="conv3x3", out=None, x2: Optional[Act] = None, affine=None, halo=False, tile_cfg=0):
@@ -96,7 +97,7 @@ class TrunkPlan:
         Cin = x.C + (x2.C if x2 is not None else 0)
         wkey = wname + ".weight"
         if halo:
-            wreg = not os.environ.get("BC_NO_WREG")                  # conv_wreg.hip (weights streamed into VGPRs) instead of conv_halo.hip
+            wreg = opt("wreg")                                       # conv_wreg.hip (weights streamed into VGPRs) instead of conv_halo.hip
             kw.update(tile_cfg=_lib.TILE_WREG if wreg else _lib.TILE_HALO, lda=x.C)
             if wreg:
                 wkey = pw.wreg(wname + ".weight")
@@ -108,7 +109,7 @@ class TrunkPlan:
             assert x2 is None and affine is None
             # the exact 2x nearest upsample in front of a plain convolution also runs on conv_wreg.hip (source pixel = halo pixel / 2)
             ups_wreg = up_to is not None and (Hv, Wv) == (2 * x.H, 2 * x.W) and stride == 1 and Cin % 64 == 0 and Cout % 160 == 0 and \
-                Wv % 16 == 0 and Hv % 8 == 0 and not os.environ.get("BC_NO_WREG") and not os.environ.get("BC_NO_WREG_UPS")
+                Wv % 16 == 0 and Hv % 8 == 0 and opt("wreg")
             if ups_wreg:
                 kw.update(tile_cfg=_lib.TILE_WREG, lda=x.C)
                 wkey = pw.wreg(wname + ".weight")
@@ -125,10 +126,10 @@ class TrunkPlan:
         single-source projection with enough tiles to fill the chip, else 0 = the planner's LDS-DMA tiles.  Stand-alone on an MI355X
         (tools/gemm8p_probe.hip, TFLOP/s, gemm_fast's best tile in brackets): [8192 x 10240 x 1280] 903 (673), [8192 x 1280 x 5120]
         957 (571), [8192 x 3840 x 1280] 968, [8192 x 1280 x 1280] 708 (~450; 160 tiles on 256 CUs), [4096 x 1280 x 1280] 392 (80 tiles:
-        stays on the 256 x 128 tiles) - hence the tile-count threshold (BC_G256_MIN_TILES, default 128)."""
-        if os.environ.get("BC_NO_G256") or kw.get("A2") is not None or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
+        stays on the 256 x 128 tiles) - hence the tile-count threshold (BC_PLAN g256_min_tiles, default 128)."""
+        if not opt("g256") or kw.get("A2") is not None or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
             return 0
-        if M % 256 or N % 256 or (M // 256) * (N // 256) < int(os.environ.get("BC_G256_MIN_TILES", "128")):
+        if M % 256 or N % 256 or (M // 256) * (N // 256) < opt("g256_min_tiles"):
             return 0
         want_gn = 1 if kw.get("want_gn") else 0
         ok = self.rec.lib.bc_gemm256_eligible(M, N, K, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, want_gn)
@@ -201,27 +202,27 @@ class TrunkPlan:
         - hence from 64 row blocks upwards.  Exception: BlobNet's UP blocks.  The UNet queue is the step's critical path and BlobNet
         runs 1.1 - 1.6 ms ahead of it by the time it reaches its 640-channel up blocks (tools/critical_path.py), so there the
         32-workgroup form is the better neighbour even though it is the slower kernel: 10.43 -> 10.385 ms (same box, two rounds)."""
-        if os.environ.get("BC_NO_ROWCHAIN") or not self.rec.lib.bc_rowchain_supported(Cc, M, HW):
+        if not opt("rowchain") or not self.rec.lib.bc_rowchain_supported(Cc, M, HW):
             return False
-        min_blocks = {320: 1, 640: int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640", "64"))}[Cc]
+        min_blocks = {320: 1, 640: opt("rowchain_min_blocks_640")}[Cc]
         if Cc == 640 and self.cfg.is_blobnet and p.startswith("up_blocks"):
-            min_blocks = int(os.environ.get("BC_ROWCHAIN_MIN_BLOCKS_640_BLOB_UP", "32"))
+            min_blocks = opt("rowchain_min_blocks_640_blob_up")
         return M // 64 >= min_blocks
 
     def rowchain_ff_split(self, Cc, M):
         """Workgroups per 64-row block for the feed-forward of the row-chain's block end (1 = the one-launch form).  A row block's
         feed-forward is MFMA-bound on ONE CU (640 channels: 120 of the launch's 150 us); with 64 row blocks (UNet, 32 x 64 level) or 32
-        (BlobNet) three quarters of the chip idle meanwhile.  BC_ROWCHAIN_FF_SPLIT_640 / _320 override (must divide 20 / 10 chunks)."""
+        (BlobNet) three quarters of the chip idle meanwhile.  BC_PLAN ff_split_640 / ff_split_320 override (must divide 20 / 10 chunks)."""
         blocks = M // 64
         if Cc == 640:
             # (round 5, OUT_FFP: proj_out [+ zero-conv] run inside every slice, so the split no longer pays for itself with a tail
             #  launch that re-reads nsplit fp32 slabs: as many slices as it takes to put a workgroup on every CU - 4 at 64 row blocks,
             #  the UNet at batch 1; BlobNet's 32 row blocks likewise 4 = 128 workgroups)
-            dflt = "4" if self.rowchain_ffp() else "2"
-            if self.cfg.is_blobnet and os.environ.get("BC_ROWCHAIN_FF_SPLIT_640_BLOB"):
-                return int(os.environ["BC_ROWCHAIN_FF_SPLIT_640_BLOB"]) if blocks <= 64 else 1
-            return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_640", dflt)) if blocks <= 64 else 1
-        return int(os.environ.get("BC_ROWCHAIN_FF_SPLIT_320", "1")) if blocks <= 128 else 1
+            dflt = 4 if self.rowchain_ffp() else 2
+            if self.cfg.is_blobnet and opt("ff_split_640_blob"):
+                return opt("ff_split_640_blob") if blocks <= 64 else 1
+            return (opt("ff_split_640") or dflt) if blocks <= 64 else 1
+        return opt("ff_split_320") if blocks <= 128 else 1
 
     def rowchain_ffp(self):
         """The split block end as OUT_FFP + sum (round 5) instead of OUT_FF + OUT_TAIL (round 3)?  OUT_FFP repeats to_out, proj_out [and
@@ -229,10 +230,10 @@ class TrunkPlan:
         CU-time.  The step is bound by the CU-time of BOTH queues' kernels at least as much as by the UNet chain (tools/
         concurrent_timeline.py): measured on one box, the UNet takes it (9.27 = 9.27 ms per step at batch 1), BlobNet, which
         runs ahead of the UNet with a millisecond of slack, keeps the form with the smaller footprint (batch 2, where only BlobNet's
-        64 row blocks split: 15.73 vs 15.88 ms).  BC_NO_FFP=1 / BC_FFP_BLOB=1 override."""
-        if os.environ.get("BC_NO_FFP"):
+        64 row blocks split: 15.73 vs 15.88 ms).  BC_PLAN ffp=0 / ffp_blob=1 override."""
+        if not opt("ffp"):
             return False
-        return not self.cfg.is_blobnet or bool(os.environ.get("BC_FFP_BLOB"))
+        return not self.cfg.is_blobnet or opt("ffp_blob")
 
     def transformer_rowchain(self, p, x: Act, r2=None, zero=None, fan_out=None):
         """One Transformer2D block as 2 (BlobNet) or 3 (UNet) row-chain launches + its attention calls: GroupNorm affine -> proj_in ->
@@ -254,12 +255,10 @@ class TrunkPlan:
 
         def packed(kind, zname=None, nsplit=1):
             key = (p, kind, zname, nsplit)
-            if os.environ.get("BC_ALIAS_WEIGHTS"):            # (diagnostics: weights.py _ALIAS)
-                key = (Cc, kind, zname is not None, nsplit)
             if key not in cache:
                 cache[key] = pack_rowchain(pw, p, kind, zname, nsplit)
             return cache[key]
-        if os.environ.get("BC_GN_FINALIZE_LAUNCH"):
+        if opt("gn_finalize_launch"):
             gnkw = dict(affine=rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"]))
         else:                                              # the GroupNorm finalize runs in the IN launch's prologue, from the statistics totals
             gnkw = dict(gn_in=(rec.gn_sources(x.t, Cc, None, 0, B, HW)[0], pw.f[p + "norm.weight"], pw.f[p + "norm.bias"], self.G, 1e-6))
@@ -338,7 +337,7 @@ class TrunkPlan:
         Measured per shape on an MI355X (tools/gw_probe.py, cold weights, graph replay): at M <= 1024 every projection is latency-bound
         (~11 us whatever the kernel), so the choice only matters where a launch disappears with it (LayerNorm folded, q | k | V^T in one
         launch) or the grid fills the chip (N >= 2560)."""
-        if os.environ.get("BC_NO_GW") or M > int(os.environ.get("BC_GW_MAXM", "1024")):
+        if not opt("gw") or M > opt("gw_maxm"):
             return 0
         order = prefer or (_lib.TILE_GW64x128,)
         for cfg in order:
@@ -348,12 +347,12 @@ class TrunkPlan:
 
     def ctx_fold_ok(self, Cc, T):
         """The cross-attention of a block as two per-image projections (bc_ctx_fold): for the widths transformer_gw takes; 8 heads x 80 kept
-        keys = K of the second projection (% 320).  BC_NO_CTX_FOLD: to_q + bc_attention + to_out.
+        keys = K of the second projection (% 320).  BC_PLAN ctx_fold=0: to_q + bc_attention + to_out.
         Only for the single edit (UNet batch 2 = the CFG pair): every image brings its own 5.9 MB of folded weights per block, and from four
         images on the shared to_q / to_out weights win (same box, interleaved, ms per step, unfolded vs folded: one edit 9.155 / 9.098 vs 9.097 /
         9.076; two 15.715 / 15.583 vs 15.755 / 15.750; eight 52.75 / 52.58 vs 52.80 / 52.79; 768^2 x 4 79.85 / 79.61 vs 80.21 / 79.90)."""
-        return (self.B <= int(os.environ.get("BC_CTX_FOLD_MAXB", "2")) and Cc % 320 == 0 and Cc not in (320, 640) and self.heads == 8 and T <= 80 and (Cc // self.heads) % 8 == 0 and Cc // self.heads <= 160
-                and not os.environ.get("BC_NO_CTX_FOLD") and not os.environ.get("BC_NO_GW"))
+        return (self.B <= opt("ctx_fold_maxb") and Cc % 320 == 0 and Cc not in (320, 640) and self.heads == 8 and T <= 80 and (Cc // self.heads) % 8 == 0 and Cc // self.heads <= 160
+                and opt("ctx_fold") and opt("gw"))
 
     def transformer_gw(self, p, x: Act, r2=None):
         """One Transformer2D block of the 1280-channel levels on gemm_wreg.hip: the three LayerNorms are folded into the projections
@@ -379,12 +378,9 @@ class TrunkPlan:
                 out = rec.empty(M, kw.get("n_t0") or n_out)
             rec.gemm(A=a_t, W=w, M=M, N=N, K=K, out=out, bias=b, tile_cfg=cfg, ln_colsum=cs, **kw)
             return out
-        if os.environ.get("BC_GW_GN_PASS"):                 # (diagnostics: the GroupNorm as its own pass in front of proj_in)
-            n = self.groupnorm(x, None, p + "norm", 1e-6, False)
-            h = proj(n.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1")
-        else:                                               # GroupNorm finalized + applied inside proj_in's row staging
-            gn = dict(x1=x.t, C1=Cc, B=B, HW=HW, G=self.G, eps=1e-6, gamma=pw.f[p + "norm.weight"], beta=pw.f[p + "norm.bias"])
-            h = proj(x.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1", a_gn=gn, rows_per_batch=HW)
+        # GroupNorm finalized + applied inside proj_in's row staging
+        gn = dict(x1=x.t, C1=Cc, B=B, HW=HW, G=self.G, eps=1e-6, gamma=pw.f[p + "norm.weight"], beta=pw.f[p + "norm.bias"])
+        h = proj(x.t, p + "proj_in", Cc, Cc, G128, kind="conv1x1", a_gn=gn, rows_per_batch=HW)
         # --- self attention: LayerNorm1 folded; q | k row-major, V transposed for the attention kernel
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
@@ -418,7 +414,7 @@ class TrunkPlan:
         # (64 x 128 workgroups everywhere: two fit a CU - 80 KiB of LDS each - and measure best at every shape of these levels, e.g.
         #  LayerNorm + GEGLU [1024 x 10240 x 1280] 51.7 us against 53.5 / 54.8 for the 256- / 320-column workgroups: tools/gw_probe.py)
         g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G128, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
-        if not os.environ.get("BC_NO_FF2_PROJ_OUT") and not os.environ.get("BC_NO_GW_FF2") and rec.lib.bc_gemm_wreg_eligible(M, Cc, 5 * Cc, 4 * Cc, G128):
+        if rec.lib.bc_gemm_wreg_eligible(M, Cc, 5 * Cc, 4 * Cc, G128):
             # ff.net.2 + residual + proj_out as ONE two-source GEMM over [g | h] with the weight [P F2 | P] made at pack time
             # (weights.ff2_proj_out): at these levels a launch on the UNet's queue costs ~40 us INSIDE the step - three times what it
             # takes alone (tools/ablate_probe.py: the six attn2.to_q launches 0.245 ms) - and this one is pure algebra
@@ -426,12 +422,9 @@ class TrunkPlan:
             out = proj(g, k, Cc, 5 * Cc, G128, A2=h, C1=4 * Cc, lda=4 * Cc, lda2=Cc, R=x.t, ldr=Cc, kind="ff", rows_per_batch=HW, want_gn=True,
                        **self._r2(r2, x.H, x.W))
             return Act(out, Cc, x.H, x.W), None
-        if not os.environ.get("BC_NO_GW_FF2"):
-            # ff.net.2 (K = 4C) unsplit on gemm_wreg: the same step time as the LDS-DMA tiles with split-K 3 (9.42 vs 9.42 ms, same box,
-            # two rounds), without their 15.7 MB of fp32 slabs and the reducer launch
-            h = proj(g, bp + "ff.net.2", Cc, 4 * Cc, G128, R=h, ldr=Cc, kind="ff")
-        else:
-            h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
+        # ff.net.2 (K = 4C) unsplit on gemm_wreg: the same step time as the LDS-DMA tiles with split-K 3 (9.42 vs 9.42 ms, same box,
+        # two rounds), without their 15.7 MB of fp32 slabs and the reducer launch
+        h = proj(g, bp + "ff.net.2", Cc, 4 * Cc, G128, R=h, ldr=Cc, kind="ff")
         out = proj(h, p + "proj_out", Cc, Cc, G128, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True, **self._r2(r2, x.H, x.W))
         return Act(out, Cc, x.H, x.W), None
 
@@ -496,7 +489,7 @@ class TrunkPlan:
                      ldc=ldvt, rows_per_batch=T, kind="ctx_kv")
             self.ctx_kv[bp] = (ck, cvt, T, ldvt)
             # blocks the row-chain takes with 8 heads and <= 80 context tokens: K / V^T also as the fragment streams of CHAIN_MIDX
-            if (Cc in (320, 640) and self.heads == 8 and T <= 80 and not os.environ.get("BC_NO_MIDX") and not os.environ.get("BC_NO_ROWCHAIN")):
+            if Cc in (320, 640) and self.heads == 8 and T <= 80 and opt("midx") and opt("rowchain"):
                 self.ctx_kvs[bp] = rec.rowchain_kv_stream(ck, cvt, B, T, Cc, ldvt)
             # blocks on gemm_wreg.hip (the 1280-channel levels): the prompt folded into attn2's weights (bc_ctx_fold) - to_q + attention +
             # to_out become two projections with per-image weights
@@ -563,9 +556,9 @@ class TrunkPlan:
         that block's GroupNorm -> proj_in -> norm1 -> attn1 are the same arithmetic on the same numbers for images b and b + B: 125 of the
         step's 5578 GFLOP at 512^2, half of one 8192-token self-attention among them.  They are recorded at batch B; one bc_dup_halves
         launch fans the four tensors that later launches read per image out to the pairs.  Results are bit-identical to the plain plan
-        (every kernel on the path is per-image deterministic: tests/test_fullsize_gpu.py).  BC_NO_CFG_PREFIX=1: the plain plan."""
+        - to fp16 rounding, tests/test_fullsize_gpu.py.  BC_PLAN cfg_prefix=0: the plain plan."""
         cfg = self.cfg
-        if not cfg_pairs or cfg.is_blobnet or self.B % 2 or not im2col or os.environ.get("BC_NO_CFG_PREFIX") or len(cfg.block_out_channels) < 2:
+        if not cfg_pairs or cfg.is_blobnet or self.B % 2 or not im2col or not opt("cfg_prefix") or len(cfg.block_out_channels) < 2:
             return False
         Cc, HW = cfg.block_out_channels[0], self.H * self.W
         return self.pw.has_cross and Cc in (320, 640) and self.rowchain_ok(Cc, (self.B // 2) * HW, HW, "down_blocks.0.attentions.0.")
@@ -710,7 +703,7 @@ class TrunkPlan:
             n = self.groupnorm(h, None, "conv_norm_out", 1e-5, True)
             # conv_out has 4 output channels: one column tile.  The planner's 256-row tiles left 64 workgroups, each gathering 1.5 MB
             # through one CU (23 us); 64-row tiles spread the same gather over 256 CUs.
-            small = 7 if (self.B * H * W) >= 64 * 128 and not os.environ.get("BC_CONV_OUT_AUTO") else 0
+            small = 7 if (self.B * H * W) >= 64 * 128 else 0
             eps = self.conv3x3(n, "conv_out", cfg.out_channels, out_f32=True, kind="conv_out", out=eps_out, tile_cfg=small)
             return eps.t
         self.feat_shapes = ([(f.C, f.H, f.W) for f in feats_d], (feat_mid.C, feat_mid.H, feat_mid.W),

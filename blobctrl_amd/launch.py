@@ -15,6 +15,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+from .options import opt
 from ._lib import BcGemm
 
 
@@ -360,9 +361,6 @@ class Recorder:
             hit = tuning_table().get(f"{mode}|{M}|{N}|{K}")
             if hit:
                 tile_cfg, sk = int(hit[0]), int(hit[1])
-            cap = os.environ.get("BC_SPLITK_MAX")              # diagnostics: cap the split-K of the GEMM family (the tile is then the cost model's)
-            if cap and (sk < 0 or sk > int(cap)):
-                tile_cfg, sk = 0, (int(cap) if sk > int(cap) else sk)
         c, s_, bm, bn = C.c_int(tile_cfg), C.c_int(sk), C.c_int(0), C.c_int(0)
         _lib.check(self.lib.bc_gemm_plan(M, N, K, 1 if fast else 0, C.byref(c), C.byref(s_), C.byref(bm), C.byref(bn)),
                    "bc_gemm_plan")
@@ -435,14 +433,14 @@ class Recorder:
                 # 144: 9.354 / 9.339; 128: 9.323 / 9.330 and 9.081 / 9.087; 112: 9.070 / 9.049; 96: 9.474 / 9.493 - the UNet's 16 x 32
                 # convolutions in 2 instead of 3 splits, BlobNet's in 4 instead of 6 (fewer slabs for the reducer); batch 2: 15.58 / 15.74
                 # vs 15.85 / 15.78; batch 8 and 768^2 batch 4 unchanged (52.8 / 52.7 vs 52.7 / 52.6; 80.5 / 80.4 vs 80.5 / 80.4).
-                target = int(os.environ.get("BC_HALO_CTAS", "128" if tile_cfg == _lib.TILE_WREG else "256"))
-                min_cps = int(os.environ.get("BC_HALO_MIN_CPS", "3" if tile_cfg == _lib.TILE_WREG else "2"))
+                target = opt("halo_ctas") or (128 if tile_cfg == _lib.TILE_WREG else 256)
+                min_cps = opt("halo_min_cps") or (3 if tile_cfg == _lib.TILE_WREG else 2)
                 # workgroups from which one pass is taken unsplit: 2/3 of the target.  (From half fill - BC_HALO_FULL=128 - the 64 x 128
                 # BlobNet and 32 x 64 UNet convolutions run as one pass instead of two K halves + a reducer: 13 reducer launches and
                 # 0.7 GB of slab traffic less, and the step gains 0.4 % (10.59 -> 10.55 ms, round 3, same box) because the other trunk's
                 # kernels fill the idle CUs - but this kernel's own average goes from 37.5 to 45.8 us (0.24 -> 0.19 of peak) and the
                 # serialised kernel time of a step rises by 0.76 ms: not the default.)
-                full = int(os.environ.get("BC_HALO_FULL", str(target * 2 // 3)))
+                full = opt("halo_full") or target * 2 // 3
                 # conv_wreg.hip: with five chunks or fewer a half-filled pass is also the faster one in isolation (64 x 128 BlobNet: 43.8 us
                 # unsplit vs 45.7 us as two K halves + reducer, cold weights); with ten chunks the split wins (32 x 64 UNet: 61.4 vs 54.5)
                 short = tile_cfg == _lib.TILE_WREG and base >= target // 2 and nch <= 5
@@ -459,7 +457,7 @@ class Recorder:
                 span = cps * 64 + 2 * (conv["Cin"] // G_)
                 t1, t2 = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"])
                 fin_max = 2752 if tile_cfg == _lib.TILE_WREG else 712          # (FIN_MAX_CH of conv_wreg.hip / conv_halo.hip)
-                if span <= fin_max and not os.environ.get("BC_GN_FINALIZE_LAUNCH"):
+                if span <= fin_max and not opt("gn_finalize_launch"):
                     g.a_tot1, g.a_tot2 = ptr(t1), ptr(t2)
                     g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), G_, a_gn["eps"]
                     self.keep.append((t1, t2, a_gn["gamma"], a_gn["beta"]))

@@ -60,13 +60,15 @@ class BlobCtrlEngine:
         self.scheduler_params = (1000, 0.00085, 0.012)               # (num_train_timesteps, beta_start, beta_end): SD-1.5 values
         self.use_graphs = use_graphs and not os.environ.get("BC_NO_GRAPHS")    # diagnostics: eager launches from the host loop
         if self.device.type == "cuda":
-            prio = int(os.environ.get("BC_STREAM_PRIO", "0"))            # diagnostics: 1 = UNet stream high priority, 2 = BlobNet stream high
-            self.stream = torch.cuda.Stream(device=self.device, priority=-1 if prio == 1 else 0)
-            self.side_stream = torch.cuda.Stream(device=self.device, priority=-1 if prio == 2 else 0)   # BlobNet branch runs here, concurrently with the UNet
+            # (stream priorities were measured and do nothing on this part: DESIGN 9)
+            self.stream = torch.cuda.Stream(device=self.device)
+            self.side_stream = torch.cuda.Stream(device=self.device)     # BlobNet branch runs here, concurrently with the UNet
             self.side_stream2 = torch.cuda.Stream(device=self.device)    # (BC_SPLIT_CFG: the cond half of the UNet batch)
         self.two_streams = not os.environ.get("BC_ONE_STREAM")
         self.loop_graph = os.environ.get("BC_LOOP_GRAPH", "1") != "0"     # whole-edit graph (one launch per edit) vs one graph per step
         self._plans = {}                                              # (batch, canvas, steps, ...) -> plan, least recently used first
+        # plan / graph cache traffic (bench.py prints it: C4's eight per-request batches of a rank must replay ONE captured whole-edit graph)
+        self.cache_stats = dict(plans_recorded=0, plan_hits=0, loop_graph_captures=0, loop_graph_hits=0)
         self.max_cached_plans = max(1, int(max_cached_plans))         # a 512^2 batch-1 plan holds ~2.5 GB of activations
         self.max_loop_graphs = 4                                      # whole-edit graphs kept per plan (one per active / inactive pattern)
         self._sched_cache = {}
@@ -81,7 +83,9 @@ class BlobCtrlEngine:
         key = (B, h, w, T, ctx_dim, nsteps, per_request)
         if key in self._plans:
             self._plans[key] = self._plans.pop(key)                   # mark as most recently used
+            self.cache_stats["plan_hits"] += 1
             return self._plans[key]
+        self.cache_stats["plans_recorded"] += 1
         while len(self._plans) >= self.max_cached_plans:              # evict the least recently used plan and its graphs
             old = self._plans.pop(next(iter(self._plans)))
             if self.device.type == "cuda":
@@ -112,7 +116,7 @@ class BlobCtrlEngine:
         P.guidance = [7.5]
 
         # rank-1 collapse of the BlobNet feature channels (per-edit weight): not for per-request batches (one weight per launch)
-        no_im2col = bool(os.environ.get("BC_NO_IM2COL"))      # diagnostics: conv_in as a 3x3 convolution (K = 72 / 9288: generic kernel)
+        no_im2col = False
         P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request and not no_im2col
         unet_cin = pad8(self.unet_cfg.in_channels)
         blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
@@ -132,7 +136,7 @@ class BlobCtrlEngine:
         if P.collapse:
             blob.record_collapse(P.feat16)
         # time-embedding path of every step, once per edit (read in the step through the device step counter)
-        temb_per_step = bool(os.environ.get("BC_TEMB_PER_STEP"))         # diagnostic: the four launches per net inside every step
+        temb_per_step = False                                # (the per-edit table replaced the four launches per net inside every step)
         if not temb_per_step:
             unet_a.record_time_table(P.t_table, nsteps, P.step_idx)
             blob.record_time_table(P.t_table, nsteps, P.step_idx)
@@ -219,6 +223,8 @@ class BlobCtrlEngine:
         P.eps_inactive = P.eps
         P.loop_graphs = {}
         P.captured = False
+        from . import options
+        P.options, P.options_non_default = options.effective(), options.non_default()     # (what BC_PLAN said while this plan was recorded)
         self._plans[key] = P
         return P
 
@@ -455,6 +461,7 @@ class BlobCtrlEngine:
             # per-step scalars (timestep, scheduler coefficients, conditioning scale) are read through the device step counter
             key = tuple(v != 0.0 for v in scales)
             g = P.loop_graphs.pop(key, None)
+            self.cache_stats["loop_graph_hits" if g is not None else "loop_graph_captures"] += 1
             if g is None:
                 torch.cuda.synchronize(self.device)
                 while len(P.loop_graphs) >= self.max_loop_graphs:              # least recently used pattern: destroy its graph exec
@@ -492,8 +499,6 @@ class BlobCtrlEngine:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(self.stream)
         out.record_stream(cur)                              # (allocated on the engine's stream, consumed on the caller's)
-        if os.environ.get("BC_SYNC_EDIT"):                  # diagnostics: the pre-round-2 behaviour (host sync per edit)
-            torch.cuda.synchronize(self.device)
         return out if output_type == "latent" else self.decode_latents(out, output_type)
 
     @torch.no_grad()

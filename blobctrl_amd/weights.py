@@ -131,12 +131,6 @@ def fold_cross_attention(k: torch.Tensor, vt: torch.Tensor, T: int, heads: int, 
     return qk, qk.float().sum(-1), qb, vo
 
 
-# BC_ALIAS_WEIGHTS=1 (diagnostics, WRONG results): every weight matrix of a shape shares the first one's storage, so that the step's
-# 3.4 GB of weights shrink to what the Infinity Cache holds - the upper bound of what ANY weight prefetch could buy (tools / DESIGN 9).
-import os as _os
-_ALIAS = bool(_os.environ.get("BC_ALIAS_WEIGHTS"))
-
-
 class PackedTrunk:
     """Device-resident packed weights of one trunk (UNet or BlobNet)."""
 
@@ -147,8 +141,6 @@ class PackedTrunk:
         from . import _lib
         nt = _lib.GW_TILES[tile_cfg]
         ck = ("gw", key, tuple(extra), nt, ln)
-        if _ALIAS:       # (diagnostics: see _ALIAS below)
-            ck = ("gw", tuple(self.h[key].shape), tuple(tuple(self.h[e].shape) for e in extra), nt, ln is not None, bias is not None)
         cache = self.__dict__.setdefault("_gw", {})
         if ck not in cache:
             w = self.h[key] if not extra else torch.cat([self.h[key]] + [self.h[e] for e in extra], 0)
@@ -188,14 +180,7 @@ class PackedTrunk:
         """Key of the BC_TILE_WREG fragment stream of the packed 3x3 weight `key` (made on first use, kept beside the matrix)."""
         k2 = key + "_wreg"
         if k2 not in self.h:
-            if _ALIAS:
-                shared = self.__dict__.setdefault("_wreg_alias", {})
-                shp = tuple(self.h[key].shape)
-                if shp not in shared:
-                    shared[shp] = pack_conv_wreg(self.h[key])
-                self.h[k2] = shared[shp]
-            else:
-                self.h[k2] = pack_conv_wreg(self.h[key])
+            self.h[k2] = pack_conv_wreg(self.h[key])
         return k2
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, block_out_channels, layers_per_block=2):
@@ -287,10 +272,6 @@ class PackedTrunk:
             h[k] = self.h_arena[off:off + n].view(shape)
             if copy_from is not None:
                 h[k].copy_(copy_from[0][k])
-        if _ALIAS:
-            first = {}
-            for k in list(h):
-                h[k] = first.setdefault(tuple(h[k].shape), h[k])
         for (k, shape, off) in self.f_layout:
             n = 1
             for d in shape:

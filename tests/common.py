@@ -268,3 +268,8 @@ def write_model_tree(root, lora=True):
     paths = dict(sd15=os.path.join(root, "sd15"), blobnet=os.path.join(root, "blobnet"), dinov2=os.path.join(root, "dinov2"),
                  unet_lora=os.path.join(root, "unet_lora"))
     return paths, dict(unet4=base_unet, blobnet=bsd, vae=vsd, clip=csd, dino=dsd, lora=lora_t)
+
+
+def set_plan(monkeypatch, **kv):
+    """BC_PLAN for the plans recorded from here on (blobctrl_amd/options.py): planner options as key=value pairs, bools as 0 / 1."""
+    monkeypatch.setenv("BC_PLAN", ",".join(f"{k}={int(v)}" for k, v in kv.items()))

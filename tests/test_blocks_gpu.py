@@ -82,9 +82,10 @@ def test_resnet_block(z, name, split):
 @pytest.mark.parametrize("name", ["tfm_320_cross", "tfm_320_self_only"])
 def test_transformer_block(z, name, fused, monkeypatch):
     """Both forms of the 320-channel block against the reference's Transformer2DModel: the fused row-chain launches
-    (csrc/rowchain.hip: 2 / 3 launches + attention) and the unfused GEMM / LayerNorm list (BC_NO_ROWCHAIN=1)."""
+    (csrc/rowchain.hip: 2 / 3 launches + attention) and the unfused GEMM / LayerNorm list (BC_PLAN rowchain=0)."""
+    from tests.common import set_plan
     if not fused:
-        monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
+        set_plan(monkeypatch, rowchain=0)
     _, p = BLOCK_CASES[name]
     x, _, ctx = block_inputs(name)
     rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"], heads=p["heads"], cross=p["ctx"])
@@ -110,19 +111,19 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     (round 5), as OUT_FF + OUT_TAIL over two (round 3), its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
     in one launch, the cross-attention as two projections with the prompt folded into their weights (round 5: bc_ctx_fold; "gw_attn" = to_q +
     bc_attention + to_out instead); and the unfused list)."""
+    from tests.common import set_plan
     if mode == "gw_attn":
-        monkeypatch.setenv("BC_NO_CTX_FOLD", "1")
+        set_plan(monkeypatch, ctx_fold=0)
         mode = "gw"
         folded = False
     else:
         folded = mode == "gw" and name == "tfm_1280_cross"
     if mode == "unfused":
-        monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
-        monkeypatch.setenv("BC_NO_GW", "1")
+        set_plan(monkeypatch, rowchain=0, gw=0)
     if mode == "rowchain_nsplit1":
-        monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", "1")
+        set_plan(monkeypatch, ff_split_640=1)
     if mode == "rowchain_tail":                  # the round-3 block end: OUT_FF + OUT_TAIL over fp32 partial sums
-        monkeypatch.setenv("BC_NO_FFP", "1")
+        set_plan(monkeypatch, ffp=0)
     _, p = BLOCK_CASES[name]
     x, _, ctx = block_inputs(name)
     rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"], heads=p["heads"], cross=p["ctx"])

@@ -95,7 +95,7 @@ def test_cfg_invariant_prefix_equals_the_plain_plan(full, batch, monkeypatch):
     eps, lat, flops, kinds = [], [], [], []
     for plain in (False, True):
         if plain:
-            monkeypatch.setenv("BC_NO_CFG_PREFIX", "1")
+            monkeypatch.setenv("BC_PLAN", "cfg_prefix=0")
         pipe = BlobCtrlEngine(full["usd"], full["bsd"], full["ucfg"], full["bcfg"], device="cuda:0", scheduler="ddim")
         out = pipe(inp["prompt"], inp["fg"], inp["bg"], score, inp["dino"], num_inference_steps=1, guidance_scale=7.5, latents=inp["latents"])
         P = pipe.plan_for(batch, h, w, 77, 768, 1)

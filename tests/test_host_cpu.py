@@ -498,3 +498,32 @@ def test_prompt_folded_into_the_cross_attention_weights_is_the_same_attention():
     a = (torch.softmax(q @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, rows, C)
     ref = a @ Wo.t()
     assert float((got - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
+def test_planner_options_parse_and_refuse_typos(monkeypatch):
+    """blobctrl_amd/options.py (round 6): ONE variable, BC_PLAN, for everything the planner decides; defaults when unset; a typo or a
+    non-integer value raises instead of silently running the default plan; no option exists that aliases weights or ablates a kernel
+    (the two diagnostics that produced wrong results are gone from the package)."""
+    from blobctrl_amd import options
+    monkeypatch.delenv("BC_PLAN", raising=False)
+    assert options.non_default() == {} and options.opt("rowchain") is True and options.opt("g256_min_tiles") == 128
+    monkeypatch.setenv("BC_PLAN", "rowchain=0, ff_split_640=2;cfg_prefix=0")
+    assert options.non_default() == {"rowchain": False, "ff_split_640": 2, "cfg_prefix": False}
+    for bad in ("rowchian=0", "rowchain", "gw_maxm=big"):
+        monkeypatch.setenv("BC_PLAN", bad)
+        with pytest.raises(ValueError):
+            options.effective()
+    assert not any("alias" in k or "dbg" in k for k in options.TABLE)
+    # the package reads no other BC_* planner switch: every os.environ / getenv name in it is on the short list of run-time switches
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blobctrl_amd")
+    names = set()
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                names |= set(re.findall(r'(?:environ(?:\.get)?\(|environ\[|getenv\()\s*"(BC_[A-Z0-9_]+)"', src))
+    allowed = {"BC_PLAN", "BC_NO_GRAPHS", "BC_LOOP_GRAPH", "BC_ONE_STREAM", "BC_NO_MODULE_GRAPHS", "BC_SPLIT_CFG", "BC_NO_TUNING", "BC_TUNING_FILE",
+               "BC_GN_UNFUSED", "BC_GEMM_GENERIC", "BC_GEMM_TILE", "BC_ATTN_NO8", "BC_WREG_STAMPS", "BC_RC_STAMPS",
+               "BC_HALO_DBG", "BC_HALO_STAMPS"}            # (the last two only inside #ifdef BC_DIAGNOSTICS of conv_halo.hip)
+    assert names <= allowed and len(names) <= 25, sorted(names - allowed)

@@ -22,18 +22,12 @@ def _block_sd(cross, seed, zero=False, C=320):
     return sd
 
 
-def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T=7, midx=True):
-    monkeypatch.setenv("BC_ROWCHAIN_MIN_BLOCKS_640", "1")      # (the engine takes the 640-channel form only from 256 row blocks upwards)
-    monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_640", str(split))  # feed-forward of the block end over `split` workgroups per row block
-    monkeypatch.setenv("BC_ROWCHAIN_FF_SPLIT_320", str(split))
-    if midx:
-        monkeypatch.delenv("BC_NO_MIDX", raising=False)
-    else:
-        monkeypatch.setenv("BC_NO_MIDX", "1")
-    if fused:
-        monkeypatch.delenv("BC_NO_ROWCHAIN", raising=False)
-    else:
-        monkeypatch.setenv("BC_NO_ROWCHAIN", "1")
+def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T=7, midx=True, ffp=True):
+    from tests.common import set_plan
+    # (the engine takes the 640-channel form only from 64 row blocks upwards; feed-forward of the block end over `split` workgroups per row
+    #  block; BlobNet's blocks keep OUT_FF + OUT_TAIL by default: engine.rowchain_ffp)
+    set_plan(monkeypatch, rowchain_min_blocks_640=1, rowchain_min_blocks_640_blob_up=1, ff_split_640=split, ff_split_640_blob=split, ff_split_320=split,
+             midx=midx, rowchain=fused, ffp=ffp, ffp_blob=1)
     sd = _block_sd(cross, 77, zero, C)
     rec, seg, plan = _plan("rc", sd, B, H, W, heads=8, cross=768 if cross else None)
     x = g(5, B, C, H, W) * 1.3 + 0.2
@@ -67,17 +61,13 @@ def _record(monkeypatch, fused, cross, B, H, W, with_r2, zero, C=320, split=1, T
     (True, 2, 16, 32, True, False, 640, 2), (False, 1, 8, 24, False, True, 640, 4), (True, 1, 8, 8, True, False, 640, 5),
     (True, 2, 16, 32, True, False, 320, 2), (False, 1, 16, 32, False, True, 320, 5)])
 def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2, zero, C, split):
-    monkeypatch.delenv("BC_NO_FFP", raising=False)
-    monkeypatch.setenv("BC_FFP_BLOB", "1")                   # (BlobNet's blocks keep OUT_FF + OUT_TAIL by default: engine.rowchain_ffp)
     rec_f, out_f, pre_f, part_f = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
     # split block end (round 5): OUT_FFP (every slice through proj_out [+ zero-conv]) + the sum of the fp16 partial outputs
     assert any("out_ffp/" in (m["variant"] or "") for m in rec_f.seg.meta) == (split > 1)
     assert any(m["kind"] == "rowchain_sum" for m in rec_f.seg.meta) == (split > 1)
     _, out_u, pre_u, _ = _record(monkeypatch, False, cross, B, H, W, with_r2, zero, C)
-    if split > 1:        # the round-3 form (OUT_FF + OUT_TAIL over fp32 partial sums) stays available behind BC_NO_FFP=1
-        monkeypatch.setenv("BC_NO_FFP", "1")
-        rec_t, out_t, pre_t, _ = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split)
-        monkeypatch.delenv("BC_NO_FFP")
+    if split > 1:        # the round-3 form (OUT_FF + OUT_TAIL over fp32 partial sums) stays available behind BC_PLAN ffp=0
+        rec_t, out_t, pre_t, _ = _record(monkeypatch, True, cross, B, H, W, with_r2, zero, C, split, ffp=False)
         assert any("out_tail" in (m["variant"] or "") for m in rec_t.seg.meta) and not any(m["kind"] == "rowchain_sum" for m in rec_t.seg.meta)
         t_, u_ = out_t.t.float().cpu().numpy(), out_u.t.float().cpu().numpy()
         assert np.abs(t_ - u_).max() / np.abs(u_).max() < 6e-3 and psnr(t_, u_) > 50.0

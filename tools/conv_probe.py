@@ -22,7 +22,9 @@ stream = torch.cuda.current_stream().cuda_stream
 SHAPES = [(2, 64, 128, 320, 0, 320), (2, 64, 128, 640, 320, 320), (2, 64, 128, 320, 320, 320), (1, 64, 128, 320, 0, 320),
           (2, 32, 64, 640, 0, 640), (2, 32, 64, 320, 0, 640), (2, 32, 64, 1280, 640, 640), (1, 32, 64, 640, 0, 640),
           (2, 16, 32, 1280, 0, 1280), (2, 16, 32, 1280, 1280, 1280), (1, 16, 32, 1280, 0, 1280),
-          (2, 8, 16, 1280, 0, 1280), (2, 8, 16, 1280, 1280, 1280), (1, 8, 16, 1280, 0, 1280)]
+          (2, 8, 16, 1280, 0, 1280), (2, 8, 16, 1280, 1280, 1280), (1, 8, 16, 1280, 0, 1280),
+          # (round 6) the UNet's shapes at batch 8: eight rounds of workgroups per launch
+          (16, 64, 128, 320, 0, 320), (16, 32, 64, 640, 0, 640), (16, 16, 32, 1280, 0, 1280)]
 only = os.environ.get("PROBE_ONLY")
 cold = os.environ.get("PROBE_COLD")            # weights from HBM (caches flushed before every launch), activations warm: as in the step
 thrash = torch.zeros(160 << 20, dtype=torch.float32, device=dev) if cold else None

@@ -2,7 +2,7 @@
 
 The step follows the UNet queue (tools/critical_path.py: 8.6 ms alone, BlobNet always ahead with up to 2.2 ms of slack) and the
 1.4 ms above that is BlobNet's workgroups taking CUs the UNet's launches want.  Stream priorities change nothing on this part
-(BC_STREAM_PRIO); this probe gives the BlobNet stream a CU mask (hipExtStreamCreateWithCUMask) and replays eager two-stream edits
+(round 3; the switch is gone); this probe gives the BlobNet stream a CU mask (hipExtStreamCreateWithCUMask) and replays eager two-stream edits
 (graph nodes do not inherit a stream's mask).  usage: python tools/cumask_probe.py [steps]"""
 import ctypes
 import os

@@ -20,9 +20,9 @@ def build(fused, cross, B, H, W, zero, C=320):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from tests.common import block_param_shapes
     if fused:
-        os.environ.pop("BC_NO_ROWCHAIN", None)
+        os.environ.pop("BC_PLAN", None)
     else:
-        os.environ["BC_NO_ROWCHAIN"] = "1"
+        os.environ["BC_PLAN"] = "rowchain=0"
     sd = {"blk." + k: v for k, v in synth.synth_state_dict(block_param_shapes("transformer", dict(C=C, ctx=768 if cross else None)), 7).items()}
     sd["conv_in.weight"] = torch.zeros(8, 4, 3, 3)
     sd["none.time_emb_proj.weight"], sd["none.time_emb_proj.bias"] = torch.zeros(8, 1280), torch.zeros(8)
@@ -61,7 +61,7 @@ def main():
     cold = bool(os.environ.get("PROBE_COLD"))
     thrash = torch.zeros(160 << 20, dtype=torch.float32, device=dev) if cold else None
     stream = torch.cuda.current_stream().cuda_stream
-    Cc = int(os.environ.get("PROBE_C", "320"))                 # 640: the 32 x 64 level (BC_ROWCHAIN_MIN_BLOCKS_640=1 to fuse BlobNet's too)
+    Cc = int(os.environ.get("PROBE_C", "320"))                 # 640: the 32 x 64 level (BC_PLAN rowchain_min_blocks_640=1 to fuse BlobNet's too)
     Hh, Ww = (64, 128) if Cc == 320 else (32, 64)
     for name, cross, B, zero in ((f"UNet  B=2 ({2 * Hh * Ww} rows)", True, 2, False), (f"BlobNet B=1 ({Hh * Ww} rows)", False, 1, True)):
         arms = {}

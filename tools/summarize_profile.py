@@ -31,8 +31,22 @@ def csrc_sha():
     return hsh.hexdigest()[:12]
 
 
+def workload_of(d):
+    """(res, batch) of the bench run the passes profiled, from the metric name of its line (bench.metric_name)."""
+    import re
+    try:
+        with open(os.path.join(d, "stats_bench.json")) as f:
+            metric = json.loads(f.read().strip().splitlines()[-1])["metric"]
+        m = re.match(r"(\d+)x\d+_", metric)
+        b = re.search(r"_batch(\d+)", metric)
+        return int(m.group(1)), int(b.group(1)) if b else 1
+    except Exception:                                               # noqa: BLE001
+        return 512, 1
+
+
 def main():
     d = sys.argv[1]
+    res, batch = workload_of(d)
     fetch, write, mfma = (agg(os.path.join(d, sub, "**", "*counter_collection.csv")) for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"))
     kernels = []
     for name in sorted(set(fetch) | set(write)):
@@ -49,7 +63,7 @@ def main():
                    # denoise steps the pass executed = launches of the per-step CFG / scheduler kernel (two 2-step edits + the warm-up
                    # replays of the active and the inactive segment before capture): per-step traffic = sum over the library's kernels / this
                    denoise_steps_profiled=max([k["launches"] for k in kernels if "cfg_step_kernel" in k["kernel"]] or [4]),
-                   csrc_sha=csrc_sha(), kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
+                   csrc_sha=csrc_sha(), res=res, batch=batch, kernels=kernels), open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
     util = []
     for name, c in mfma.items():
         if "GRBM_GUI_ACTIVE" not in c:
@@ -65,7 +79,7 @@ def main():
                            "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --denoise-steps 2",
                    note="fractions of the launch's own GPU cycles (GRBM_GUI_ACTIVE/8): MFMA pipe busy over 1024 SIMDs, VALU issue port "
                         "(SQ_ACTIVE_INST_VALU counts 4-cycle quads), LDS array over 256 CUs; all launches of a kernel summed",
-                   csrc_sha=csrc_sha(), kernels=util), open(os.path.join(d, "pmc_mfma_util.json"), "w"), indent=1)
+                   csrc_sha=csrc_sha(), res=res, batch=batch, kernels=util), open(os.path.join(d, "pmc_mfma_util.json"), "w"), indent=1)
     print("summaries:", os.listdir(d))
 
 
