@@ -62,7 +62,7 @@ _SIGNATURES = {
     "bc_gemm_wreg_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gemm_wreg_stream_elems": (C.c_longlong, [C.c_int, C.c_int]),
     "bc_gemm_wreg_eligible": (C.c_int, [C.c_int] * 5),
-    "bc_gemm256_eligible": (C.c_int, [C.c_int] * 6),
+    "bc_gemm256_eligible": (C.c_int, [C.c_int] * 7),
     "bc_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bc_gn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

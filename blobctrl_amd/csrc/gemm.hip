@@ -485,7 +485,8 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
     if (p.R2) BC_CHECK_ARG(p.ldr2 >= g.n_out && p.r2_bmod > 0, "bc_gemm: bad R2 params");
     if (p.rowvec) BC_CHECK_ARG(p.ld_rowvec >= p.N, "bc_gemm: ld_rowvec too small");
     const bool gw = bc_gemm_wreg_nt(p.tile_cfg) != 0;
-    BC_CHECK_ARG(gw || (!p.ln_colsum && !p.C_t), "bc_gemm: ln_colsum / C_t need a BC_TILE_GW* configuration");
+    BC_CHECK_ARG(gw || !p.ln_colsum, "bc_gemm: ln_colsum needs a BC_TILE_GW* configuration");
+    BC_CHECK_ARG(gw || p.tile_cfg == BC_TILE_G256 || !p.C_t, "bc_gemm: C_t needs a BC_TILE_GW* or the BC_TILE_G256 configuration");
     BC_CHECK_ARG(gw || (!p.w_bstride && !p.vec_bstride && !p.sm_group), "bc_gemm: w_bstride / vec_bstride / sm_group need a BC_TILE_GW* configuration");
     if (p.out_mode == BC_OUT_F16_T) {
         BC_CHECK_ARG(p.M % p.rows_per_batch == 0 && p.ldc >= p.rows_per_batch, "bc_gemm: transposed output needs M%%rows_per_batch==0, ldc>=rows_per_batch");
@@ -508,8 +509,8 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         return bc_gemm_wreg_launch(g, stream);
     }
     if (p.tile_cfg == BC_TILE_G256) {
-        BC_CHECK_ARG(bc_gemm256_ok(p), "bc_gemm: BC_TILE_G256 needs dense single-source A, M%%256==0, N%%256==0, K%%128==0, no split-K, fp16 row-major "
-                     "or transposed (bias / alpha only) output (M=%d N=%d K=%d out_mode=%d)", p.M, p.N, p.K, p.out_mode);
+        BC_CHECK_ARG(bc_gemm256_ok(p), "bc_gemm: BC_TILE_G256 needs dense A (C1%%128==0), M%%256==0, N%%256==0, K%%128==0, no split-K, fp16 row-major "
+                     "or transposed (bias / alpha only) output, n_t0%%256==0 with C_t (M=%d N=%d K=%d out_mode=%d)", p.M, p.N, p.K, p.out_mode);
         g.nk = p.K / BK; g.kt_per_split = g.nk; p.splitk = 1;
         g.div_rpb = make_fastdiv((unsigned)p.rows_per_batch);
         g.div_outw = make_fastdiv((unsigned)p.out_w);
@@ -517,8 +518,9 @@ extern "C" int bc_gemm(const BcGemm* pp, bc_stream stream_) {
         g.cfg = BC_TILE_G256; g.bm = 256; g.bn = 256;
         auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
         g.vec_epilogue = g.n_out % 8 == 0 && p.ldc % 8 == 0 && al16(p.C) && (!p.R || (p.ldr % 8 == 0 && al16(p.R))) &&
-                         (!p.R2 || (p.ldr2 % 8 == 0 && al16(p.R2))) && (!p.rowvec || p.ld_rowvec % 8 == 0);
-        BC_CHECK_ARG(g.vec_epilogue, "bc_gemm: BC_TILE_G256 needs 16-byte aligned C / R / R2 and widths %% 8 == 0");
+                         (!p.R2 || (p.ldr2 % 8 == 0 && al16(p.R2))) && (!p.rowvec || p.ld_rowvec % 8 == 0) && (!p.C_t || al16(p.C_t)) &&
+                         (!p.A2 || al16(p.A2));
+        BC_CHECK_ARG(g.vec_epilogue, "bc_gemm: BC_TILE_G256 needs 16-byte aligned C / C_t / R / R2 / A2 and widths %% 8 == 0");
         BC_CHECK_ARG(!p.gn_tot || (p.rows_per_batch % 256 == 0 && p.M % p.rows_per_batch == 0),
                      "bc_gemm: BC_TILE_G256 with GroupNorm statistics needs rows_per_batch%%256==0 (a tile's rows inside one image)");
         g.vec_transposed = p.out_mode == BC_OUT_F16_T; g.nband = 0;

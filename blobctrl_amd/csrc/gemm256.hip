@@ -28,7 +28,9 @@
 //     (XOR-swizzled 16-byte chunks: conflict-free both ways), re-read row-major, 8 output columns per thread = gemm_fast's shared
 //     epilogue (bias, GEGLU / GELU / SiLU, scales, residual, BlobNet right-half residual, 16-byte stores, GroupNorm statistics totals);
 //     BC_OUT_F16_T (V^T for the attention kernel) as 16-byte stores along the token axis.
-// Eligibility (bc_gemm256_eligible): dense single-source A, M % 256 == 0, N % 256 == 0, K % 128 == 0, no split-K.
+//   * two-source A (BcGemm.A2 / C1 % 128 == 0: torch.cat([x, skip], 1) in front of a 1 x 1 shortcut, [g | h] in front of the fused
+//     ff.net.2 + proj_out weight) by switching the staged source at k = C1; BcGemm.C_t / n_t0 (q | k row-major + V^T in one launch).
+// Eligibility (bc_gemm256_eligible): dense A, M % 256 == 0, N % 256 == 0, K % 128 == 0, no split-K.
 #include <stdlib.h>
 #include <type_traits>
 #include "gemm_common.h"
@@ -63,7 +65,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 // draining pair (only phase 0 stages; phase 3 waits for everything); 2: last tile (nothing staged, nothing waited for).
 template <int B, int MODE>
 __device__ __forceinline__ void tile_phases(f32x4 (&acc)[8][4], Frags& f, const char* aB, const char* bB, char* stg, const char* a1, const char* b0n,
-                                            const char* a0n, const char* b1n, unsigned voA, unsigned voB) {
+                                            const char* a0n, const char* b1n, unsigned voA1, unsigned voA0n, unsigned voB) {
     constexpr int O = B * KBUF, ON = (B ^ 1) * KBUF;
     auto mfma = [&](auto ac, auto bc) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
@@ -91,8 +93,8 @@ __device__ __forceinline__ void tile_phases(f32x4 (&acc)[8][4], Frags& f, const 
         for (int ks = 0; ks < 2; ++ks) f.a[rt][ks] = *reinterpret_cast<const h16x8*>(aB + O + 1 * HT + rt * 2048 + ks * 1024);
     SB();
     if (MODE <= 1) {
-        glds16(a1 + voA, stg + ON + 3 * HT);
-        glds16(a1 + voA + 64, stg + ON + 3 * HT + 1024);
+        glds16(a1 + voA1, stg + ON + 3 * HT);
+        glds16(a1 + voA1 + 64, stg + ON + 3 * HT + 1024);
     }
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the B0 reads have returned: B0's slot is restaged one phase later
     BAR();
@@ -118,8 +120,8 @@ __device__ __forceinline__ void tile_phases(f32x4 (&acc)[8][4], Frags& f, const 
         for (int ks = 0; ks < 2; ++ks) f.a[rt][ks] = *reinterpret_cast<const h16x8*>(aB + O + 3 * HT + rt * 2048 + ks * 1024);
     SB();
     if (MODE == 0) {
-        glds16(a0n + voA, stg + O + 1 * HT);
-        glds16(a0n + voA + 64, stg + O + 1 * HT + 1024);
+        glds16(a0n + voA0n, stg + O + 1 * HT);
+        glds16(a0n + voA0n + 64, stg + O + 1 * HT + 1024);
     }
     BAR();
     mfma(IC<1>{}, IC<1>{});
@@ -175,15 +177,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     if (j >= jend) return;                                  // (never with the launcher's grid; all waves leave together)
 
     const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* A2b = reinterpret_cast<const char*>(p.A2);          // second source: columns k >= C1 (C1 % 128 == 0), row stride p.lda2
     const char* Wb = reinterpret_cast<const char*>(p.W);
-    const long long lda2 = 2ll * p.lda, ldw2 = 2ll * p.ldw;
+    const long long lda2 = 2ll * p.lda, ldw2 = 2ll * p.ldw, ldb2 = 2ll * p.lda2;
+    const long long c1b = A2b ? 2ll * p.C1 : (1ll << 60);           // byte offset inside a row where the second source starts
     // staging: this wave fills sub-tiles 2 wave, 2 wave + 1 (the two k-steps of one 16-row group) of every half-tile; a lane lands in
     // (row lane >> 2, chunk lane & 3) of the sub-tile (lane-linear) and fetches the chunk that the read-side swizzle expects there
     const int srow = lane >> 2;
     const int skq = (lane & 3) ^ (((lane >> 5) & 1) << 1);
     const unsigned voA = (unsigned)(((wave >> 2) * 128 + (wave & 3) * 16 + srow) * lda2 + skq * 16);       // + 64 rows: the "1" half
+    const unsigned voA2 = (unsigned)(((wave >> 2) * 128 + (wave & 3) * 16 + srow) * ldb2 + skq * 16);      // the same rows of the second source
     const unsigned voB = (unsigned)(((wave >> 1) * 64 + (wave & 1) * 16 + srow) * ldw2 + skq * 16);        // + 32 rows: the "1" half
-    const long long a_half = 64 * lda2, b_half = 32 * ldw2;
+    const long long a_half = 64 * lda2, a2_half = 64 * ldb2, b_half = 32 * ldw2;
     char* stg = smem + wave * 2048;
     // fragment reads: lane (r = lane & 15, kq = lane >> 4) reads chunk kq ^ (2 if r >= 8) of row r
     const int foff = (lane & 15) * 64 + ((((lane >> 4) ^ (((lane >> 3) & 1) << 1))) << 4);
@@ -194,7 +199,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     int tm, tn;
     tile_coords(j, tiles_m, tiles_n, tm, tn);
     const char* cA = Ab + (long long)tm * G_BM * lda2;     // wave-uniform bases of the current tile's operand panels (k = 0)
+    const char* cA2 = A2b ? A2b + (long long)tm * G_BM * ldb2 : nullptr;
     const char* cB = Wb + (long long)tn * G_BN * ldw2;
+    // source of the A half-tile `half` (0 / 1) at byte offset kb of the tile's rows: (wave-uniform pointer, per-lane offset) - the
+    // first source below C1, the second from C1 on (every k-tile lies inside one source: C1 % 64 == 0)
+    auto a_src = [&](const char* a, const char* a2, long long kb, int half, unsigned& vo) __attribute__((always_inline)) -> const char* {
+        if (kb < c1b) { vo = voA; return a + kb + half * a_half; }
+        vo = voA2;
+        return a2 + (kb - c1b) + half * a2_half;
+    };
     const int T = p.K / BK;                                 // even, >= 2
     // prologue: half-tiles 0..6 = k-tile 0 (B0 A0 B1 A1), k-tile 1 (B0 A0 B1)
     glds16(cB + voB, stg + 0 * HT);                    glds16(cB + voB + 64, stg + 0 * HT + 1024);
@@ -210,17 +223,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     f32x4 acc[8][4];
     Frags f;
     const bool geglu = p.act == BC_ACT_GEGLU;
-    const bool transposed = p.out_mode == BC_OUT_F16_T;
+    const bool all_transposed = p.out_mode == BC_OUT_F16_T;
     const float alpha = scalar_alpha(p);
 
     for (;;) {
         const int jn = j + jstep;
         const bool has_next = jn < jend;                    // (workgroup-uniform)
-        const char *nA = cA, *nB = cB;
+        const char *nA = cA, *nA2 = cA2, *nB = cB;
         int tmn = tm, tnn = tn;
         if (has_next) {
             tile_coords(jn, tiles_m, tiles_n, tmn, tnn);
             nA = Ab + (long long)tmn * G_BM * lda2;
+            nA2 = A2b ? A2b + (long long)tmn * G_BM * ldb2 : nullptr;
             nB = Wb + (long long)tnn * G_BN * ldw2;
         }
 #pragma unroll
@@ -233,10 +247,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             // sources of the k-tiles two and three ahead: this tile's - or, in the last pair, the NEXT tile's k-tiles 0 and 1: the staging
             // stream runs on across the tile boundary (without a next tile it re-reads this tile's head: 7 half-tiles nobody uses)
             const bool last = it == T / 2 - 1;              // (uniform)
-            const char* hA = last ? nA : cA + kb + 256;
+            const char *hA = last ? nA : cA, *hA2 = last ? nA2 : cA2;
+            const long long hk = last ? 0 : kb + 256;       // byte offset of the k-tile two ahead inside ITS tile's rows
             const char* hB = last ? nB : cB + kb + 256;
-            tile_phases<0, 0>(acc, f, aB, bB, stg, cA + a_half + kb + 128, hB, hA, hB + b_half, voA, voB);
-            tile_phases<1, 0>(acc, f, aB, bB, stg, hA + a_half, hB + 128, hA + 128, hB + b_half + 128, voA, voB);
+            unsigned v1, v2, v3, v4;
+            const char* s1 = a_src(cA, cA2, kb + 128, 1, v1);        // A1 of the next k-tile
+            const char* s2 = a_src(hA, hA2, hk, 0, v2);              // A0 two ahead
+            const char* s3 = a_src(hA, hA2, hk, 1, v3);              // A1 two ahead (staged in the second tile's phase 0)
+            const char* s4 = a_src(hA, hA2, hk + 128, 0, v4);        // A0 three ahead
+            tile_phases<0, 0>(acc, f, aB, bB, stg, s1, hB, s2, hB + b_half, v1, v2, voB);
+            tile_phases<1, 0>(acc, f, aB, bB, stg, s3, hB + 128, s4, hB + b_half + 128, v3, v4, voB);
             kb += 256;
         }
         if (wr == 0) BAR();                                 // both groups in step again
@@ -253,6 +273,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         const int wrow = wr * 16 + (lane & 15);             // slab row this lane parks into
         char* wbase = reinterpret_cast<char*>(slab) + wrow * 1024;
         const int wsw = wrow & 7, wc4 = wc * 16 + (lane >> 4);
+        // BcGemm.C_t: the column tiles from n_t0 on go TRANSPOSED into C_t (q | k row-major + V^T for the attention kernel out of one launch)
+        const bool transposed = all_transposed || (p.C_t != nullptr && n0 >= p.n_t0);      // (tile-uniform)
         if (!transposed) {
             const int TSO = geglu ? G_BN / 2 : G_BN;        // output columns of this tile
             const int CPR = TSO / 8;                        // 8-column chunks per row: 32 or 16
@@ -344,7 +366,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                     }
                     const int b = (int)fdiv((unsigned)m, g.div_rpb);
                     const int pix = m - b * (int)g.div_rpb.d;
-                    bc_st16(reinterpret_cast<h16*>(p.C) + ((size_t)b * g.n_out + n) * p.ldc + pix, outraw);
+                    if (all_transposed) bc_st16(reinterpret_cast<h16*>(p.C) + ((size_t)b * g.n_out + n) * p.ldc + pix, outraw);
+                    else bc_st16(reinterpret_cast<h16*>(p.C_t) + ((size_t)b * (p.N - p.n_t0) + (n - p.n_t0)) * p.ldc_t + pix, outraw);
                 }
                 __syncthreads();
             }
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #undef tid
 #undef lane
         if (!has_next) break;
-        j = jn; tm = tmn; tn = tnn; cA = nA; cB = nB;
+        j = jn; tm = tmn; tn = tnn; cA = nA; cA2 = nA2; cB = nB;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the last tile's run-ahead LDS-DMA must have landed before the LDS is given back)
 }
@@ -360,9 +383,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 }  // namespace
 
 int bc_gemm256_ok(const BcGemm& p) {
-    if (p.a_mode != BC_A_DENSE || p.A2 || p.splitk > 1) return 0;
+    if (p.a_mode != BC_A_DENSE || p.splitk > 1) return 0;
+    if (p.A2 && (p.C1 <= 0 || p.C1 % 128 != 0 || p.C1 >= p.K)) return 0;                 // (two sources: every k-tile pair inside one of them)
     if (p.M <= 0 || p.M % G_BM != 0 || p.N % G_BN != 0 || p.K % 128 != 0 || p.K < 128) return 0;
-    if (p.a_affine || p.a_tot1 || p.ln_colsum || p.C_t || p.w_bstride || p.vec_bstride || p.sm_group) return 0;
+    if (p.a_affine || p.a_tot1 || p.ln_colsum || p.w_bstride || p.vec_bstride || p.sm_group) return 0;
+    if (p.C_t) {                                            // row-major columns [0, n_t0) + transposed columns [n_t0, N): plain projections only
+        const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+        if (p.out_mode != BC_OUT_F16 || p.n_t0 <= 0 || p.n_t0 % G_BN != 0 || p.n_t0 >= p.N || p.act != BC_ACT_NONE || p.R || p.R2 || p.gn_tot || p.rowvec ||
+            p.colscale || p.alpha_bstride || rpb % 8 != 0 || p.M % rpb != 0 || p.ldc_t % 8 != 0)
+            return 0;
+    }
     if (p.out_mode == BC_OUT_F16_T) {
         if (p.act != BC_ACT_NONE || p.rowvec || p.colscale || p.R || p.R2 || p.gn_tot || p.alpha_bstride) return 0;
         const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
@@ -371,14 +401,15 @@ int bc_gemm256_ok(const BcGemm& p) {
         return 0;
     }
     // per-lane source offsets are 32-bit: 256 rows of either operand must stay below 4 GiB
-    if (256ll * 2 * std::max(p.lda, p.ldw) >= (1ll << 31)) return 0;
+    if (256ll * 2 * std::max(std::max(p.lda, p.lda2), p.ldw) >= (1ll << 31)) return 0;
     return 1;
 }
 
-extern "C" int bc_gemm256_eligible(int M, int N, int K, int out_mode, int rows_per_batch, int want_gn) {
+extern "C" int bc_gemm256_eligible(int M, int N, int K, int C1, int out_mode, int rows_per_batch, int want_gn) {
     BcGemm p = {};
-    p.a_mode = BC_A_DENSE; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldw = K; p.out_mode = out_mode; p.splitk = 1; p.alpha = 1.0f;
+    p.a_mode = BC_A_DENSE; p.M = M; p.N = N; p.K = K; p.lda = C1 > 0 ? C1 : K; p.ldw = K; p.out_mode = out_mode; p.splitk = 1; p.alpha = 1.0f;
     p.rows_per_batch = rows_per_batch;
+    if (C1 > 0) { p.A2 = reinterpret_cast<const bc_half*>(&p); p.C1 = C1; p.lda2 = K - C1; }     // (only tested for non-null)
     if (want_gn && (rows_per_batch <= 0 || rows_per_batch % G_BM != 0)) return 0;      // a tile's rows must lie inside one image
     return bc_gemm256_ok(p);
 }

@@ -127,12 +127,15 @@ class TrunkPlan:
         (tools/gemm8p_probe.hip, TFLOP/s, gemm_fast's best tile in brackets): [8192 x 10240 x 1280] 903 (673), [8192 x 1280 x 5120]
         957 (571), [8192 x 3840 x 1280] 968, [8192 x 1280 x 1280] 708 (~450; 160 tiles on 256 CUs), [4096 x 1280 x 1280] 392 (80 tiles:
         stays on the 256 x 128 tiles) - hence the tile-count threshold (BC_PLAN g256_min_tiles, default 128)."""
-        if not opt("g256") or kw.get("A2") is not None or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
+        if not opt("g256") or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
             return 0
         if M % 256 or N % 256 or (M // 256) * (N // 256) < opt("g256_min_tiles"):
             return 0
         want_gn = 1 if kw.get("want_gn") else 0
-        ok = self.rec.lib.bc_gemm256_eligible(M, N, K, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, want_gn)
+        c1 = kw.get("C1", 0) if kw.get("A2") is not None else 0
+        if kw.get("C_t") is not None and (kw.get("n_t0", 0) % 256 or kw.get("ldc_t", 0) % 8):
+            return 0
+        ok = self.rec.lib.bc_gemm256_eligible(M, N, K, c1, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, want_gn)
         return _lib.TILE_G256 if ok else 0
 
     def dense(self, x_t, M, K, wname, N, bias=True, out=None, kind="linear", wkey=None, **kw):
@@ -444,11 +447,18 @@ class TrunkPlan:
         h = self.dense(n.t, M, Cc, p + "proj_in", Cc, kind="conv1x1")
         # --- self attention
         ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm1.weight"], pw.f[bp + "norm1.bias"], 1e-5)
-        qk = self.dense(ln, M, Cc, None, 2 * Cc, bias=False, wkey=bp + "attn1.to_qk.weight", kind="qkv")
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
-        self.dense(ln, M, Cc, None, Cc, bias=False, wkey=bp + "attn1.to_v.weight", out=vt, out_mode=_lib.OUT_F16_T,
-                   ldc=ldvt, rows_per_batch=HW, kind="qkv")
+        qkv_kw = dict(C_t=vt, ldc_t=ldvt, n_t0=2 * Cc, rows_per_batch=HW)
+        if self.g256_tile(M, 3 * Cc, Cc, qkv_kw):
+            # q | k row-major + V^T out of ONE launch on the 256 x 256 tiles (480 tiles at M = 8192: two full rounds of the chip instead of
+            # 320 + 160 in three)
+            qk = rec.empty(M, 2 * Cc)
+            rec.gemm(A=ln, W=pw.h[pw.qkv_weight(bp)], M=M, N=3 * Cc, K=Cc, out=qk, tile_cfg=_lib.TILE_G256, kind="qkv", **qkv_kw)
+        else:
+            qk = self.dense(ln, M, Cc, None, 2 * Cc, bias=False, wkey=bp + "attn1.to_qk.weight", kind="qkv")
+            self.dense(ln, M, Cc, None, Cc, bias=False, wkey=bp + "attn1.to_v.weight", out=vt, out_mode=_lib.OUT_F16_T,
+                       ldc=ldvt, rows_per_batch=HW, kind="qkv")
         a = rec.empty(M, Cc)
         rec.attention(qk, qk, vt, a, B, self.heads, d, HW, HW, 2 * Cc, 2 * Cc, ldvt, Cc, HW * 2 * Cc, HW * 2 * Cc,
                       Cc * ldvt, HW * Cc, scale, q_off=0, k_off=Cc)
@@ -465,10 +475,18 @@ class TrunkPlan:
         # --- GEGLU feed-forward
         ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm3.weight"], pw.f[bp + "norm3.bias"], 1e-5)
         g = self.dense(ln, M, Cc, bp + "ff.net.0.proj", 8 * Cc, act=_lib.ACT_GEGLU, kind="ff")
+        r2kw = self._r2(r2, x.H, x.W)
+        fused_kw = dict(A2=h, C1=4 * Cc, lda=4 * Cc, lda2=Cc, R=x.t, ldr=Cc, rows_per_batch=HW, want_gn=True, **r2kw)
+        if self.g256_tile(M, Cc, 5 * Cc, fused_kw):
+            # ff.net.2 + residual + proj_out as ONE two-source GEMM over [g | h] with the pack-time product [P F2 | P] (weights.ff2_proj_out,
+            # as on gemm_wreg.hip at M <= 1024): a dependent launch and the h round trip less
+            k = pw.ff2_proj_out(p)
+            out = rec.empty(M, Cc)
+            rec.gemm(A=g, W=pw.h[k + ".weight"], M=M, N=Cc, K=5 * Cc, out=out, bias=pw.f[k + ".bias"], tile_cfg=_lib.TILE_G256, kind="ff", **fused_kw)
+            return Act(out, Cc, x.H, x.W), None
         h = self.dense(g, M, 4 * Cc, bp + "ff.net.2", Cc, R=h, ldr=Cc, kind="ff")
         # --- proj_out + residual (+ BlobNet residual)
-        out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True,
-                         **self._r2(r2, x.H, x.W))
+        out = self.dense(h, M, Cc, p + "proj_out", Cc, R=x.t, ldr=Cc, kind="conv1x1", rows_per_batch=HW, want_gn=True, **r2kw)
         return Act(out, Cc, x.H, x.W), None
 
     # ------------------------------------------------------------------------------------------- prologue

@@ -483,9 +483,9 @@ class Recorder:
                     self.register(t)
         elif tile_cfg == _lib.TILE_G256:
             # large-M dense projection on 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups (gemm256.hip)
-            assert not conv and A2 is None and a_affine is None and splitk in (None, 1)
+            assert not conv and a_affine is None and splitk in (None, 1)
             cfg, sk, bm, bn = tile_cfg, 1, 256, 256
-            fast, mode = True, "g256"
+            fast, mode = True, "g256" + ("_qkv" if C_t is not None else "") + ("_2src" if A2 is not None else "")
         else:
             assert a_affine is None and (not conv or A2 is None), "fused GroupNorm prologue / two-source conv need TILE_HALO / TILE_WREG"
             cfg, sk, bm, bn = self.plan_gemm(M, N, K, fast, mode, tile_cfg, splitk)

@@ -166,6 +166,14 @@ class PackedTrunk:
             self.f[k + ".bias"] = (P @ self.f[bp + "ff.net.2.bias"].float() + self.f[p + "proj_out.bias"].float()).contiguous()
         return k
 
+    def qkv_weight(self, bp: str) -> str:
+        """Key of attn1's to_q | to_k | to_v as ONE row-concatenated matrix [3C][C] (round 6: one BC_TILE_G256 launch writes q | k row-major
+        and V^T through BcGemm.C_t; attention_processor.py:2191-2196)."""
+        k = bp + "attn1.to_qkv.weight"
+        if k not in self.h:
+            self.h[k] = torch.cat([self.h[bp + "attn1.to_qk.weight"], self.h[bp + "attn1.to_v.weight"]], 0).contiguous()
+        return k
+
     def ctx_fold_weights(self, bp: str):
         """What bc_ctx_fold multiplies the projected prompt with (block prefix `bp` = "...transformer_blocks.0."): (wq = fp16 of
         attn2.to_q.weight diag(gamma of norm2) [C][C], bq = to_q.weight . beta of norm2 fp32 [C], wo = attn2.to_out.0.weight [C][C] as stored) -

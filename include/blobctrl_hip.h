@@ -151,8 +151,8 @@ enum { BC_TILE_AUTO = 0, BC_TILE_256x128 = 1, BC_TILE_128x128_S3 = 2, BC_TILE_12
         * activation).  Never chosen by BC_TILE_AUTO (bc_gemm_wreg_eligible). */
        BC_TILE_GW64x128 = 10, BC_TILE_GW64x256 = 11, BC_TILE_GW64x320 = 12,
        /* large-M dense projections (gemm256.hip, round 6): 256 x 256 tiles, 8 waves, the 8-phase LDS-DMA pipeline, persistent workgroups
-        * (grid = min(tiles, CUs), the next tile's first loads under this tile's epilogue).  Dense single-source A, M % 256 == 0,
-        * N % 256 == 0, K % 128 == 0, no split-K; the whole shared epilogue (bias, row vector, GEGLU / GELU / SiLU, scales, residual,
+        * (grid = min(tiles, CUs), the next tile's first loads under this tile's epilogue).  Dense A (one source, or two split at
+        * C1 % 128 == 0), M % 256 == 0, N % 256 == 0, K % 128 == 0, no split-K; the whole shared epilogue (bias, row vector, GEGLU / GELU / SiLU, scales, residual,
         * BlobNet right-half residual, GroupNorm statistics totals when rows_per_batch % 256 == 0) for BC_OUT_F16, bias + alpha for
         * BC_OUT_F16_T.  Replaces, at batch >= 2, the Linear / 1 x 1 layers of the 1280-channel transformer blocks
         * (attention.py:1161-1167, attention_processor.py:2191-2224, transformer_2d.py:479-527).  Never chosen by BC_TILE_AUTO
@@ -165,9 +165,10 @@ int bc_gemm_wreg_pack(const bc_half* w, int ldw, int N, int K, int tile_cfg, bc_
 long long bc_gemm_wreg_stream_elems(int N, int K);
 /* 1 when a dense projection (C1 > 0: two-source A split at C1) can run on the given BC_TILE_GW* configuration. */
 int bc_gemm_wreg_eligible(int M, int N, int K, int C1, int tile_cfg);
-/* 1 when a dense single-source projection can run on BC_TILE_G256 (out_mode BC_OUT_F16 / BC_OUT_F16_T; want_gn = 1: the launch also
- * produces GroupNorm statistics totals, which needs a tile's 256 rows inside one image). */
-int bc_gemm256_eligible(int M, int N, int K, int out_mode, int rows_per_batch, int want_gn);
+/* 1 when a dense projection (C1 > 0: two-source A split at C1, C1 % 128 == 0) can run on BC_TILE_G256 (out_mode BC_OUT_F16 / BC_OUT_F16_T;
+ * want_gn = 1: the launch also produces GroupNorm statistics totals, which needs a tile's 256 rows inside one image).  BC_TILE_G256 also
+ * takes C_t / ldc_t / n_t0 (n_t0 % 256 == 0: the column tiles from n_t0 on are written transposed, plain projections only). */
+int bc_gemm256_eligible(int M, int N, int K, int C1, int out_mode, int rows_per_batch, int want_gn);
 /* Re-order a 3x3 weight matrix w[N][9 * Cin] (k = (ky * 3 + kx) * Cin + c; N % 160 == 0, Cin % 64 == 0) into the per-wave fragment
  * streams of BC_TILE_WREG (same size, out of place): per 160-column block, per (column group 3|2|2|3 tiles, K half of the 64-channel
  * chunk) one contiguous stream [chunk][kx][ky][tile][64 lanes][8]; lane l holds w[n0 + 16 tile + (l & 15)][k0 + 8 (l >> 4) .. + 8]. */

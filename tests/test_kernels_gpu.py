@@ -949,15 +949,19 @@ def test_cross_attention_as_two_folded_projections(rec, rows, T, Cc):
 
 
 # ---------------------------------------------------------------------------------------------------- BC_TILE_G256 (gemm256.hip, round 6)
-@pytest.mark.parametrize("mode", ["plain", "geglu", "gelu_alpha", "res_r2_gn", "transposed", "rowscale"])
+@pytest.mark.parametrize("mode", ["plain", "geglu", "gelu_alpha", "res_r2_gn", "transposed", "rowscale", "qkv", "two_source"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (1024, 512, 256), (9728, 2560, 384)])
 def test_gemm256_modes(rec, mode, M, N, K):
     """The 256 x 256 / 8-wave / 8-phase LDS-DMA GEMM against fp32 torch on the fp16-rounded operands: every epilogue mode the plan uses it
     with, at tile counts from 1 (one workgroup, two k-tiles: prologue + drain only) to 360 (persistent workgroups that take a second
     tile while the first one's epilogue runs; the 9 x 4-row grouped tile order with a ragged last group of 2 row tiles)."""
     from blobctrl_amd import _lib
-    if M == 9728 and mode not in ("plain", "res_r2_gn", "geglu"):
-        pytest.skip("the large case runs the three modes that differ in the persistent epilogue")
+    if M == 9728 and mode not in ("plain", "res_r2_gn", "geglu", "qkv", "two_source"):
+        pytest.skip("the large case runs the modes that differ in the persistent staging / epilogue")
+    if mode == "qkv" and N < 512:
+        pytest.skip("q | k | V^T needs at least two column tiles")
+    if mode == "two_source" and K < 256:
+        pytest.skip("two sources need at least one k-tile pair each")
     B = 2 if M % 512 == 0 else 1
     rows = M // B
     A = g(1, M, K) * 1.3 + 0.2
@@ -992,10 +996,26 @@ def test_gemm256_modes(rec, mode, M, N, K):
         out = torch.zeros(B, N, ldc, dtype=torch.float16, device="cuda")
         kw.update(out_mode=_lib.OUT_F16_T, ldc=ldc, rows_per_batch=rows)
         ref = ref.view(B, rows, N).permute(0, 2, 1)
-    assert rec.lib.bc_gemm256_eligible(M, N, K, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, 1 if kw.get("want_gn") else 0)
-    res = run(rec, lambda: rec.gemm(A=h(A), W=h(W), M=M, N=N, K=K, out=out if out is not None else rec.empty(M, n_out), bias=b.cuda(),
+    vt, n_t0 = None, 0
+    if mode == "qkv":                                               # the last 256 columns transposed into C_t, the others row-major (ldc = n_t0)
+        n_t0, ldvt = N - 256, rows + 64
+        vt = torch.zeros(B, 256, ldvt, dtype=torch.float16, device="cuda")
+        kw.update(C_t=vt, ldc_t=ldvt, n_t0=n_t0, rows_per_batch=rows)
+        n_out = n_t0
+    Ad, c1 = h(A), 0
+    if mode == "two_source":                                        # columns k >= C1 from a second tensor with its own row stride
+        c1 = 128 if K == 256 else (K // 256) * 128
+        Ad = h(A[:, :c1].contiguous())
+        kw.update(A2=h(A[:, c1:].contiguous()), C1=c1, lda=c1, lda2=K - c1)
+    assert rec.lib.bc_gemm256_eligible(M, N, K, c1, kw.get("out_mode", _lib.OUT_F16), kw.get("rows_per_batch", 0) or M, 1 if kw.get("want_gn") else 0)
+    res = run(rec, lambda: rec.gemm(A=Ad, W=h(W), M=M, N=N, K=K, out=out if out is not None else rec.empty(M, n_out), bias=b.cuda(),
                                     tile_cfg=_lib.TILE_G256, **kw))
     assert rec.seg.meta[-1]["rocprof"] == "gemm256_kernel"
+    if mode == "qkv":
+        close(res, ref[:, :n_t0], what=f"gemm256 q | k part {M}x{N}x{K}")
+        close(vt[:, :, :rows], ref[:, n_t0:].view(B, rows, 256).permute(0, 2, 1), what=f"gemm256 V^T part {M}x{N}x{K}")
+        assert float(vt[:, :, rows:].abs().max()) == 0.0
+        return
     if mode == "transposed":
         close(res[:, :, :rows], ref, what=f"gemm256 transposed {M}x{N}x{K}")
         assert float(res[:, :, rows:].abs().max()) == 0.0

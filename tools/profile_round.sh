@@ -10,9 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof${TAG:+_$TAG}
 rm -rf $OUT && mkdir -p $OUT
-B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-configs --table $EXTRA"
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-configs --no-calibration --table $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $B > $OUT/stats_bench.json 2> $OUT/stats.log
-P="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-configs --denoise-steps 2 $EXTRA"
+P="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-e2e --no-configs --no-calibration --denoise-steps 2 $EXTRA"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- $P > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- $P > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE -d $OUT/pmc_mfma -o m --output-format csv -- $P > /dev/null 2> $OUT/pmc_mfma.log
