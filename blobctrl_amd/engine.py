@@ -516,14 +516,24 @@ class TrunkPlan:
                 self.ctx_folded[bp] = rec.ctx_fold(ck, cvt, B, T, Cc, ldvt, self.heads, (Cc // self.heads) ** -0.5, wq, bq, wo)
 
     # ------------------------------------------------------------------------------------------- per-edit weight collapse
-    def record_collapse(self, feat16: torch.Tensor):
+    def record_collapse(self, feat16: torch.Tensor, per_image: int = 0):
         """BlobNet conv_in over the F feature channels, which are score x f (rank 1, pipe:706-721, SURVEY 8a note iii):
         g[o, tap] = sum_c W[o, 5+c, tap] * f_c is computed once per edit (one GEMV on the MFMA path) and written into input
         channel 5 of an 8-channel conv_in weight; the step then convolves [latents(4), score, score, 0, 0] - as a dense K = 128
-        GEMM over the im2col operand that bc_assemble_input_im2col writes (weight [co][128], k = tap * 8 + channel)."""
+        GEMM over the im2col operand that bc_assemble_input_im2col writes (weight [co][128], k = tap * 8 + channel).
+        `per_image` = B (round 6): a batch of B independent requests has B feature vectors, hence B collapsed weights - one GEMV per
+        image into its own copy of the 8-channel weight, and conv_in then runs as B launches of one image each (record_forward) instead
+        of ONE 1029-channel convolution over the batch: 390 GFLOP per step (K = 9288, off the LDS-DMA fast path) become 8 x 0.7 GFLOP."""
         pw = self.pw
         w8 = pw.h["conv_in.weight8"]
         fm = pw.h["conv_in.featmat"]
+        if per_image:
+            # (a plan-owned copy per image, saved WITH its contents by bc_plan_save: channels 0-4 of the weight are constants)
+            self.w8_img = self.rec.register(w8.unsqueeze(0).repeat(per_image, 1, 1).contiguous())
+            self.rec.keep.append(self.w8_img)
+            for b in range(per_image):
+                self.rec.gemm(A=fm, W=feat16[b:b + 1], M=fm.shape[0], N=1, K=fm.shape[1], out=self.w8_img[b], ldc=8, out_offset=5, kind="collapse")
+            return
         self.rec.gemm(A=fm, W=feat16, M=fm.shape[0], N=1, K=fm.shape[1], out=w8, ldc=8, out_offset=5, kind="collapse")
 
     # ------------------------------------------------------------------------------------------- time embedding
@@ -635,7 +645,18 @@ class TrunkPlan:
         conv_in_name = "conv_in"
         if not im2col and x_in.shape[-1] == 8 and pad8(cfg.in_channels) > 8:
             raise ValueError("the rank-1-collapsed BlobNet input is consumed in its im2col form (bc_assemble_input_im2col, im2col=True)")
-        if im2col:
+        if im2col and getattr(self, "w8_img", None) is not None:
+            # per-request batch (record_collapse per_image): one launch per image with that image's collapsed weight; the statistics totals
+            # of the output are one table over the batch, every launch adding to its own image's rows
+            def conv_in(r2=None):
+                assert r2 is None                              # (BlobNet takes no residuals)
+                out_all, tot = self.rec.empty(self.B, H * W, boc[0]), self.rec.new_tot(self.B, boc[0])
+                for b in range(self.B):
+                    self.rec.gemm(A=x_in[b], W=self.w8_img[b], M=H * W, N=boc[0], K=128, out=out_all[b], bias=pw.f["conv_in.bias"],
+                                  rows_per_batch=H * W, kind="conv_in", want_gn=True, gn_tot_out=tot[b:b + 1])
+                self.rec.tots[out_all.data_ptr()] = tot
+                return Act(out_all, boc[0], H, W)
+        elif im2col:
             wkey = "conv_in.weight8" if pad8(cfg.in_channels) > 8 else "conv_in.weight_k128"
             conv_in = lambda r2=None: self.conv_in_dense(x_in, wkey, r2)
         else:

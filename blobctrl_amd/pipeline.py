@@ -115,16 +115,17 @@ class BlobCtrlEngine:
         P.eps_guided = rec.zeros(B, 4, h, w, dtype=f32, name="eps_guided")
         P.guidance = [7.5]
 
-        # rank-1 collapse of the BlobNet feature channels (per-edit weight): not for per-request batches (one weight per launch)
+        # rank-1 collapse of the BlobNet feature channels (per-edit weight; round 6: per-IMAGE weights for a batch of independent requests -
+        # conv_in then runs as one launch per image, engine.record_collapse)
         no_im2col = False
-        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not per_request and not no_im2col
+        P.collapse = F > 3 and "conv_in.featmat" in self.blob_w.h and not no_im2col
         unet_cin = pad8(self.unet_cfg.in_channels)
         blob_cin = 8 if P.collapse else pad8(self.blob_cfg.in_channels)
         # 8-channel inputs (the UNet's 4 latents + score; BlobNet's rank-1-collapsed 4 latents + 2 x score) are assembled directly as
         # the 3x3 im2col operand [rows][128] of conv_in, which then runs as a dense GEMM on the LDS-DMA fast path (K = 72 does not)
         P.unet_im2col = unet_cin == 8 and not no_im2col
         P.blob_im2col = P.collapse
-        P.feat16 = rec.zeros(1, pad8(max(F, 1)), name="feat16")
+        P.feat16 = rec.zeros(Bi, pad8(max(F, 1)), name="feat16")
         P.blob_in = rec.zeros(B, H * W, 128 if P.blob_im2col else blob_cin)
         P.unet_in = rec.zeros(2 * B, H * W, 128 if P.unet_im2col else unet_cin)
 
@@ -134,7 +135,7 @@ class BlobCtrlEngine:
         unet_a.record_context(P.ctx, T)
         blob = TrunkPlan(rec, self.blob_w, self.blob_cfg, B, H, W)
         if P.collapse:
-            blob.record_collapse(P.feat16)
+            blob.record_collapse(P.feat16, per_image=B if per_request else 0)
         # time-embedding path of every step, once per edit (read in the step through the device step counter)
         temb_per_step = False                                # (the per-edit table replaced the four launches per net inside every step)
         if not temb_per_step:
@@ -199,7 +200,7 @@ class BlobCtrlEngine:
         rec.sid = 1
         rec.wait(fork)
         if P.blob_im2col:
-            rec.call("bc_assemble_input_im2col", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(), 1, B, h, w, 1,
+            rec.call("bc_assemble_input_im2col", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(), Bi, B, h, w, 1,
                      P.blob_in.data_ptr(), kind="assemble")
         else:
             rec.call("bc_assemble_input", P.latents.data_ptr(), B, P.fg_lat.data_ptr(), P.fg_score.data_ptr(),
