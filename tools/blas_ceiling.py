@@ -2,7 +2,9 @@
 hipBLASLt / rocBLAS, fp16 in, fp32 accumulate, random-normal operands - power-limited clocks make zeros / constants meaningless)."""
 import torch
 dev = torch.device("cuda:0")
-for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 2560, 320), (16384, 5120, 640), (4096, 5120, 640)]:
+for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 2560, 320), (16384, 5120, 640), (4096, 5120, 640),
+                  # (round 6) the shapes csrc/gemm256.hip runs in the batch-8 plan (tools/gemm8p_probe.hip on the same box)
+                  (8192, 10240, 1280), (8192, 1280, 5120), (8192, 1280, 1280), (8192, 3840, 1280), (4096, 10240, 1280), (9216, 10240, 1280), (8192, 1280, 6400)]:
     A = torch.randn(M, K, device=dev, dtype=torch.float16) * 1.0
     B = torch.randn(N, K, device=dev, dtype=torch.float16) * 0.05
     for _ in range(5):

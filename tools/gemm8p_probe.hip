@@ -292,7 +292,7 @@ int main(int argc, char** argv) {
     run<0>(1024, 768, 128, 5, true);
     run<0>(2048, 1280, 1280, 5, true);
     const int shapes[][3] = {{4096, 4096, 4096}, {8192, 8192, 8192}, {8192, 10240, 1280}, {8192, 1280, 5120}, {8192, 1280, 1280}, {8192, 3840, 1280},
-                             {4096, 10240, 1280}, {4096, 1280, 1280}, {16384, 5120, 640}, {9216, 10240, 1280}, {2048, 10240, 1280}, {2048, 1280, 5120}};
+                             {4096, 10240, 1280}, {4096, 1280, 1280}, {16384, 5120, 640}, {9216, 10240, 1280}, {2048, 10240, 1280}, {2048, 1280, 5120}, {8192, 1280, 6400}};
     for (auto& sh : shapes) run<0>(sh[0], sh[1], sh[2], 20, false);
     return 0;
 }
