@@ -488,7 +488,7 @@ def roofline(pipe, plan, res=512, batch=1):
 
 # Reference readings of the two calibration probes (the box profiles/r6_bench_final.json was taken on): a box's speed index is the mean
 # of its two ratios to these
-CAL_REF = {"gemm_8192_tflops": 1263.0, "attn_l0_us": 170.0}
+CAL_REF = {"gemm_8192_tflops": 1385.0, "attn_l0_us": 217.0}
 
 
 def box_calibration(dev, seconds=1.0):
