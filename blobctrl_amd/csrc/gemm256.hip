@@ -33,6 +33,7 @@
 // Eligibility (bc_gemm256_eligible): dense A, M % 256 == 0, N % 256 == 0, K % 128 == 0, no split-K.
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 #include "gemm_common.h"
 
 using namespace bcg;
@@ -49,6 +50,41 @@ constexpr int KBUF = 4 * HT;           // one k-tile: [B0][A0][B1][A1]
 constexpr int STG_BYTES = 2 * KBUF;    // 128 KiB of staging
 constexpr int SLAB_BYTES = 32768;      // epilogue slab: 32 rows x 256 fp32
 constexpr int G_LDS = STG_BYTES + SLAB_BYTES;
+
+// LDS visibility only (the epilogue's slab): a __syncthreads() also waits vmcnt(0) - i.e. for the previous pass's global STORES to be
+// acknowledged and for the next tile's run-ahead LDS-DMA: ~1 us per pass, 8 passes per tile (tools/g256_probe.py: 42.6 -> 35 us per K = 1280 tile)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Epilogue read-back of a wave's slab slice, as inline assembly: a compiler-visible LDS read with the next tile's run-ahead LDS-DMA in flight gets an
+// s_waitcnt vmcnt(0) in front of it (the DMA's destination and the slab come from one shared array: "may alias"), which parks the epilogue until all
+// seven half-tiles have landed.  lds_wait4 ties the four results to the wait, so that no use can be scheduled above it.
+__device__ __forceinline__ f32x4 lds_read16_raw(const char* p) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lptr_t)p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+// The residual rows of the unrolled residual form, likewise: the compiler's own count for them became vmcnt(0) - the previous row-tile's stores
+// included - once the read-back above was assembly.  Issue order per row-tile: wait, finish, the NEXT row-tile's two loads, this one's two stores;
+// so vmcnt(2) at the next wait leaves exactly those stores in flight (row-tile 0: nothing was stored yet, vmcnt(0)).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld16_raw(const void* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait2(u32x4& a, u32x4& b) {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+    else asm volatile("s_waitcnt vmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+}
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
@@ -139,6 +175,109 @@ __device__ __forceinline__ void tile_phases(f32x4 (&acc)[8][4], Frags& f, const 
     BAR();
 }
 
+// The GEMM family's 8-column epilogue (gemm_common.h epi8_store) for this kernel, whose 256 x 256 tile has 128 outputs per thread and whose
+// epilogue time is VALU issue + one exposed memory round trip (in-kernel stamps, -DBC_DIAGNOSTICS: 28.6k of a K = 1280 tile's 85k cycles before
+// this form).  Differences, none of them in the arithmetic's order per output except the bias: (i) the BIAS is the accumulators' initial value
+// (record: acc = b; acc += a w), so no bias load sits in the epilogue - vmcnt is in-order, and a load issued there waits behind the next
+// tile's seven run-ahead half-tiles; (ii) column scales and GroupNorm statistics cost nothing when the launch does not use them
+// (launch-uniform flags); (iii) the residual rows of a pass are requested before any of its arithmetic.
+// LD: which global LOADS the pass loop may hold (the compiler's s_waitcnt insertion is exact in straight-line code, and falls back to vmcnt(0) -
+// every store of the pass before and the whole run-ahead of the next tile - where a load sits under a branch: that alone was 2/3 of this epilogue):
+// 0 none (bias / activation / scales / statistics), 1 the residual R (requested one pass ahead), 2 all of them (row vector, R2, per-batch alpha).
+// ACTK: the activation known at compile time (0 none, 1 GEGLU) or 2 = the launch's (run-time chain).
+template <int LD, int ACTK>
+__device__ __forceinline__ uint4 epi8_finish(const GemmArgs& g, int n_first, const float alpha, float (&v)[8], const float (&gt)[8], int m, float (&gs)[8],
+                                            float (&gq)[8], const uint4 rraw, const bool scaled, const bool stats) {
+    const BcGemm& p = g.p;
+    int b = 0, pix = m;
+    if (LD == 2 && (p.rowvec || p.R2 || p.alpha_bstride > 0)) {
+        b = (int)fdiv((unsigned)m, g.div_rpb);
+        pix = m - b * (int)g.div_rpb.d;
+    }
+    if (LD == 2 && p.rowvec) {
+        const uint4 raw = bc_ld16(rowvec_base(p) + (size_t)b * p.ld_rowvec + n_first);
+        const h16* rh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+    }
+    if (ACTK == 0) {
+    } else if (ACTK == 1 || p.act == BC_ACT_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = bc_gelu_f2((f32x2){gt[j], gt[j + 1]});
+            v[j] *= gl.x;
+            v[j + 1] *= gl.y;
+        }
+    } else if (p.act == BC_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = bc_gelu_f2((f32x2){v[j], v[j + 1]});
+            v[j] = gl.x;
+            v[j + 1] = gl.y;
+        }
+    } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+    } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
+    }
+    if (scaled) {                                           // column scales (LD 2 only: a load) x the launch's scalar alpha
+        if (LD == 2 && p.colscale) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= p.colscale[n_first + j] * alpha;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= alpha;
+        }
+    }
+    if (LD == 2 && p.alpha_bstride > 0) {
+        const float ab = batch_alpha(g, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= ab;
+    }
+    if (LD == 1 || (LD == 2 && p.R)) {
+        const h16* rh = reinterpret_cast<const h16*>(&rraw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+    }
+    if (LD == 2 && p.R2) {
+        const int y = (int)fdiv((unsigned)pix, g.div_outw);
+        const int x = pix - y * (int)g.div_outw.d;
+        if (x >= p.r2_xmin) {
+            int bmod = p.r2_bmod;                           // (laundered: the reciprocal of a hoisted modulus would stay live across the k-loop)
+            asm volatile("" : "+s"(bmod));
+            const int bb = b % bmod;
+            const uint4 raw = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)bb * g.div_rpb.d + pix) * p.ldr2 + n_first);
+            const h16* rh = reinterpret_cast<const h16*>(&raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+        }
+    }
+    uint4 outraw;
+    h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
+    if (stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)o[j];
+            gs[j] += f;
+            gq[j] += f * f;
+        }
+    }
+    return outraw;
+}
+
+// acc[i][0..3] for a RUN-TIME (wave-uniform) pass index i: an if-chain over compile-time indices (scalar branches), so that the
+// accumulators keep static register numbers while the epilogue's pass loop stays a real loop.  Unrolled eight times the epilogue was 60 KB of
+// code - the kernel 82 KB against a 64 KB instruction cache - and cost 13-14 us per tile whatever it did (K sweep, tools/g256_probe.py).
+__device__ __forceinline__ void acc_row(const f32x4 (&acc)[8][4], int i, f32x4 (&w)[4]) {
+#define BC_ROW(I) if (i == I) { w[0] = acc[I][0]; w[1] = acc[I][1]; w[2] = acc[I][2]; w[3] = acc[I][3]; }
+    BC_ROW(0) else BC_ROW(1) else BC_ROW(2) else BC_ROW(3) else BC_ROW(4) else BC_ROW(5) else BC_ROW(6) else BC_ROW(7)
+#undef BC_ROW
+}
+
 // tile index -> (row tile, column tile): runs of 4 row tiles walk the columns, so that consecutive ids share operand panels
 __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
     constexpr int GM = 4;
@@ -154,6 +293,15 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
     }
 }
 
+// GEN: false = the three unrolled epilogue forms of the large projections (plain / GEGLU / residual), true = the rolled general form; two code
+// objects because together the forms' tile-invariant values do not fit the 64 registers the accumulators and fragments leave across the k-loop.
+__host__ __device__ inline bool g256_general(const BcGemm& p) {
+    if (p.rowvec || p.R2 || p.alpha_bstride > 0 || p.colscale || p.gn_tot) return true;
+    if (p.act == BC_ACT_NONE) return false;
+    return !(p.act == BC_ACT_GEGLU && !p.R);
+}
+
+template <bool GEN>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const BcGemm& p = g.p;
@@ -222,11 +370,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     f32x4 acc[8][4];
     Frags f;
-    const bool geglu = p.act == BC_ACT_GEGLU;
-    const bool all_transposed = p.out_mode == BC_OUT_F16_T;
-    const float alpha = scalar_alpha(p);
+    const float alpha = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(scalar_alpha(p))));      // (an SGPR: launch-uniform, live across the k-loop)
+    // launch-uniform epilogue flags as ONE scalar, decoded inside the tile loop from a laundered copy (as booleans they are three SGPR pairs live
+    // across the k-loop, and the allocator parks what does not fit in vector registers): GEGLU | transposed output | scaled (the per-column
+    // scale multiply of the epilogue is skipped otherwise)
+    const int eflags = __builtin_amdgcn_readfirstlane((p.act == BC_ACT_GEGLU ? 1 : 0) | (p.out_mode == BC_OUT_F16_T ? 2 : 0) | ((p.colscale != nullptr || alpha != 1.0f) ? 4 : 0));
 
+#ifdef BC_DIAGNOSTICS
+    unsigned long long* const stamps = g.halo_stamps;       // [workgroup][tile < 4][16]: tile start, k-loop done, epilogue done (s_memtime of wave 0)
+    int tile_no = 0;
+#define G256_STAMP(k) do { if (stamps && threadIdx.x == 0 && tile_no < 4) stamps[((size_t)blockIdx.x * 4 + tile_no) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G256_STAMP(k) do { } while (0)
+#endif
     for (;;) {
+        G256_STAMP(0);
         const int jn = j + jstep;
         const bool has_next = jn < jend;                    // (workgroup-uniform)
         const char *nA = cA, *nA2 = cA2, *nB = cB;
@@ -237,10 +395,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             nA2 = A2b ? A2b + (long long)tmn * G_BM * ldb2 : nullptr;
             nB = Wb + (long long)tnn * G_BN * ldw2;
         }
+        // accumulators start at the BIAS of their four columns (epi8_finish i): lane (lane >> 4) owns columns 64 wc + 32 (jj >> 1) + 16 (jj & 1) + 4 (lane >> 4) ..+4
+        const float* bias_e = p.bias;                       // (laundered: the hoisted null test is one more boolean across the k-loop)
+        asm volatile("" : "+s"(bias_e));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int jj = 0; jj < 4; ++jj) {
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bias_e) bv = *reinterpret_cast<const f32x4*>(bias_e + tn * G_BN + wc * 64 + (jj >> 1) * 32 + (jj & 1) * 16 + 4 * (lane >> 4));
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 8; ++i) acc[i][jj] = bv;
+        }
         if (wr == 1) BAR();                                 // the second wave group runs one barrier behind the first
         long long kb = 0;                                   // byte offset of the pair's first k-tile inside a row
         for (int it = 0; it < T / 2; ++it) {
@@ -260,15 +424,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             kb += 256;
         }
         if (wr == 0) BAR();                                 // both groups in step again
+        G256_STAMP(1);
 
         // ------------------------------------------------------------------------------------------------ epilogue of tile (tm, tn)
         // (lane-derived epilogue addresses come from a laundered thread id: they are tile-invariant, and hoisted out of the tile loop they
         //  would stay live across the k-loop, where the 192 accumulator + fragment registers leave no room for them)
-        int tid_e = threadIdx.x;
-        asm volatile("" : "+v"(tid_e));
+        // (the id itself is rebuilt from the wave number, an SGPR, and the lane count - keeping threadIdx.x alive across the k-loop costs the
+        //  register that tips the kernel into scratch)
+        int tid_e;                                          // (volatile: the lane count itself must not be hoisted out of the tile loop either)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_e));
+        tid_e |= wave << 6;
 #define tid tid_e
         const int lane_e = tid_e & 63;
 #define lane lane_e
+        int ef = eflags;
+        asm volatile("" : "+s"(ef));
+        const bool geglu = ef & 1, all_transposed = ef & 2, scaled = ef & 4;
         const int m0 = tm * G_BM, n0 = tn * G_BN;
         const int wrow = wr * 16 + (lane & 15);             // slab row this lane parks into
         char* wbase = reinterpret_cast<char*>(slab) + wrow * 1024;
@@ -276,104 +447,179 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         // BcGemm.C_t: the column tiles from n_t0 on go TRANSPOSED into C_t (q | k row-major + V^T for the attention kernel out of one launch)
         const bool transposed = all_transposed || (p.C_t != nullptr && n0 >= p.n_t0);      // (tile-uniform)
         if (!transposed) {
-            const int TSO = geglu ? G_BN / 2 : G_BN;        // output columns of this tile
-            const int CPR = TSO / 8;                        // 8-column chunks per row: 32 or 16
-            const int col8 = tid & (CPR - 1);
-            const int c_out = col8 * 8;
-            const int n_first = (geglu ? n0 / 2 : n0) + c_out;
-            const int cv = geglu ? (c_out >> 5) * 64 + (c_out & 31) : c_out;      // tile column of the (value) accumulators
-            const int nitem = geglu ? 1 : 2;
-            Cols8 cols;
-            cols8_init(g, cols, n_first, n0 + cv, geglu, alpha);
+            // Row-major tiles leave through WAVE-PRIVATE slices of the slab - no workgroup barrier in the epilogue (round 6: the two barriers per
+            // 32-row pass of the shared-slab form, the waits they made every wave inherit and the run-time accumulator select were 20k of a tile's
+            // cycles; this form is bounded by the LDS round trip alone).  Per accumulator row-tile i a wave parks its 16 x 64 fp32 block (4 KB,
+            // 16-byte chunks XOR-swizzled by the row: reads and writes both spread evenly over the banks), and reads it back as
+            // lane -> (row lane >> 2, the 8 columns (lane & 3) * 8 and the 8 columns 32 further): with GEGLU those are a value chunk and its gate,
+            // otherwise two output chunks; a store instruction then covers 64 contiguous bytes of each of 16 rows.
+            char* const ws = reinterpret_cast<char*>(slab) + wave * 4096;
+            char* const wrowp = ws + (lane & 15) * 256;
+            const int wx = lane & 15, wq = lane >> 4;
+            // read-back: one 8-column output chunk per lane - GEGLU: (row lane >> 2, value chunk lane & 3 and its gate 32 columns further), 16 rows at once;
+            // otherwise (row lane >> 3, chunk lane & 7), the block's rows 0..7 and 8..15 in two sub-passes
+            const int nsub = geglu ? 1 : 2;
+            const int rrow = geglu ? lane >> 2 : lane >> 3;
+            const int rc = geglu ? (lane & 3) * 2 : (lane & 7) * 2;
+            const int n_first = geglu ? n0 / 2 + wc * 32 + (lane & 3) * 8 : n0 + wc * 64 + (lane & 7) * 8;
+            const int mrow = m0 + wr * 128 + rrow;
+            const bool stats = p.gn_tot != nullptr;
             float gs[8], gq[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { gs[q] = 0.f; gq[q] = 0.f; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    *reinterpret_cast<f32x4*>(wbase + (((wc4 + (jj >> 1) * 8 + (jj & 1) * 4) ^ wsw) << 4)) = acc[i][jj];
-                __syncthreads();
-                for (int c = 0; c < nitem; ++c) {
-                    const int rl = (tid + 512 * c) / CPR;                          // slab row 0..31
-                    const int m = m0 + (rl >> 4) * 128 + i * 16 + (rl & 15);
-                    const char* rb = reinterpret_cast<const char*>(slab) + rl * 1024;
-                    const int sw = rl & 7, c4 = cv >> 2;
-                    const float4 lo = *reinterpret_cast<const float4*>(rb + ((c4 ^ sw) << 4));
-                    const float4 hi = *reinterpret_cast<const float4*>(rb + (((c4 + 1) ^ sw) << 4));
-                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (geglu) {
-                        const float4 glo = *reinterpret_cast<const float4*>(rb + (((c4 + 8) ^ sw) << 4));
-                        const float4 ghi = *reinterpret_cast<const float4*>(rb + (((c4 + 9) ^ sw) << 4));
-                        gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
-                        gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
-                    }
-                    epi8_store(g, cols, v, gt, m, gs, gq);
+            auto passes = [&](auto LDK, auto AK) {
+                constexpr int LD = decltype(LDK)::value, ACTK = decltype(AK)::value;
+                const h16* const Rb = reinterpret_cast<const h16*>(p.R) + n_first;
+                u32x4 rn[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
+                if (LD == 1) {                              // residual rows of row-tile 0 (LD 1 is never GEGLU: two sub-passes)
+                    rn[0] = ld16_raw(Rb + (size_t)mrow * p.ldr);
+                    rn[1] = ld16_raw(Rb + (size_t)(mrow + 8) * p.ldr);
                 }
-                __syncthreads();
-            }
-            if (p.gn_tot) {
-                // per-thread column partials -> lanes with equal col8 inside a wave -> waves (through the slab) -> one atomic add per column
-                for (int o = CPR; o < 64; o <<= 1) {
+                auto body = [&](const int i, const f32x4 (&w)[4]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
+                    for (int jj = 0; jj < 4; ++jj)
+                        *reinterpret_cast<f32x4*>(wrowp + ((((jj >> 1) * 8 + (jj & 1) * 4 + wq) ^ wx) << 4)) = w[jj];
+                    uint4 rr[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)}, o[2];
+                    float v[2][8];
+                    f32x4 lo[2], hi[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {           // GEGLU: c = value / gate of one row; otherwise the two sub-passes' rows
+                        const int row = geglu ? rrow : rrow + 8 * c, ch = geglu ? rc + 8 * c : rc;
+                        const char* const rp = ws + row * 256;
+                        lo[c] = lds_read16_raw(rp + ((ch ^ row) << 4));
+                        hi[c] = lds_read16_raw(rp + (((ch + 1) ^ row) << 4));
+                    }
+                    lds_wait4(lo[0], hi[0], lo[1], hi[1]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        v[c][0] = lo[c].x; v[c][1] = lo[c].y; v[c][2] = lo[c].z; v[c][3] = lo[c].w;
+                        v[c][4] = hi[c].x; v[c][5] = hi[c].y; v[c][6] = hi[c].z; v[c][7] = hi[c].w;
+                    }
+                    const int m = mrow + i * 16;
+                    if (LD == 1) {
+                        if (i == 0) vm_wait2<0>(rn[0], rn[1]);
+                        else vm_wait2<2>(rn[0], rn[1]);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) rr[c] = make_uint4(rn[c].x, rn[c].y, rn[c].z, rn[c].w);
+                    }
+                    if (ACTK == 1 || (ACTK == 2 && geglu)) {
+                        if (LD == 2) rr[0] = p.R ? bc_ld16(Rb + (size_t)m * p.ldr) : make_uint4(0u, 0u, 0u, 0u);
+                        o[0] = epi8_finish<LD, ACTK>(g, n_first, alpha, v[0], v[1], m, gs, gq, rr[0], scaled, LD == 2 && stats);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            if (LD == 2) rr[c] = p.R ? bc_ld16(Rb + (size_t)(m + 8 * c) * p.ldr) : make_uint4(0u, 0u, 0u, 0u);
+                            o[c] = epi8_finish<LD, ACTK>(g, n_first, alpha, v[c], v[c], m + 8 * c, gs, gq, rr[c], scaled, LD == 2 && stats);
+                        }
+                    }
+                    if (LD == 1 && i < 7) {                 // the next row-tile's residual rows, ahead of this one's stores (vmcnt is in-order); every
+                        const int mn = mrow + (i + 1) * 16; // such load MUST meet its vm_wait2: its registers are only the compiler's until then
+                        rn[0] = ld16_raw(Rb + (size_t)mn * p.ldr);
+                        rn[1] = ld16_raw(Rb + (size_t)(mn + 8) * p.ldr);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c >= nsub) continue;
+#ifdef BC_DIAGNOSTICS
+                        if ((g.halo_dbg & 2) && !(o[c].x == 0x7fff7fffu && o[c].y == 0x12345678u)) continue;      // stores skipped (values kept alive)
+#endif
+                        bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)(m + 8 * c) * p.ldc + n_first, o[c]);
+                    }
+                };
+                if (LD == 2) {                              // (the rarely used general form stays rolled: its finish is long)
+#pragma unroll 1
+                    for (int i = 0; i < 8; ++i) {
+                        f32x4 w[4];
+                        acc_row(acc, i, w);
+                        body(i, w);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) body(i, acc[i]);
+                }
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            if constexpr (GEN) {
+                passes(I2{}, I2{});
+            } else {                                        // unrolled: static accumulator rows, exact wait counts
+                if (geglu) passes(I0{}, I1{});
+                else if (p.R) passes(I1{}, I0{});
+                else passes(I0{}, I0{});
+            }
+            if (GEN && stats) {
+                // per-lane column partials -> the lanes of a wave that share a column chunk -> the wave's slice -> the two waves of a column group -> one atomic add per column
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    for (int o = geglu ? 4 : 8; o < 64; o <<= 1) {
                         gs[q] += __shfl_xor(gs[q], o);
                         gq[q] += __shfl_xor(gq[q], o);
                     }
                 }
-                if (lane < CPR) {
+                int tid2;                                   // (a fresh lane count: the epilogue's stays out of the pass loop's live set)
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid2));
+                const int lane2 = tid2;
+                tid2 |= wave << 6;
+                float* const wsf = reinterpret_cast<float*>(slab) + wave * 1024;
+                if (lane2 < (geglu ? 4 : 8)) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        slab[((wave * TSO) + c_out + q) * 2] = gs[q];
-                        slab[((wave * TSO) + c_out + q) * 2 + 1] = gq[q];
+                        wsf[(lane2 * 8 + q) * 2] = gs[q];
+                        wsf[(lane2 * 8 + q) * 2 + 1] = gq[q];
                     }
                 }
-                __syncthreads();
-                if (tid < TSO) {
+                lds_barrier();
+                const int TSO = geglu ? G_BN / 2 : G_BN, wcols = geglu ? 32 : 64;     // output columns of the tile / of a wave
+                if (tid2 < TSO) {
+                    const int cw = geglu ? tid2 >> 5 : tid2 >> 6, cc = tid2 - cw * wcols;
                     float s = 0.f, q2 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        s += slab[(w * TSO + tid) * 2];
-                        q2 += slab[(w * TSO + tid) * 2 + 1];
+                    for (int w = 0; w < 2; ++w) {
+                        s += slab[(w * 4 + cw) * 1024 + cc * 2];
+                        q2 += slab[(w * 4 + cw) * 1024 + cc * 2 + 1];
                     }
                     const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-                    bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + tid) * BC_GN_TOT_WORDS, s, q2);
+                    bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + tid2) * BC_GN_TOT_WORDS, s, q2);
                 }
-                __syncthreads();
+                lds_barrier();
             }
         } else {
             // BC_OUT_F16_T: thread = (column, 8 consecutive tokens) -> one 16-byte store into C[(b N + n) ldc + pix]  (bias and alpha only)
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < 8; ++i) {
+                f32x4 w[4];
+                acc_row(acc, i, w);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
-                    *reinterpret_cast<f32x4*>(wbase + (((wc4 + (jj >> 1) * 8 + (jj & 1) * 4) ^ wsw) << 4)) = acc[i][jj];
-                __syncthreads();
+                    *reinterpret_cast<f32x4*>(wbase + (((wc4 + (jj >> 1) * 8 + (jj & 1) * 4) ^ wsw) << 4)) = w[jj];
+                lds_barrier();
+#pragma unroll 1
                 for (int c = 0; c < 2; ++c) {
                     const int item = tid + 512 * c;
                     const int col = item & 255, ch = item >> 8;                     // ch 0..3: rows 8 ch .. 8 ch + 7 of the slab
                     const int n = n0 + col;
                     const int m = m0 + (ch >> 1) * 128 + i * 16 + (ch & 1) * 8;
-                    const float bias = p.bias ? p.bias[n] : 0.f;
                     uint4 outraw;
                     h16* o = reinterpret_cast<h16*>(&outraw);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         const int rl = ch * 8 + r;
                         const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(slab) + rl * 1024 + ((((col >> 2) ^ (rl & 7))) << 4) + (col & 3) * 4);
-                        o[r] = (h16)((x + bias) * alpha);
+                        o[r] = (h16)(x * alpha);              // (the bias is the accumulators' initial value)
                     }
                     const int b = (int)fdiv((unsigned)m, g.div_rpb);
                     const int pix = m - b * (int)g.div_rpb.d;
                     if (all_transposed) bc_st16(reinterpret_cast<h16*>(p.C) + ((size_t)b * g.n_out + n) * p.ldc + pix, outraw);
                     else bc_st16(reinterpret_cast<h16*>(p.C_t) + ((size_t)b * (p.N - p.n_t0) + (n - p.n_t0)) * p.ldc_t + pix, outraw);
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
 #undef tid
 #undef lane
+        G256_STAMP(2);
+#ifdef BC_DIAGNOSTICS
+        ++tile_no;
+#endif
         if (!has_next) break;
         j = jn; tm = tmn; tn = tnn; cA = nA; cA2 = nA2; cB = nB;
     }
@@ -387,6 +633,7 @@ int bc_gemm256_ok(const BcGemm& p) {
     if (p.A2 && (p.C1 <= 0 || p.C1 % 128 != 0 || p.C1 >= p.K)) return 0;                 // (two sources: every k-tile pair inside one of them)
     if (p.M <= 0 || p.M % G_BM != 0 || p.N % G_BN != 0 || p.K % 128 != 0 || p.K < 128) return 0;
     if (p.a_affine || p.a_tot1 || p.ln_colsum || p.w_bstride || p.vec_bstride || p.sm_group) return 0;
+    if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return 0;                  // (the accumulators start at the bias: 16-byte loads)
     if (p.C_t) {                                            // row-major columns [0, n_t0) + transposed columns [n_t0, N): plain projections only
         const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
         if (p.out_mode != BC_OUT_F16 || p.n_t0 <= 0 || p.n_t0 % G_BN != 0 || p.n_t0 >= p.N || p.act != BC_ACT_NONE || p.R || p.R2 || p.gn_tot || p.rowvec ||
@@ -427,8 +674,44 @@ int bc_gemm256_launch(const GemmArgs& g, hipStream_t stream) {
     int grid = std::min(ntiles, cus);
     if (grid >= 8) grid &= ~7;                              // (the schedule deals whole workgroups to the 8 XCDs)
     static std::atomic<unsigned long long> lds_set{0};
-    BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm256_kernel), G_LDS));
-    hipLaunchKernelGGL(gemm256_kernel, dim3(grid), dim3(512), G_LDS, stream, g);
+    static std::atomic<unsigned long long> lds_set_gen{0};
+    const bool gen = g256_general(p);
+    if (gen) BC_CHECK_HIP(bc_set_max_lds(lds_set_gen, reinterpret_cast<const void*>(&gemm256_kernel<true>), G_LDS));
+    else BC_CHECK_HIP(bc_set_max_lds(lds_set, reinterpret_cast<const void*>(&gemm256_kernel<false>), G_LDS));
+#ifdef BC_DIAGNOSTICS
+    // BC_G256_STAMPS=1 (diagnostic builds: HIPCC_EXTRA=-DBC_DIAGNOSTICS; synchronises): where a workgroup's cycles go, per tile
+    // value = bit 0 (always) | bit 1: the epilogue's global stores are skipped (WRONG results: what the stores cost) | (workgroups << 8): grid override
+    static const int stamp_bits = getenv("BC_G256_STAMPS") ? atoi(getenv("BC_G256_STAMPS")) : 0;
+    const bool want_stamps = stamp_bits != 0;
+    if (want_stamps) {
+        if (stamp_bits >> 8) grid = std::min(grid, stamp_bits >> 8);
+        static unsigned long long* buf = nullptr;
+        if (!buf) BC_CHECK_HIP(hipMalloc(&buf, 256 * 64 * sizeof(unsigned long long)));
+        BC_CHECK_HIP(hipMemsetAsync(buf, 0, 256 * 64 * sizeof(unsigned long long), stream));
+        GemmArgs g2 = g;
+        g2.halo_stamps = buf;
+        g2.halo_dbg = stamp_bits & 2;
+        if (gen) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(grid), dim3(512), G_LDS, stream, g2);
+        else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(grid), dim3(512), G_LDS, stream, g2);
+        BC_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h(256 * 64);
+        BC_CHECK_HIP(hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double kl[4] = {0}, ep[4] = {0};
+        int n[4] = {0};
+        for (int w = 0; w < grid; ++w)
+            for (int t = 0; t < 4; ++t) {
+                const unsigned long long* q = &h[(w * 4 + t) * 16];
+                if (!q[2]) continue;
+                kl[t] += (double)(q[1] - q[0]); ep[t] += (double)(q[2] - q[1]); ++n[t];
+            }
+        for (int t = 0; t < 4; ++t)
+            if (n[t]) fprintf(stderr, "[g256 stamps] M=%d N=%d K=%d act=%d grid=%d tile %d: k-loop %.0f ticks, epilogue %.0f (wave 0; n=%d)\n", p.M, p.N, p.K, p.act, grid, t,
+                              kl[t] / n[t], ep[t] / n[t], n[t]);
+        return 0;
+    }
+#endif
+    if (gen) hipLaunchKernelGGL(gemm256_kernel<true>, dim3(grid), dim3(512), G_LDS, stream, g);
+    else hipLaunchKernelGGL(gemm256_kernel<false>, dim3(grid), dim3(512), G_LDS, stream, g);
     BC_CHECK_LAUNCH();
     return 0;
 }

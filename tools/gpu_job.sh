@@ -1,4 +1,11 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-for v in 0 3; do echo "NBAND_MB=$v"; BC_X_NBAND_MB=$v PROBE_ONLY=auto PROBE_SHAPES=15,16 PROBE_COLD=1 timeout 300 python tools/conv_probe.py 2>&1 | grep "^B"; done
-bash tools/sweep_batch.sh gpurun_out/sw8 "--batch 8" "BC_X=1" "BC_X_NBAND_MB=3" 2>&1 | tail -4
+# scratch job: batch-8 A/B: row-chain vs unfused blocks on gemm256
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+for plan in "" "rowchain=0" "" "rowchain=0"; do
+  BC_PLAN="$plan" timeout 600 python bench.py --batch 8 --steps 10 --warmup 3 --no-calibration > gpurun_out/b8.json 2> gpurun_out/b8.err || tail -5 gpurun_out/b8.err
+  python - "$plan" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/b8.json').read().strip().splitlines()[-1]); print('batch8 plan[%s] ms/step %.2f'%(sys.argv[1], d['ms_per_step']/50), d['config'].get('plan'))
+PY
+done
