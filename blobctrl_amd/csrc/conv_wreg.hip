@@ -650,75 +650,90 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
         }
         const float ab = p.alpha_bstride > 0 ? batch_alpha(g, b) : 1.0f;
         constexpr int NR = 6;                                       // rows row0 + 24 k < 128
-        uint4 rr[NR], rr2[NR];
-        int mrow[NR];
-        bool has2[NR];
+        // H2 = the launch has a right-half residual (R2: per-lane loads under per-lane conditions).  Without it (every ResBlock convolution)
+        // no load of this pass sits under a per-lane branch: the residual chunks of all six rows are requested from clamped addresses, and
+        // the compiler's waits then count exactly - each leaves the later requests and all earlier STORES in flight, where the conditional
+        // form made every row wait vmcnt(0), i.e. for the previous row's store to be acknowledged (BC_WREG_STAMPS: "stores" 9.4k of a
+        // 320-channel workgroup's 69k cycles at batch 8)
+        // (HR = the launch has a residual, known at compile time in the form without R2: under a run-time `if (p.R)` the compiler moves the
+        //  fp16 -> fp32 conversions of a residual chunk up into the load's block, and each of the six requests is awaited where it is made)
+        auto rows = [&](auto H2K, auto HRK) {
+            constexpr bool H2 = decltype(H2K)::value, HR = decltype(HRK)::value;
+            uint4 rr[NR], rr2[NR];
+            int mrow[NR];
+            bool has2[NR];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = row0 + 24 * k;
-            const int py = ty0 + (row >> 4), px = tx0 + (row & 15);
-            mrow[k] = b * rpb + py * W + px;
-            has2[k] = false;
-            if (row < HBM) {
-                if (p.R) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
-                if (p.R2) {
+            for (int k = 0; k < NR; ++k) {
+                const int row = row0 + 24 * k;
+                const int rowc = (k < 5 || row < HBM) ? row : row0;   // (only k = 5 can leave the tile)
+                const int py = ty0 + (rowc >> 4), px = tx0 + (rowc & 15);
+                mrow[k] = b * rpb + py * W + px;
+                has2[k] = false;
+                if (!H2) {
+                    if (HR) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
+                } else if (row < HBM) {
+                    if (p.R) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
                     const int pix = py * W + px;
                     const int x = pix - (int)fdiv((unsigned)pix, g.div_outw) * (int)g.div_outw.d;
                     has2[k] = x >= p.r2_xmin;
                     if (has2[k]) rr2[k] = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)(b % p.r2_bmod) * rpb + pix) * p.ldr2 + n_first);
                 }
             }
-        }
+            if (!H2) __builtin_amdgcn_sched_barrier(0);               // (all six requests before the first use)
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = row0 + 24 * k;
-            if (row >= HBM) continue;
-            const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
-            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            for (int k = 0; k < NR; ++k) {
+                const int row = row0 + 24 * k;
+                if (k == 5 && row >= HBM) continue;
+                const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += bias_v[j];
-            if (p.rowvec) {
+                for (int j = 0; j < 8; ++j) v[j] += bias_v[j];
+                if (p.rowvec) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rvec[j];
+                    for (int j = 0; j < 8; ++j) v[j] += rvec[j];
+                }
+                if (p.act == BC_ACT_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
+                } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+                } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= cs[j];
+                if (p.alpha_bstride > 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= ab;
+                }
+                if (H2 ? p.R != nullptr : HR) {
+                    const h16* rh = reinterpret_cast<const h16*>(&rr[k]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+                }
+                if (H2 && has2[k]) {
+                    const h16* rh = reinterpret_cast<const h16*>(&rr2[k]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+                }
+                uint4 outraw;
+                h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[j] = (h16)v[j];
+                    const float f = (float)o[j];
+                    gs[j] += f;
+                    gq[j] += f * f;
+                }
+                bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[k] * p.ldc + n_first, outraw);
             }
-            if (p.act == BC_ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
-            } else if (p.act == BC_ACT_SILU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
-            } else if (p.act == BC_ACT_QUICK_GELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= cs[j];
-            if (p.alpha_bstride > 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= ab;
-            }
-            if (p.R) {
-                const h16* rh = reinterpret_cast<const h16*>(&rr[k]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-            }
-            if (has2[k]) {
-                const h16* rh = reinterpret_cast<const h16*>(&rr2[k]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-            }
-            uint4 outraw;
-            h16* o = reinterpret_cast<h16*>(&outraw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                o[j] = (h16)v[j];
-                const float f = (float)o[j];
-                gs[j] += f;
-                gq[j] += f * f;
-            }
-            bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[k] * p.ldc + n_first, outraw);
-        }
+        };
+        if (p.R2) rows(std::true_type{}, std::false_type{});
+        else if (p.R) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
     }
     if (p.gn_tot) {
         float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile

@@ -525,5 +525,5 @@ def test_planner_options_parse_and_refuse_typos(monkeypatch):
                 names |= set(re.findall(r'(?:environ(?:\.get)?\(|environ\[|getenv\()\s*"(BC_[A-Z0-9_]+)"', src))
     allowed = {"BC_PLAN", "BC_NO_GRAPHS", "BC_LOOP_GRAPH", "BC_ONE_STREAM", "BC_NO_MODULE_GRAPHS", "BC_SPLIT_CFG", "BC_NO_TUNING", "BC_TUNING_FILE",
                "BC_GN_UNFUSED", "BC_GEMM_GENERIC", "BC_GEMM_TILE", "BC_ATTN_NO8", "BC_WREG_STAMPS", "BC_RC_STAMPS",
-               "BC_HALO_DBG", "BC_HALO_STAMPS"}            # (the last two only inside #ifdef BC_DIAGNOSTICS of conv_halo.hip)
+               "BC_HALO_DBG", "BC_HALO_STAMPS", "BC_G256_STAMPS"}        # (the last three only inside #ifdef BC_DIAGNOSTICS: conv_halo.hip, gemm256.hip)
     assert names <= allowed and len(names) <= 25, sorted(names - allowed)
