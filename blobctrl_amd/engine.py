@@ -123,10 +123,12 @@ class TrunkPlan:
 
     def g256_tile(self, M, N, K, kw):
         """BC_TILE_G256 (csrc/gemm256.hip: 256 x 256 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups) for a dense
-        single-source projection with enough tiles to fill the chip, else 0 = the planner's LDS-DMA tiles.  Stand-alone on an MI355X
-        (tools/gemm8p_probe.hip, TFLOP/s, gemm_fast's best tile in brackets): [8192 x 10240 x 1280] 903 (673), [8192 x 1280 x 5120]
-        957 (571), [8192 x 3840 x 1280] 968, [8192 x 1280 x 1280] 708 (~450; 160 tiles on 256 CUs), [4096 x 1280 x 1280] 392 (80 tiles:
-        stays on the 256 x 128 tiles) - hence the tile-count threshold (BC_PLAN g256_min_tiles, default 128)."""
+        single-source projection with enough tiles, else 0 = the planner's LDS-DMA tiles.  Stand-alone on an MI355X (tools/g256_probe.py,
+        TFLOP/s with the fused epilogue, gemm_fast's best tile in brackets): [8192 x 10240 x 1280] 1233 (673), with GEGLU 1137,
+        [8192 x 1280 x 5120] 971 (571), [8192 x 3840 x 1280] 1144, [8192 x 1280 x 1280] 799 (~450; 160 tiles on 256 CUs),
+        [16384 x 5120 x 640] 1042.  The tile-count threshold (BC_PLAN g256_min_tiles, default 64): at 80 tiles - BlobNet's and the UNet's
+        N = 1280 projections at batch 8 - a launch fills 80 CUs for about the time the 160 half-size tiles take, and leaves the other
+        queue the rest (batch 8: 48.39 / 48.30 -> 48.14 ms per step on one box; below 64 tiles it loses)."""
         if not opt("g256") or kw.get("tile_cfg") or kw.get("splitk") not in (None, 1):
             return 0
         if M % 256 or N % 256 or (M // 256) * (N // 256) < opt("g256_min_tiles"):

@@ -42,7 +42,7 @@ TABLE = {
     "ff_split_320": (1, "workgroups per row block of the 320-channel block end up to 128 row blocks"),
     "gw_maxm": (1024, "largest M of a projection on gemm_wreg.hip"),
     "ctx_fold_maxb": (2, "largest UNet batch that takes the prompt-folded cross-attention"),
-    "g256_min_tiles": (128, "fewest 256 x 256 tiles for gemm256.hip"),
+    "g256_min_tiles": (64, "fewest 256 x 256 tiles for gemm256.hip (a quarter of the CUs: the other queue has the rest)"),
 }
 
 

@@ -170,6 +170,105 @@ def test_no_hot_kernel_uses_scratch(tmp_path):
         assert scratch <= limit, f"{name}: {scratch} bytes of scratch per lane"
 
 
+def _vgprs(tok):
+    import re
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def scan_pending_load_hazards(listing):
+    """Linear scan of one kernel's disassembly: every global / LDS load's destination registers stay 'pending' until an s_waitcnt that
+    retires the request (vmcnt / lgkmcnt are in-order counters: a wait for N leaves the N youngest requests of that kind in flight).  Returns
+    the instructions that touch a pending register.  Compiler-made loads never show up here (the compiler waits before a use); hand-written
+    `asm volatile` loads - whose waits are hand-counted - are what this guards (csrc/gemm256.hip: lds_read16_raw / ld16_raw)."""
+    import re
+    vm, lgkm, bad = [], [], []          # in-order queues of (destination registers, text)
+    for line in listing:
+        t = line.split("//")[0].strip()
+        if not t or t.endswith(":") or t.startswith("<"):
+            continue
+        op = t.split()[0]
+        toks = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                vm = vm[len(vm) - int(m.group(1)):] if int(m.group(1)) < len(vm) else vm
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                lgkm = lgkm[len(lgkm) - int(m.group(1)):] if int(m.group(1)) < len(lgkm) else lgkm
+            continue
+        used = set()
+        for k in toks:
+            used |= _vgprs(k)
+        pend = set().union(*[d for d, _ in vm], *[d for d, _ in lgkm]) if (vm or lgkm) else set()
+        if used & pend:
+            bad.append(t)
+        if op.startswith(("global_load", "buffer_load", "scratch_load")):
+            vm.append((set() if "_lds_" in op else _vgprs(toks[0]), t))
+        elif op.startswith(("global_store", "buffer_store", "global_atomic", "scratch_store")):
+            vm.append((set(), t))
+        elif op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_permute") or op.startswith("ds_swizzle"):
+            lgkm.append((_vgprs(toks[0]), t))
+        elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_memtime"):
+            lgkm.append((set(), t))
+    return bad
+
+
+def test_pending_load_scan_catches_a_use_before_its_wait():
+    ok = ["global_load_dwordx4 v[4:7], v[0:1], off", "global_store_dwordx4 v[2:3], v[8:11], off", "s_waitcnt vmcnt(1)", "v_add_f32 v4, v4, v5"]
+    assert scan_pending_load_hazards(ok) == []
+    early = ["global_load_dwordx4 v[4:7], v[0:1], off", "global_load_dwordx4 v[12:15], v[0:1], off", "s_waitcnt vmcnt(1)", "v_add_f32 v12, v4, v5"]
+    assert scan_pending_load_hazards(early) == ["v_add_f32 v12, v4, v5"]
+    lds = ["ds_read_b128 v[4:7], v1", "v_mov_b32 v9, v4", "s_waitcnt lgkmcnt(0)", "v_mov_b32 v9, v4"]
+    assert scan_pending_load_hazards(lds) == ["v_mov_b32 v9, v4"]
+
+
+def test_hand_counted_loads_of_gemm256_are_awaited_before_use(tmp_path):
+    """csrc/gemm256.hip issues its epilogue's slab read-back and residual loads from inline assembly with hand-counted waits (the compiler's
+    own would be vmcnt(0): DESIGN 3.11).  The compiler does not know those registers are in flight - a register copy or an early use placed
+    between request and wait would read garbage.  Disassemble the built kernels and check that nothing touches such a register early."""
+    import shutil
+    import subprocess
+    from blobctrl_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    bundler, objdump = os.path.join(llvm, "clang-offload-bundler"), os.path.join(llvm, "llvm-objdump")
+    if not (os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        pytest.skip("ROCm LLVM tools not available")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat])
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+    kernels = {}
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        part, co = str(tmp_path / f"b{n}.bin"), str(tmp_path / f"b{n}.co")
+        open(part, "wb").write(blob[a:b])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--output={co}"], stderr=subprocess.DEVNULL)
+        dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+        if "gemm256_kernel" not in dis:
+            continue
+        name = None
+        for line in dis.splitlines():
+            if line.endswith(">:") and "<" in line:
+                name = line[line.index("<") + 1:-2]
+                kernels[name] = []
+            elif name:
+                kernels[name].append(line)
+    g256 = {k: v for k, v in kernels.items() if "gemm256_kernel" in k}
+    assert len(g256) == 2, sorted(kernels)
+    # the scan is linear, so it is run on the code object whose hand-counted region is straight-line: gemm256_kernel<false> (unrolled plain /
+    # GEGLU / residual forms).  gemm256_kernel<true> keeps compiler-made loads under branches (a linear scan sees the other branch's register
+    # writes as early uses); its only assembly loads are the slab reads, awaited in the statement after them
+    (name, listing), = [(k, v) for k, v in g256.items() if "ILb0E" in k]
+    assert sum("global_load_dwordx4" in l for l in listing) >= 16 and sum("ds_read_b128" in l for l in listing) >= 64, name
+    bad = scan_pending_load_hazards(listing)
+    assert not bad, f"{name}: {bad[:5]}"
+
+
 def test_image_processors_match_the_reference_processors(golden_dir):
     """Dinov2ImageProcessor vs transformers' BitImageProcessor with the dinov2 preprocessor_config values, VaeImageProcessor.preprocess
     vs diffusers' (lanczos resize to (height, width), RGB, [-1, 1]) on a non-square image - fixture from tools/make_golden.py."""
@@ -506,7 +605,7 @@ def test_planner_options_parse_and_refuse_typos(monkeypatch):
     (the two diagnostics that produced wrong results are gone from the package)."""
     from blobctrl_amd import options
     monkeypatch.delenv("BC_PLAN", raising=False)
-    assert options.non_default() == {} and options.opt("rowchain") is True and options.opt("g256_min_tiles") == 128
+    assert options.non_default() == {} and options.opt("rowchain") is True and options.opt("g256_min_tiles") == 64
     monkeypatch.setenv("BC_PLAN", "rowchain=0, ff_split_640=2;cfg_prefix=0")
     assert options.non_default() == {"rowchain": False, "ff_split_640": 2, "cfg_prefix": False}
     for bad in ("rowchian=0", "rowchain", "gw_maxm=big"):

@@ -63,6 +63,12 @@ for (B, H, W, C1, C2, Co) in SHAPES:
                      tile_cfg=cfg, splitk=sk, a_act=_lib.ACT_SILU, want_gn=not os.environ.get("PROBE_NO_GN"),
                      a_gn=dict(x1=x1, C1=C1, x2=x2, C2=C2, B=B, HW=HW, G=32, eps=1e-5, gamma=gamma, beta=beta), **kw)
             segs[f"{name}_sk{sk}({s2.meta[-1]['shape'][-1]})"] = s2
+    # (round 6) GroupNorm-apply pass + the PLAIN conv_wreg kernel (no statistics table, no in-place transform of the halo rows)
+    s3 = rec.begin("gnpass_wreg")
+    y3 = rec.groupnorm(x1, C1, x2, C2, B, HW, 32, 1e-5, gamma, beta, True)
+    rec.gemm(A=y3, W=wt_wreg, M=M, N=Co, K=9 * Cin, out=rec.empty(M, Co), bias=bias, conv=conv, rows_per_batch=HW, tile_cfg=_lib.TILE_WREG,
+             want_gn=not os.environ.get("PROBE_NO_GN"))
+    segs[f"gnpass+wreg0({s3.meta[-1]['shape'][-1]})"] = s3
     for rnd in range(3):
         for k, s in segs.items():
             res.setdefault(k, []).append(time_launch_cold(rec, s, stream, 6, thrash, [t for t in (x1, x2) if t is not None])

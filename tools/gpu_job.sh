@@ -1,22 +1,5 @@
 #!/bin/bash
-# scratch job: conv_wreg epilogue with batched residual requests: tests + same-box A/B (batch 1 and 8) against the previous library
+# scratch job: fused GroupNorm prologue vs GroupNorm pass + plain conv_wreg at batch 8 / 1
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_blocks_gpu.py -x -q > gpurun_out/t_k.log 2>&1
-tail -3 gpurun_out/t_k.log
-for rep in 1 2; do
-for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
-  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --steps 3 --warmup 2 --no-calibration > gpurun_out/b1.json 2> gpurun_out/b1.err || tail -5 gpurun_out/b1.err
-  python - "$lib" <<'PY'
-import json,sys
-d=json.loads(open('gpurun_out/b1.json').read().strip().splitlines()[-1]); print('batch1 lib[%s] ms/step %.3f'%(sys.argv[1][-12:], d['ms_per_step']/50))
-PY
-done; done
-for rep in 1 2; do
-for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
-  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --batch 8 --steps 6 --warmup 2 --no-calibration > gpurun_out/b8.json 2> gpurun_out/b8.err || tail -5 gpurun_out/b8.err
-  python - "$lib" <<'PY'
-import json,sys
-d=json.loads(open('gpurun_out/b8.json').read().strip().splitlines()[-1]); print('batch8 lib[%s] ms/step %.2f'%(sys.argv[1][-12:], d['ms_per_step']/50))
-PY
-done; done
+PROBE_ONLY=auto PROBE_SPLIT=1 PROBE_SHAPES=14,15,16,0,4 timeout 900 python tools/conv_probe.py 2>&1 | tail -40
