@@ -1,5 +1,7 @@
 #!/bin/bash
-# scratch job: fused GroupNorm prologue vs GroupNorm pass + plain conv_wreg at batch 8 / 1
+# scratch job: round-6 profiles on the final kernel sources (batch 1 / 8 / 768^2 x 4 / batch 2)
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
-PROBE_ONLY=auto PROBE_SPLIT=1 PROBE_SHAPES=14,15,16,0,4 timeout 900 python tools/conv_probe.py 2>&1 | tail -40
+bash tools/profile_round.sh "" > gpurun_out/prof_b1.log 2>&1; tail -2 gpurun_out/prof_b1.log
+bash tools/profile_round.sh c3 --batch 8 > gpurun_out/prof_c3.log 2>&1; tail -2 gpurun_out/prof_c3.log
+bash tools/profile_round.sh c5 --res 768 --batch 4 > gpurun_out/prof_c5.log 2>&1; tail -2 gpurun_out/prof_c5.log
+bash tools/profile_round.sh b2 --batch 2 > gpurun_out/prof_b2.log 2>&1; tail -2 gpurun_out/prof_b2.log
