@@ -418,7 +418,13 @@ class TrunkPlan:
         # --- GEGLU feed-forward: LayerNorm3 folded into ff.net.0; ff.net.2 (K = 4C) stays on the LDS-DMA tiles with split-K
         # (64 x 128 workgroups everywhere: two fit a CU - 80 KiB of LDS each - and measure best at every shape of these levels, e.g.
         #  LayerNorm + GEGLU [1024 x 10240 x 1280] 51.7 us against 53.5 / 54.8 for the 256- / 320-column workgroups: tools/gw_probe.py)
-        g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G128, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
+        if opt("gw_ff1_g256") and self.g256_tile(M, 8 * Cc, Cc, dict(act=_lib.ACT_GEGLU)):
+            # (round 6) ff.net.0 is the one projection of these levels wide enough for the 256 x 256 tiles (M = 1024: 4 x 40 = 160 workgroups of
+            # one tile each): a LayerNorm launch + gemm256.hip with the GEGLU epilogue against the LayerNorm-folded gemm_wreg launch
+            ln = rec.layernorm(h, M, Cc, pw.f[bp + "norm3.weight"], pw.f[bp + "norm3.bias"], 1e-5)
+            g = self.dense(ln, M, Cc, bp + "ff.net.0.proj", 8 * Cc, act=_lib.ACT_GEGLU, kind="ff")
+        else:
+            g = proj(h, bp + "ff.net.0.proj", 8 * Cc, Cc, G128, ln=bp + "norm3", act=_lib.ACT_GEGLU, kind="ff")
         if rec.lib.bc_gemm_wreg_eligible(M, Cc, 5 * Cc, 4 * Cc, G128):
             # ff.net.2 + residual + proj_out as ONE two-source GEMM over [g | h] with the weight [P F2 | P] made at pack time
             # (weights.ff2_proj_out): at these levels a launch on the UNet's queue costs ~40 us INSIDE the step - three times what it

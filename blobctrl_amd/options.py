@@ -27,6 +27,7 @@ TABLE = {
     "gw": (True, "1280-channel projections at M <= gw_maxm on csrc/gemm_wreg.hip (0: LDS-DMA tiles + LayerNorm launches)"),
     "ctx_fold": (True, "cross-attention of the 1280-channel blocks folded over the prompt (0: to_q + bc_attention + to_out)"),
     "g256": (True, "large-M dense projections on csrc/gemm256.hip from g256_min_tiles tiles on (0: gemm_fast tiles)"),
+    "gw_ff1_g256": (True, "ff.net.0 of the 1280-channel blocks at M <= gw_maxm as LayerNorm + gemm256.hip where it has >= g256_min_tiles tiles"),
     "cfg_prefix": (True, "CFG-invariant prefix of the UNet once per image pair (0: every launch at the full CFG batch)"),
     "wreg": (True, "ResBlock convolutions on csrc/conv_wreg.hip (0: csrc/conv_halo.hip)"),
     "halo": (True, "ResBlock convolutions with the fused GroupNorm prologue at all (0: GroupNorm pass + implicit GEMM)"),

@@ -104,18 +104,25 @@ def test_transformer_block(z, name, fused, monkeypatch):
 @pytest.mark.parametrize("name,mode", [("tfm_640_cross", "rowchain"), ("tfm_640_cross", "rowchain_tail"), ("tfm_640_cross", "rowchain_nsplit1"),
                                        ("tfm_640_cross", "unfused"),
                                        ("tfm_640_self_only", "rowchain"), ("tfm_640_self_only", "unfused"),
-                                       ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "gw_attn"), ("tfm_1280_cross", "unfused"), ("tfm_1280_self_only", "gw")])
+                                       ("tfm_1280_cross", "gw"), ("tfm_1280_cross", "gw_attn"), ("tfm_1280_cross", "gw_ff1"), ("tfm_1280_cross", "unfused"),
+                                       ("tfm_1280_self_only", "gw")])
 def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     """The block sizes rounds 3 / 4 built kernels for, against the reference's Transformer2DModel: 640 channels
     on a 32 x 64 map at B = 2 (64 row blocks: the row-chain with the block end as OUT_FFP + sum over four workgroups per row block
     (round 5), as OUT_FF + OUT_TAIL over two (round 3), its one-launch form, and the unfused list); 1280 channels on the 16 x 32 map (gemm_wreg.hip: LayerNorms folded, q | k | V^T
     in one launch, the cross-attention as two projections with the prompt folded into their weights (round 5: bc_ctx_fold; "gw_attn" = to_q +
-    bc_attention + to_out instead); and the unfused list)."""
+    bc_attention + to_out instead), ff.net.0 as LayerNorm + gemm256.hip (round 6; "gw_ff1" = the LayerNorm-folded gemm_wreg launch instead);
+    and the unfused list)."""
     from tests.common import set_plan
+    ff1_g256 = True
     if mode == "gw_attn":
         set_plan(monkeypatch, ctx_fold=0)
         mode = "gw"
         folded = False
+    elif mode == "gw_ff1":
+        set_plan(monkeypatch, gw_ff1_g256=0)
+        mode, ff1_g256 = "gw", False
+        folded = name == "tfm_1280_cross"
     else:
         folded = mode == "gw" and name == "tfm_1280_cross"
     if mode == "unfused":
@@ -142,7 +149,8 @@ def test_transformer_block_640_1280(z, name, mode, monkeypatch):
     if mode == "gw":
         # (round 5) ff.net.2 + residual + proj_out run as ONE two-source GEMM with the pack-time product [P F2 | P]: K = 5C
         assert any(m["kind"] == "ff" and m["shape"][3] == 5 * p["C"] for m in rec.seg.meta), [m["shape"] for m in rec.seg.meta if m["kind"] == "ff"]
-        assert "layernorm" not in kinds and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
+        assert kinds.get("layernorm", 0) == (1 if ff1_g256 else 0) and sum("_qkv" in v for v in variants) == 1, (kinds, variants)
+        assert any(v.startswith("gemm256_kernel") and m["kind"] == "ff" for v, m in zip(variants, rec.seg.meta)) == ff1_g256, variants
         assert not any(k.startswith("groupnorm") for k in kinds) and sum("_gn" in v for v in variants) == 1, (kinds, variants)
         # cross-attention: ctx_fold (per edit) + softmax projection + output projection, and only the self-attention left as bc_attention
         assert (kinds.get("xattn", 0) == 2 and kinds.get("ctx_fold", 0) == 1 and kinds.get("attention", 0) == 1) == folded, kinds
