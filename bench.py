@@ -486,9 +486,9 @@ def roofline(pipe, plan, res=512, batch=1):
         dict(by_kernel=table, top_shapes=detail)
 
 
-# Reference readings of the two calibration probes (the box profiles/r6_bench_final.json was taken on): a box's speed index is the mean
+# Reference readings of the two calibration probes (the box the round-6 profiles and parity margins were taken on): a box's speed index is the mean
 # of its two ratios to these
-CAL_REF = {"gemm_8192_tflops": 1385.0, "attn_l0_us": 217.0}
+CAL_REF = {"gemm_8192_tflops": 1416.0, "attn_l0_us": 226.0}
 
 
 def box_calibration(dev, seconds=1.0):
