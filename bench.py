@@ -515,6 +515,16 @@ def box_calibration(dev, seconds=1.0):
     seg_a = rec.begin("cal_attn")
     C_ = heads * d
     rec.attention(qk, qk, vt, rec.empty(B * N, C_), B, heads, d, N, N, 2 * C_, 2 * C_, N, C_, N * 2 * C_, N * 2 * C_, C_ * N, N * C_, d ** -0.5, q_off=0, k_off=C_)
+    # (third probe, round 6 late: the two above read within 1 % on boxes whose batch-1 steps were 2.3 % apart - that step is made of launches
+    #  that do NOT fill the chip) a chain of 32 dependent [1024 x 1280 x 1280] projections: launch gap + the latency of a small grid
+    xc = (torch.randn(1024, 1280, generator=gen) * 0.5).half().to(dev)
+    Wc = (torch.randn(1280, 1280, generator=gen) * 0.03).half().to(dev)
+    seg_c = rec.begin("cal_chain")
+    cur = xc
+    for _ in range(32):
+        nxt = rec.empty(1024, 1280)
+        rec.gemm(A=cur, W=Wc, M=1024, N=1280, K=1280, out=nxt)
+        cur = nxt
     s = torch.cuda.current_stream(dev).cuda_stream
 
     def time_seg(seg, budget):
@@ -537,10 +547,13 @@ def box_calibration(dev, seconds=1.0):
         return best[len(best) // 2], reps
     g_ms, g_reps = time_seg(seg_g, seconds)
     a_ms, a_reps = time_seg(seg_a, seconds)
+    c_ms, c_reps = time_seg(seg_c, 0.5 * seconds)
     rec.close()
     out = {"gemm_8192_tflops": round(2.0 * n ** 3 / (g_ms * 1e-3) / 1e12, 1), "attn_l0_us": round(a_ms * 1e3, 1),
-           "reference": CAL_REF, "launches": [g_reps, a_reps]}
+           "chain_us_per_launch": round(c_ms * 1e3 / 32, 2), "reference": CAL_REF, "launches": [g_reps, a_reps, c_reps]}
     out["speed_index"] = round(0.5 * (out["gemm_8192_tflops"] / CAL_REF["gemm_8192_tflops"] + CAL_REF["attn_l0_us"] / out["attn_l0_us"]), 4)
+    if CAL_REF.get("chain_us_per_launch"):
+        out["latency_index"] = round(CAL_REF["chain_us_per_launch"] / out["chain_us_per_launch"], 4)
     return out
 
 
