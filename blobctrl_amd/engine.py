@@ -159,6 +159,13 @@ class TrunkPlan:
         pw = self.pw
         C2 = x2.C if x2 is not None else 0
         if self.halo_ok(x.C + C2, C2 and x.C, Cout, x.H, x.W):
+            requests = self.B if self.cfg.is_blobnet else max(1, self.B // 2)         # (the UNet runs the CFG pair of every request)
+            if opt("gn_pass_min_requests") and requests >= opt("gn_pass_min_requests") and x.C + C2 >= opt("gn_pass_min_cin") and opt("wreg"):
+                # batches of >= 4 requests: a GroupNorm-apply pass + the PLAIN conv_wreg kernel.  The fused prologue costs every workgroup of
+                # every round ~10k cycles (statistics table, in-place pass over the halo rows: stand-alone 230 vs 195 + 25 us at 640 channels
+                # and batch 8, tools/conv_probe.py); the pass costs a launch on the queue, which is what decides at batch 1-2 whatever the grid
+                # (same box, ms per step, fused / pass: batch 2 14.38 / 14.50-14.57, batch 4 25.38 / 25.19, batch 8 48.19 / 47.49, 768^2 x 4 74.49 / 73.43)
+                return self.conv3x3(self.groupnorm(x, x2, norm, eps, True), wname, Cout, halo=True, **kw)
             gn = dict(x1=x.t, C1=x.C, x2=x2.t if x2 is not None else None, C2=C2, B=self.B, HW=x.H * x.W, G=self.G, eps=eps,
                       gamma=pw.f[norm + ".weight"], beta=pw.f[norm + ".bias"])
             return self.conv3x3(x, wname, Cout, x2=x2, affine=(gn, _lib.ACT_SILU), halo=True, **kw)

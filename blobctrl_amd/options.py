@@ -43,6 +43,8 @@ TABLE = {
     "ff_split_320": (1, "workgroups per row block of the 320-channel block end up to 128 row blocks"),
     "gw_maxm": (1024, "largest M of a projection on gemm_wreg.hip"),
     "ctx_fold_maxb": (2, "largest UNet batch that takes the prompt-folded cross-attention"),
+    "gn_pass_min_requests": (4, "edit requests per batch from which a ResBlock convolution runs as GroupNorm pass + plain conv_wreg (0: never)"),
+    "gn_pass_min_cin": (320, "... and fewest input channels of such a convolution"),
     "g256_min_tiles": (64, "fewest 256 x 256 tiles for gemm256.hip (a quarter of the CUs: the other queue has the rest)"),
 }
 

@@ -63,8 +63,13 @@ def _run(seg):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("gn_pass", [False, True])
 @pytest.mark.parametrize("name,split", [("res_320_320", 0), ("res_320_640_shortcut", 0), ("res_2560_1280", 0), ("res_2560_1280", 1280)])
-def test_resnet_block(z, name, split):
+def test_resnet_block(z, name, split, gn_pass, monkeypatch):
+    """The reference's ResnetBlock2D against the fused form (GroupNorm finalize + normalise + SiLU inside conv_wreg.hip's halo staging) and
+    the form batches of >= 4 requests take (round 6: GroupNorm-apply pass + the plain conv_wreg kernel; BC_PLAN gn_pass_min_requests)."""
+    from tests.common import set_plan
+    set_plan(monkeypatch, gn_pass_min_requests=1 if gn_pass else 0)
     _, p = BLOCK_CASES[name]
     x, temb, _ = block_inputs(name)
     rec, seg, plan = _plan(name, block_weights(name), p["B"], p["H"], p["W"])
@@ -74,8 +79,11 @@ def test_resnet_block(z, name, split):
         out = plan.resnet("blk.", _act(x[:, :split]), _act(x[:, split:]), p["cout"])
     else:
         out = plan.resnet("blk.", _act(x), None, p["cout"])
+    variants = [m.get("rocprof", "") for m in rec.seg.meta]
+    if any(v.startswith("conv_wreg_kernel") for v in variants):        # (the 2560 -> 1280 fixture's map is too small for conv_wreg.hip: one form only)
+        assert any(v == "conv_wreg_kernel<0>" for v in variants) == gn_pass and any(v == "conv_wreg_kernel<2>" for v in variants) == (not gn_pass), variants
     _run(seg)
-    _check(name + ("(hidden|skip)" if split else ""), _nchw(out, p["B"]), z[name])
+    _check(name + ("(hidden|skip)" if split else "") + (" (GroupNorm pass)" if gn_pass else ""), _nchw(out, p["B"]), z[name])
 
 
 @pytest.mark.parametrize("fused", [True, False])
