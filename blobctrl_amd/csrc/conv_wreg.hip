@@ -51,13 +51,12 @@ constexpr int HALO_BYTES = 24 * 1024;           // one 64-channel chunk of the h
 constexpr int NBUF = 3;                         // halo images: multiplied | being transformed | landing
 constexpr int OFF_AB = NBUF * HALO_BYTES;
 constexpr int MAX_CH = 40;                      // channel chunks per workgroup (affine table: 512 B per chunk)
-constexpr int TS = HBN + 4;                     // epilogue tile row stride (floats)
-constexpr int OFF_SCR = HBM * TS * 4;           // GroupNorm-partial scratch behind the epilogue tile
+constexpr int TS = HBN + 4;                     // split-K: row stride (floats) of the fp32 partial tile
 constexpr int LDS_LOOP = OFF_AB + MAX_CH * 512;
-constexpr int LDS_EPI = OFF_SCR + 24 * HBN * 2 * 4;
+constexpr int LDS_EPI = 8 * 16384;              // epilogue: one 16-KB slice per wave (64 pixels x 256 B); the split-K tile (HBM * TS * 4 bytes) fits below
 constexpr int OFF_EPI = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;   // bias[160] | time-embedding row[160] (floats), staged in the prologue
 constexpr int LDS_TOTAL = OFF_EPI + 2 * HBN * 4;
-static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES, "LDS budget");
+static_assert(LDS_TOTAL <= 160 * 1024 && HPIX * 128 <= HALO_BYTES && HBM * TS * 4 <= LDS_EPI, "LDS budget");
 constexpr int FIN_MAX_CH = 2752;                // in-kernel GroupNorm finalize: channel span (incl. group straddle) per workgroup
 constexpr int OFF_FIN = LDS_LOOP;               // its scratch: [span][2] doubles + [groups][2] floats, behind the loop's LDS
 constexpr int LDS_TOTAL_FIN = OFF_FIN + FIN_MAX_CH * 16 + 1024 > LDS_TOTAL ? OFF_FIN + FIN_MAX_CH * 16 + 1024 : LDS_TOTAL;
@@ -551,7 +550,7 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                         if (i < 0 || i >= 8) continue;
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(h16x8, ring[(kx * 3 + ky) * NT + t]), acc[i][t], 0, 0, 0);
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ring[(kx * 3 + ky) * NT + t]), af, acc[i][t], 0, 0, 0);   // (swapped product: a lane holds 4 consecutive CHANNELS of one pixel)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -598,27 +597,181 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 const f32x4v o = *reinterpret_cast<const f32x4v*>(xch + (((i_keep + ii) * NT + t) * 64 + lane) * 16);
                 fin[ii][t] = (kg ? acc[4 + ii][t] : acc[ii][t]) + o;
             }
-        __syncthreads();                                          // every fragment has been read: the tile may overwrite the exchange area
-        const int er = (lane >> 4) * 4, ec = tile0 * 16 + (lane & 15);
+        __syncthreads();                                          // every fragment has been read: the exchange area is free
+        // fin[ii][t]: pixel (row tile i_keep + ii, x = lane & 15), channels tile0 * 16 + t * 16 + 4 (lane >> 4) .. + 3  (the swapped product)
+        if (p.splitk > 1) {
+            // split-K: the row-major fp32 tile for the slab store below
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<f32x4v*>(tilef + ((i_keep + ii) * 16 + (lane & 15)) * TS + tile0 * 16 + t * 16 + 4 * (lane >> 4)) = fin[ii][t];
+            __syncthreads();
+            return;
+        }
+        // ---- epilogue of an unsplit launch, per wave and without a workgroup barrier (round 6; before: the row-major fp32 tile of all eight waves,
+        // a barrier, a 480-thread row pass - "k-half sum + stores" 13k of a 640-channel workgroup's 88k cycles, BC_WREG_STAMPS).  The wave parks its 64
+        // pixels x NT * 16 channels in a private 16-KB slice (rows of 256 B, 16-byte chunk index XOR-ed with the row: conflict-free both
+        // ways; LDS operations of one wave execute in order) and reads them back as (pixel, 8-channel chunk) per lane: NT = 3 - 8 pixels x 6 chunks
+        // per pass (lanes with chunk position 6, 7 idle), 8 passes; NT = 2 - 16 pixels x 4 chunks, 4 passes.  Arithmetic as epi8_store, in its order.
+        constexpr int RPP = NT == 3 ? 8 : 16, NP = 64 / RPP;
+        char* const sl = smem + wave * 16384;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                const int row = ii * 16 + (lane & 15), ck = t * 4 + (lane >> 4);
+                *reinterpret_cast<f32x4v*>(sl + row * 256 + ((ck ^ (row & 15)) << 4)) = fin[ii][t];
+            }
+        int cpos, rsub;
+        bool lane_on = true;
+        if (NT == 3) {
+            cpos = lane & 7;
+            rsub = lane >> 3;
+            lane_on = cpos < 6;
+            if (!lane_on) cpos = 5;                               // (idle lanes repeat chunk 5 of their row; they do not count towards the statistics)
+        } else {
+            // 16 lanes served together read 4 pixels x 4 chunks: pixels {0, 1, 8, 9} + 2 (lane >> 4), so that their XOR-ed chunk sets are disjoint
+            const int sub = (lane >> 2) & 3;
+            cpos = lane & 3;
+            rsub = 2 * (lane >> 4) + (sub & 1) + 8 * (sub >> 1);
+        }
+        const int ch0 = tile0 * 16 + cpos * 8, n_first = n0 + ch0;
+        const int rpb = (int)g.div_rpb.d;
+        const float alpha = scalar_alpha(p);
+        const float* ev = reinterpret_cast<const float*>(smem + OFF_EPI) + ch0;
+        float bias_v[8], rvec[8], cs[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tilef[(er + (i_keep + ii) * 16 + r) * TS + ec + t * 16] = fin[ii][t][r];
-        __syncthreads();
+        for (int j = 0; j < 8; ++j) {
+            bias_v[j] = ev[j];
+            rvec[j] = ev[HBN + j];
+            cs[j] = (p.colscale ? p.colscale[n_first + j] : 1.0f) * alpha;
+        }
+        const float ab = p.alpha_bstride > 0 ? batch_alpha(g, b) : 1.0f;
+        float gs[8], gq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+        // HR: the launch has a residual (compile time: under a run-time `if (p.R)` the compiler moves each chunk's fp16 -> fp32 conversions up into
+        // the load's block and awaits every request where it is made); H2: a right-half residual (per-lane loads under per-lane conditions)
+        // (H2 = the general form: also an activation after the convolution - no layer of these networks has one; kept rolled, loads where used)
+        auto passes = [&](auto H2K, auto HRK) {
+            constexpr bool H2 = decltype(H2K)::value, HR = decltype(HRK)::value;
+            uint4 rr[NP];
+            int mrow[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const int row = j * RPP + rsub;
+                mrow[j] = b * rpb + (ty0 + i_keep + (row >> 4)) * W + tx0 + (row & 15);
+                if (HR) rr[j] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[j] * p.ldr + n_first);
+            }
+            if (!H2) __builtin_amdgcn_sched_barrier(0);               // (all requests before the first use: the waits then count exactly)
+#pragma unroll H2 ? 1 : NP
+            for (int j = 0; j < NP; ++j) {
+                const int row = j * RPP + rsub;
+                const f32x4v lo = *reinterpret_cast<const f32x4v*>(sl + row * 256 + (((2 * cpos) ^ (row & 15)) << 4));
+                const f32x4v hi = *reinterpret_cast<const f32x4v*>(sl + row * 256 + (((2 * cpos + 1) ^ (row & 15)) << 4));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += bias_v[q];
+                if (p.rowvec) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += rvec[q];
+                }
+                if (H2) {
+                    if (p.act == BC_ACT_GELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bc_gelu_f(v[q]);
+                    } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bc_silu_f(v[q]);
+                    } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bc_quick_gelu_f(v[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= cs[q];
+                if (p.alpha_bstride > 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= ab;
+                }
+                if (HR) {
+                    const h16* rh = reinterpret_cast<const h16*>(&rr[j]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += (float)rh[q];
+                }
+                if (H2 && p.R) {
+                    const uint4 r1 = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[j] * p.ldr + n_first);
+                    const h16* rh = reinterpret_cast<const h16*>(&r1);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += (float)rh[q];
+                }
+                if (H2 && p.R2) {
+                    const int pix = mrow[j] - b * rpb;
+                    const int x = pix - (int)fdiv((unsigned)pix, g.div_outw) * (int)g.div_outw.d;
+                    if (x >= p.r2_xmin) {
+                        const uint4 r2 = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)(b % p.r2_bmod) * rpb + pix) * p.ldr2 + n_first);
+                        const h16* rh = reinterpret_cast<const h16*>(&r2);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += (float)rh[q];
+                    }
+                }
+                uint4 outraw;
+                h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    o[q] = (h16)v[q];
+                    const float f = lane_on ? (float)o[q] : 0.f;
+                    gs[q] += f;
+                    gq[q] += f * f;
+                }
+                // (no branch around the store: the idle lanes of NT = 3 repeat chunk 5's store of their row, same address and data - under a per-lane
+                //  branch the compiler cannot count the store, and every wait for a residual chunk covers the previous row's store again)
+                bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[j] * p.ldc + n_first, outraw);
+            }
+        };
+        if (p.R2 || p.act != BC_ACT_NONE) passes(std::true_type{}, std::false_type{});
+        else if (p.R) passes(std::false_type{}, std::true_type{});
+        else passes(std::false_type{}, std::false_type{});
+        if (p.gn_tot) {
+            // column statistics of the fp16-rounded outputs.  The lanes of one chunk position hold eight column sums each; a REDUCE-SCATTER over three
+            // lane bits (exchange 4, then 2, then 1 of them: 7 shuffles per statistic instead of the butterfly's 24 - 32) leaves lane (chunk position,
+            // q) with column q's sum over the wave's 64 pixels (NT = 2: one more exchange over the fourth bit).  Fixed order: deterministic.  The
+            // K-half-1 wave of the column group (pixels 64 .. 127) hands its sums to the K-half-0 wave through its own slice; one atomic add per
+            // column and workgroup.
+            constexpr int X0 = NT == 3 ? 8 : 4, X1 = 2 * X0, X2 = 4 * X0;
+            const bool b0 = lane & X0, b1 = lane & X1, b2 = lane & X2;
+            auto scatter = [&](const float (&v)[8]) __attribute__((always_inline)) {
+                float k4[4], k2[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) k4[k] = (b0 ? v[4 + k] : v[k]) + __shfl_xor(b0 ? v[k] : v[4 + k], X0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) k2[k] = (b1 ? k4[2 + k] : k4[k]) + __shfl_xor(b1 ? k4[k] : k4[2 + k], X1);
+                float t = (b2 ? k2[1] : k2[0]) + __shfl_xor(b2 ? k2[0] : k2[1], X2);
+                if (NT == 2) t += __shfl_xor(t, 32);
+                return t;
+            };
+            const float s_own = scatter(gs), q2_own = scatter(gq);
+            const int q_own = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+            const bool owner = NT == 3 ? lane_on : lane < 32;
+            float* sc = reinterpret_cast<float*>(smem + (wave | 1) * 16384);
+            if (kg == 1 && owner) {
+                sc[(cpos * 8 + q_own) * 2] = s_own;
+                sc[(cpos * 8 + q_own) * 2 + 1] = q2_own;
+            }
+            __syncthreads();
+            if (kg == 0 && owner)
+                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n_first + q_own) * BC_GN_TOT_WORDS, s_own + sc[(cpos * 8 + q_own) * 2], q2_own + sc[(cpos * 8 + q_own) * 2 + 1]);
+        }
     };
     if (three) body(IC<3>{}, IC<0>{});
     else body(IC<2>{}, IC<1>{});
     stamp(4);
-
-    // ------------------------------------------------------------------------------------------------ epilogue (as conv_halo.hip)
-    // row-major pass: 24 rows x 20 eight-column chunks per sweep (480 of the 512 threads)
-    const int col8 = tid % 20, row0 = tid / 20;
-    const bool act = tid < 480;
-    const int rpb = (int)g.div_rpb.d;
     if (p.splitk > 1) {
-        if (act) {
+        // split-K: this split's fp32 partial tile into its slab (24 rows x 20 eight-column chunks per sweep: 480 of the 512 threads)
+        const int col8 = tid % 20, row0 = tid / 20;
+        const int rpb = (int)g.div_rpb.d;
+        if (tid < 480) {
             float* slab = p.slab + (size_t)split * p.M * p.N;
             for (int row = row0; row < HBM; row += 24) {
                 const int m = b * rpb + (ty0 + (row >> 4)) * W + tx0 + (row & 15);
@@ -628,131 +781,6 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
                 *reinterpret_cast<float4*>(dst) = lo;
                 *reinterpret_cast<float4*>(dst + 4) = hi;
             }
-        }
-        stamp(5);
-        return;
-    }
-    // Same arithmetic, in the same order, as epi8_store (gemm_common.h); bias and the time-embedding row come from LDS, and the
-    // residual loads of all (up to six) rows of a thread are issued before the first one is used.
-    float gs[8], gq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
-    if (act) {
-        const float alpha = scalar_alpha(p);
-        const int n_first = n0 + col8 * 8;
-        const float* ev = reinterpret_cast<const float*>(smem + OFF_EPI) + col8 * 8;
-        float bias_v[8], rvec[8], cs[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bias_v[j] = ev[j];
-            rvec[j] = ev[HBN + j];
-            cs[j] = (p.colscale ? p.colscale[n_first + j] : 1.0f) * alpha;
-        }
-        const float ab = p.alpha_bstride > 0 ? batch_alpha(g, b) : 1.0f;
-        constexpr int NR = 6;                                       // rows row0 + 24 k < 128
-        // H2 = the launch has a right-half residual (R2: per-lane loads under per-lane conditions).  Without it (every ResBlock convolution)
-        // no load of this pass sits under a per-lane branch: the residual chunks of all six rows are requested from clamped addresses, and
-        // the compiler's waits then count exactly - each leaves the later requests and all earlier STORES in flight, where the conditional
-        // form made every row wait vmcnt(0), i.e. for the previous row's store to be acknowledged (BC_WREG_STAMPS: "stores" 9.4k of a
-        // 320-channel workgroup's 69k cycles at batch 8)
-        // (HR = the launch has a residual, known at compile time in the form without R2: under a run-time `if (p.R)` the compiler moves the
-        //  fp16 -> fp32 conversions of a residual chunk up into the load's block, and each of the six requests is awaited where it is made)
-        auto rows = [&](auto H2K, auto HRK) {
-            constexpr bool H2 = decltype(H2K)::value, HR = decltype(HRK)::value;
-            uint4 rr[NR], rr2[NR];
-            int mrow[NR];
-            bool has2[NR];
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int row = row0 + 24 * k;
-                const int rowc = (k < 5 || row < HBM) ? row : row0;   // (only k = 5 can leave the tile)
-                const int py = ty0 + (rowc >> 4), px = tx0 + (rowc & 15);
-                mrow[k] = b * rpb + py * W + px;
-                has2[k] = false;
-                if (!H2) {
-                    if (HR) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
-                } else if (row < HBM) {
-                    if (p.R) rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)mrow[k] * p.ldr + n_first);
-                    const int pix = py * W + px;
-                    const int x = pix - (int)fdiv((unsigned)pix, g.div_outw) * (int)g.div_outw.d;
-                    has2[k] = x >= p.r2_xmin;
-                    if (has2[k]) rr2[k] = bc_ld16(reinterpret_cast<const h16*>(p.R2) + ((size_t)(b % p.r2_bmod) * rpb + pix) * p.ldr2 + n_first);
-                }
-            }
-            if (!H2) __builtin_amdgcn_sched_barrier(0);               // (all six requests before the first use)
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int row = row0 + 24 * k;
-                if (k == 5 && row >= HBM) continue;
-                const float4 lo = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8);
-                const float4 hi = *reinterpret_cast<const float4*>(tilef + row * TS + col8 * 8 + 4);
-                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += bias_v[j];
-                if (p.rowvec) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += rvec[j];
-                }
-                if (p.act == BC_ACT_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = bc_gelu_f(v[j]);
-                } else if (p.act == BC_ACT_SILU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
-                } else if (p.act == BC_ACT_QUICK_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= cs[j];
-                if (p.alpha_bstride > 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= ab;
-                }
-                if (H2 ? p.R != nullptr : HR) {
-                    const h16* rh = reinterpret_cast<const h16*>(&rr[k]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-                }
-                if (H2 && has2[k]) {
-                    const h16* rh = reinterpret_cast<const h16*>(&rr2[k]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
-                }
-                uint4 outraw;
-                h16* o = reinterpret_cast<h16*>(&outraw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    o[j] = (h16)v[j];
-                    const float f = (float)o[j];
-                    gs[j] += f;
-                    gq[j] += f * f;
-                }
-                bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)mrow[k] * p.ldc + n_first, outraw);
-            }
-        };
-        if (p.R2) rows(std::true_type{}, std::false_type{});
-        else if (p.R) rows(std::false_type{}, std::true_type{});
-        else rows(std::false_type{}, std::false_type{});
-    }
-    if (p.gn_tot) {
-        float* scr = reinterpret_cast<float*>(smem + OFF_SCR);     // [24][160][2], behind the tile
-        if (act) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                scr[(row0 * HBN + col8 * 8 + j) * 2] = gs[j];
-                scr[(row0 * HBN + col8 * 8 + j) * 2 + 1] = gq[j];
-            }
-        }
-        __syncthreads();
-        if (tid < HBN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int r = 0; r < 24; ++r) {
-                s += scr[(r * HBN + tid) * 2];
-                q += scr[(r * HBN + tid) * 2 + 1];
-            }
-            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n0 + tid) * BC_GN_TOT_WORDS, s, q);
         }
     }
     stamp(5);

@@ -1,6 +1,22 @@
 #!/bin/bash
-# scratch job: GroupNorm pass form as default for >= 4 requests: block tests + full-size batch tests
+# scratch job: conv_wreg per-wave epilogue (3): batch-1 / batch-2 A/B + full GPU suite
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_blocks_gpu.py tests/test_fullsize_loop_gpu.py tests/test_dist_gpu.py -x -q -s > gpurun_out/t_gn.log 2>&1
-tail -5 gpurun_out/t_gn.log; grep -n "C3 request\|c5\|768" gpurun_out/t_gn.log | head
+for rep in 1 2 3; do
+for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
+  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --steps 3 --warmup 2 --no-calibration --no-cpu-baseline --no-e2e --no-configs > gpurun_out/b1.json 2> gpurun_out/b1.err || tail -5 gpurun_out/b1.err
+  python - "$lib" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/b1.json').read().strip().splitlines()[-1]); print('batch1 lib[%s] ms/step %.3f'%(sys.argv[1][-12:], d['ms_per_step']/50))
+PY
+done; done
+for rep in 1 2; do
+for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
+  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --batch 2 --steps 3 --warmup 2 --no-calibration > gpurun_out/b2.json 2> gpurun_out/b2.err || tail -5 gpurun_out/b2.err
+  python - "$lib" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/b2.json').read().strip().splitlines()[-1]); print('batch2 lib[%s] ms/step %.3f'%(sys.argv[1][-12:], d['ms_per_step']/50))
+PY
+done; done
+timeout 1200 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1
+tail -3 gpurun_out/t_all.log
