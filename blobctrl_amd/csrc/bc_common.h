@@ -126,6 +126,36 @@ __device__ __forceinline__ void bc_gn_tot_add(unsigned long long* t, float s, fl
         if (b[i]) __hip_atomic_fetch_add(t + 3 + i, (unsigned long long)b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// Channels per totals BLOCK (round 6).  Atomics on one cache line execute one after the other, ~22 ns each (tools/gn_atomic_probe.hip): the 64
+// row tiles of an image adding 2 - 5 slices per channel into the same 48 bytes kept every launch that produces statistics alive 3 - 5 us after
+// its last store - 5 % of the batch-1 step (a build that stores instead of adding: 8.64 -> 8.20 ms).  GroupNorm never needs one channel's
+// statistics, only a group's.  In a table whose width is a multiple of 320 - every GroupNorm input of the UNet / BlobNet: 32 groups of 10 k
+// channels, also over concatenated sources - a producer therefore adds ONE partial per block of 10 consecutive channels, and it adds it into
+// slot (block + spread % 10): the ten channel slots of a block are ten accumulators of the block's sums, picked by the producer's row-tile
+// index.  A tenth of the atomics, a tenth of the chain per line, and no consumer changes: a group's sum over its channels' slots is the same
+// sum.  MEANINGFUL ARE ONLY SUMS OVER WHOLE BLOCKS - launch.py refuses the producer's totals to a GroupNorm whose groups are not unions of
+// blocks (it runs a statistics pass instead).  Tables of other widths (the VAE: 128 / 256 / 512 channels, groups of 4 - 16) stay per channel.
+__host__ __device__ __forceinline__ int bc_gn_cg(int n_out) { return n_out % 320 == 0 ? 10 : 1; }
+// The thread that holds column n of a workgroup covering columns [n_lo, n_hi) adds what is its to add: with cg == 1 its own column; else, if n is
+// the first column of its block inside [n_lo, n_hi), the block's columns inside that range (col(k) -> (sum, sum of squares) of column k, from LDS).
+template <class F>
+__device__ __forceinline__ void bc_gn_tot_add_slot(unsigned long long* table_of_image, int n, int n_lo, int n_hi, int cg, int spread, F&& col) {
+    if (cg <= 1) {
+        const float2 v = col(n);
+        bc_gn_tot_add(table_of_image + (size_t)n * BC_GN_TOT_WORDS, v.x, v.y);
+        return;
+    }
+    const int d0 = n / cg * cg;
+    if (n != (d0 > n_lo ? d0 : n_lo)) return;
+    const int last = d0 + cg < n_hi ? d0 + cg : n_hi;
+    float s = 0.f, q = 0.f;
+    for (int k = n; k < last; ++k) {
+        const float2 v = col(k);
+        s += v.x;
+        q += v.y;
+    }
+    bc_gn_tot_add(table_of_image + (size_t)(d0 + (unsigned)spread % (unsigned)cg) * BC_GN_TOT_WORDS, s, q);
+}
 // (sum, sum of squares) of one channel from its six words; a poisoned total reads as NaN
 __device__ __forceinline__ void bc_gn_tot_decode(unsigned long long w0, unsigned long long w1, unsigned long long w2, unsigned long long w3,
                                                  unsigned long long w4, unsigned long long w5, double& s, double& q) {

@@ -460,15 +460,16 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmArgs g) {
             }
         }
         __syncthreads();
-        if (tid < HBN) {
-            float s = 0.f, q = 0.f;
+        if (tid < HBN)                            // one add per totals block (bc_gn_cg): the block's first column sums its columns' 24 row partials
+            bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, n0 + tid, n0, n0 + HBN, bc_gn_cg(g.n_out), tin, [&](int k) {
+                float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 24; ++r) {
-                s += scr[(r * HBN + tid) * 2];
-                q += scr[(r * HBN + tid) * 2 + 1];
-            }
-            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n0 + tid) * BC_GN_TOT_WORDS, s, q);
-        }
+                for (int r = 0; r < 24; ++r) {
+                    s += scr[(r * HBN + k - n0) * 2];
+                    q += scr[(r * HBN + k - n0) * 2 + 1];
+                }
+                return make_float2(s, q);
+            });
     }
     stamp(6);
 }

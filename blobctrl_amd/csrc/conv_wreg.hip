@@ -754,14 +754,22 @@ __global__ __launch_bounds__(512) void conv_wreg_kernel(const GemmArgs g) {
             const float s_own = scatter(gs), q2_own = scatter(gq);
             const int q_own = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
             const bool owner = NT == 3 ? lane_on : lane < 32;
-            float* sc = reinterpret_cast<float*>(smem + (wave | 1) * 16384);
-            if (kg == 1 && owner) {
+            // both waves of the column group leave their column sums in their own slices; the K-half-0 wave adds per totals block (bc_gn_cg: one
+            // partial per 10 channels for these networks, into the block's slot tin % 10 - bc_common.h)
+            float* sc = reinterpret_cast<float*>(smem + wave * 16384);
+            if (owner) {
                 sc[(cpos * 8 + q_own) * 2] = s_own;
                 sc[(cpos * 8 + q_own) * 2 + 1] = q2_own;
             }
             __syncthreads();
-            if (kg == 0 && owner)
-                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n_first + q_own) * BC_GN_TOT_WORDS, s_own + sc[(cpos * 8 + q_own) * 2], q2_own + sc[(cpos * 8 + q_own) * 2 + 1]);
+            if (kg == 0 && owner) {
+                const float* sp = reinterpret_cast<const float*>(smem + (wave | 1) * 16384);
+                const int n_lo = n0 + tile0 * 16;
+                bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, n_first + q_own, n_lo, n_lo + NT * 16, bc_gn_cg(g.n_out), tin, [&](int k) {
+                    const int c = k - n_lo;
+                    return make_float2(sc[c * 2] + sp[c * 2], sc[c * 2 + 1] + sp[c * 2 + 1]);
+                });
+            }
         }
     };
     if (three) body(IC<3>{}, IC<0>{});

@@ -299,16 +299,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs g
         }
         __syncthreads();
         if (tid < 64) {
-            const int n = blockIdx.x * 64 + tid;
+            const int nb = blockIdx.x * 64, n = nb + tid;
             if (n < g.n_out) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    s += scr[(w * 64 + tid) * 2];
-                    q += scr[(w * 64 + tid) * 2 + 1];
-                }
                 const int b = (int)fdiv((unsigned)(blockIdx.y * SK_ROWS), g.div_rpb);
-                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n) * BC_GN_TOT_WORDS, s, q);
+                bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, n, nb, min(nb + 64, g.n_out), bc_gn_cg(g.n_out), (int)blockIdx.y, [&](int k) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        s += scr[(w * 64 + k - nb) * 2];
+                        q += scr[(w * 64 + k - nb) * 2 + 1];
+                    }
+                    return make_float2(s, q);
+                });
             }
         }
     }

@@ -570,15 +570,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                 lds_barrier();
                 const int TSO = geglu ? G_BN / 2 : G_BN, wcols = geglu ? 32 : 64;     // output columns of the tile / of a wave
                 if (tid2 < TSO) {
-                    const int cw = geglu ? tid2 >> 5 : tid2 >> 6, cc = tid2 - cw * wcols;
-                    float s = 0.f, q2 = 0.f;
+                    const int b = (int)fdiv((unsigned)m0, g.div_rpb), nb = geglu ? n0 / 2 : n0;
+                    bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, nb + tid2, nb, nb + TSO, bc_gn_cg(g.n_out), tm, [&](int k) {
+                        const int c = k - nb, cw = geglu ? c >> 5 : c >> 6, cc = c - cw * wcols;
+                        float s = 0.f, q2 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        s += slab[(w * 4 + cw) * 1024 + cc * 2];
-                        q2 += slab[(w * 4 + cw) * 1024 + cc * 2 + 1];
-                    }
-                    const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-                    bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + tid2) * BC_GN_TOT_WORDS, s, q2);
+                        for (int w = 0; w < 2; ++w) {
+                            s += slab[(w * 4 + cw) * 1024 + cc * 2];
+                            q2 += slab[(w * 4 + cw) * 1024 + cc * 2 + 1];
+                        }
+                        return make_float2(s, q2);
+                    });
                 }
                 lds_barrier();
             }

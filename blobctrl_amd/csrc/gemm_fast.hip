@@ -284,16 +284,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const GemmArgs 
         }
         __syncthreads();
         if (tid < TSO) {
-            const int n = (geglu ? n0 / 2 : n0) + tid;
+            const int nb = geglu ? n0 / 2 : n0, n = nb + tid;
             if (n < g.n_out) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    s += scr[(w * TSO + tid) * 2];
-                    q += scr[(w * TSO + tid) * 2 + 1];
-                }
                 const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-                bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + n) * BC_GN_TOT_WORDS, s, q);
+                bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, n, nb, min(nb + TSO, g.n_out), bc_gn_cg(g.n_out), m0 / BM, [&](int k) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        s += scr[(w * TSO + k - nb) * 2];
+                        q += scr[(w * TSO + k - nb) * 2 + 1];
+                    }
+                    return make_float2(s, q);
+                });
             }
         }
     }

@@ -410,13 +410,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
         }
         __syncthreads();
         for (int c = tid; c < TSO; c += 256) {
-            float s = 0.f, qq = 0.f;
-            for (int r = 0; r < RG; ++r) {
-                s += scr[(r * TSO + c) * 2];
-                qq += scr[(r * TSO + c) * 2 + 1];
-            }
-            const int b = (int)fdiv((unsigned)m0, g.div_rpb);
-            bc_gn_tot_add(p.gn_tot + ((size_t)b * g.n_out + (geglu ? n0 / 2 : n0) + c) * BC_GN_TOT_WORDS, s, qq);
+            const int b = (int)fdiv((unsigned)m0, g.div_rpb), nb = geglu ? n0 / 2 : n0;
+            bc_gn_tot_add_slot(p.gn_tot + (size_t)b * g.n_out * BC_GN_TOT_WORDS, nb + c, nb, nb + TSO, bc_gn_cg(g.n_out), m0 / GW_BM, [&](int k) {
+                float s = 0.f, qq = 0.f;
+                for (int r = 0; r < RG; ++r) {
+                    s += scr[(r * TSO + k - nb) * 2];
+                    qq += scr[(r * TSO + k - nb) * 2 + 1];
+                }
+                return make_float2(s, qq);
+            });
         }
     }
 }

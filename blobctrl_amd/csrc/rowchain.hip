@@ -463,8 +463,10 @@ __device__ __forceinline__ void layernorm_to_X(const f32x4v (&acc)[RC_NT][4], co
 }
 
 // per-channel (sum, sum of squares) of the fp16 rows in S over the 64 rows, added to the consumer's GroupNorm statistics totals
+// (round 6: one add per totals block - bc_common.h bc_gn_cg - through `scratch`, RC_C * 8 bytes of LDS nobody reads meanwhile; two barriers)
 template <int RC_C>
-__device__ __forceinline__ void gn_partials_from_S(const char* S, unsigned long long* __restrict__ dst, int tid) {
+__device__ __forceinline__ void gn_partials_from_S(const char* S, char* scratch, unsigned long long* __restrict__ dst, int tid, int spread) {
+    float* const sc = reinterpret_cast<float*>(scratch);
     if (tid < RC_C / 2) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
         const int unit = tid >> 1, half = tid & 1;
@@ -475,9 +477,12 @@ __device__ __forceinline__ void gn_partials_from_S(const char* S, unsigned long 
             s0 += a; q0 = fmaf(a, a, q0);
             s1 += b; q1 = fmaf(b, b, q1);
         }
-        bc_gn_tot_add(dst + (size_t)(2 * tid) * BC_GN_TOT_WORDS, s0, q0);
-        bc_gn_tot_add(dst + (size_t)(2 * tid + 1) * BC_GN_TOT_WORDS, s1, q1);
+        *reinterpret_cast<float4*>(sc + 4 * tid) = make_float4(s0, q0, s1, q1);
     }
+    lds_barrier();
+    for (int c = tid; c < RC_C; c += (int)blockDim.x)
+        bc_gn_tot_add_slot(dst, c, 0, RC_C, bc_gn_cg(RC_C), spread, [&](int k) { return make_float2(sc[2 * k], sc[2 * k + 1]); });
+    lds_barrier();
 }
 
 template <int RC_C, int KIND, bool BLOB>
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(RCfg<RC_C>::NTH, 2) void rowchain_kernel(const RowC
     // summed output are the sum kernel's
     h16* const p16 = reinterpret_cast<h16*>(a.part);
     S_to_rows<RC_C>(FFP ? p16 + ((size_t)z * a.M + m0) * RC_C : a.out0 + (size_t)m0 * RC_C, RC_C, S, cm);
-    if (!FFP && a.gn_tot) gn_partials_from_S<RC_C>(S, a.gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid);
+    if (!FFP && a.gn_tot) gn_partials_from_S<RC_C>(S, X, a.gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid, m0 / RC_BM);    // (X is free here)
     stamp(7);
     if (BLOB) {
         // zero-conv of the block output (the BlobNet residual the UNet adds): r = (W out + b) * conditioning scale
@@ -983,15 +988,16 @@ __global__ __launch_bounds__(640) void rowchain_sum_kernel(const h16* __restrict
         }
         __syncthreads();
         const int b = m0 / rows_per_batch;
-        if (tid < RC_C) {                                           // one channel per thread, the row lanes in a fixed order
-            float ss = 0.f, qq = 0.f;
+        if (tid < RC_C)                                             // one add per totals block (bc_gn_cg: 10 channels), the row lanes in a fixed order
+            bc_gn_tot_add_slot(gn_tot + (size_t)b * RC_C * BC_GN_TOT_WORDS, tid, 0, RC_C, bc_gn_cg(RC_C), (int)blockIdx.x, [&](int k) {
+                float ss = 0.f, qq = 0.f;
 #pragma unroll
-            for (int r2 = 0; r2 < RL; ++r2) {
-                ss += red[r2][tid >> 3][tid & 7];
-                qq += red[r2][tid >> 3][8 + (tid & 7)];
-            }
-            bc_gn_tot_add(gn_tot + ((size_t)b * RC_C + tid) * BC_GN_TOT_WORDS, ss, qq);
-        }
+                for (int r2 = 0; r2 < RL; ++r2) {
+                    ss += red[r2][k >> 3][k & 7];
+                    qq += red[r2][k >> 3][8 + (k & 7)];
+                }
+                return make_float2(ss, qq);
+            });
     }
 }
 

@@ -273,7 +273,7 @@ class TrunkPlan:
         if opt("gn_finalize_launch"):
             gnkw = dict(affine=rec.gn_affine(x.t, Cc, None, 0, B, HW, self.G, 1e-6, pw.f[p + "norm.weight"], pw.f[p + "norm.bias"]))
         else:                                              # the GroupNorm finalize runs in the IN launch's prologue, from the statistics totals
-            gnkw = dict(gn_in=(rec.gn_sources(x.t, Cc, None, 0, B, HW)[0], pw.f[p + "norm.weight"], pw.f[p + "norm.bias"], self.G, 1e-6))
+            gnkw = dict(gn_in=(rec.gn_sources(x.t, Cc, None, 0, B, HW, self.G)[0], pw.f[p + "norm.weight"], pw.f[p + "norm.bias"], self.G, 1e-6))
         ldvt = (HW + 63) // 64 * 64
         vt = rec.zeros(B, Cc, ldvt)
         # (the block's head on the column-tiled gemm_wreg projections - all CUs - instead of one 64-row workgroup per row block was

@@ -45,6 +45,14 @@ def decode_gn_tot(tot: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gn_tot_slots(sums: torch.Tensor) -> torch.Tensor:
+    """Per-channel (sum, sum of squares) [..., C, 2] -> per totals BLOCK [..., C / cg, 2] (csrc/bc_common.h bc_gn_cg: a producer's table whose
+    width is a multiple of 320 holds sums of 10-channel blocks, spread over the block's ten slots; tests compare block sums on both sides)."""
+    C = sums.shape[-2]
+    cg = 10 if C % 320 == 0 else 1
+    return sums.reshape(*sums.shape[:-2], C // cg, cg, 2).sum(-2)
+
+
 def encode_gn_tot(sums: torch.Tensor) -> torch.Tensor:
     """(sum, sum of squares) [..., 2] -> totals [..., GN_TOT_WORDS] int64, sliced the way the kernels do it (csrc/bc_common.h
     bc_gn_slices): tools and tests that stand in for a producer."""
@@ -184,6 +192,7 @@ class Recorder:
             self.num_cu = info[0]
         self.bytes_allocated = 0
         self.tots = {}                      # data_ptr of an activation -> its GroupNorm statistics totals [B][C][GN_TOT_WORDS] (int64)
+        self.tots_per_channel = set()       # ids of the tables a bc_gn_stats pass (or a test standing in for a producer) filled per channel
         self._tot_chunk = {}                # (segment id, stream id) -> [chunk tensor, used words]: the arenas new tables are carved from
         self.sid = 0                        # stream id new launches are recorded for (0 main, 1 side)
         self.events = []
@@ -455,7 +464,7 @@ class Recorder:
                 # overlapping its channel span - whenever that span fits the kernel's scratch, else as its own launch.
                 G_ = a_gn["G"]
                 span = cps * 64 + 2 * (conv["Cin"] // G_)
-                t1, t2 = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"])
+                t1, t2 = self.gn_sources(a_gn["x1"], a_gn["C1"], a_gn["x2"], a_gn["C2"], a_gn["B"], a_gn["HW"], a_gn["G"])
                 fin_max = 2752 if tile_cfg == _lib.TILE_WREG else 712          # (FIN_MAX_CH of conv_wreg.hip / conv_halo.hip)
                 if span <= fin_max and not opt("gn_finalize_launch"):
                     g.a_tot1, g.a_tot2 = ptr(t1), ptr(t2)
@@ -475,7 +484,7 @@ class Recorder:
             fast, mode = True, "gw" + ("_ln" if ln_colsum is not None else "") + ("_qkv" if C_t is not None else "") + ("_gn" if a_gn is not None else "") + \
                 ("_softmax" if sm_group else "") + ("_wimg" if w_bstride else "")
             if a_gn is not None:          # GroupNorm(x) -> projection: finalize in the kernel's prologue from the statistics totals of x
-                t1, _ = self.gn_sources(a_gn["x1"], a_gn["C1"], None, 0, a_gn["B"], a_gn["HW"])
+                t1, _ = self.gn_sources(a_gn["x1"], a_gn["C1"], None, 0, a_gn["B"], a_gn["HW"], a_gn["G"])
                 g.a_tot1 = ptr(t1)
                 g.a_gamma, g.a_beta, g.a_groups, g.a_eps = ptr(a_gn["gamma"]), ptr(a_gn["beta"]), a_gn["G"], a_gn["eps"]
                 self.keep.append((t1, a_gn["gamma"], a_gn["beta"]))
@@ -541,16 +550,21 @@ class Recorder:
     def _op(self, name, args, kind, **meta):
         self._add_op(_lib.OPS[name], _lib.op_signature(name), args, kind, **meta)
 
-    def gn_sources(self, x1, C1, x2, C2, B, HW):
-        """GroupNorm statistics totals of (x1 | x2): the tables the producers' epilogues added to when they exist, else a recorded
-        bc_gn_stats pass.  Returns (tot1, tot2 or None)."""
+    def gn_sources(self, x1, C1, x2, C2, B, HW, G):
+        """GroupNorm statistics totals of (x1 | x2) for a GroupNorm of G groups: the tables the producers' epilogues added to when they
+        exist AND can serve it, else a recorded bc_gn_stats pass.  Returns (tot1, tot2 or None).
+        A producer's table of a width that is a multiple of 320 holds sums of 10-channel BLOCKS, spread over the block's ten slots (csrc/
+        bc_common.h bc_gn_cg): it serves a GroupNorm whose groups are unions of whole blocks - every one of the UNet / BlobNet - and no other."""
         srcs = []
-        for x, c in ((x1, C1), (x2, C2 if x2 is not None else 0)):
+        c2_ = C2 if x2 is not None else 0
+        cpg = (C1 + c2_) // G
+        for x, c, off in ((x1, C1, 0), (x2, c2_, C1)):
             if x is None:
                 srcs.append(None)
                 continue
             hit = self.tots.get(x.data_ptr())
-            if hit is not None and hit.shape[1] == c:
+            blocks_ok = c % 320 != 0 or id(hit) in self.tots_per_channel or (cpg % 10 == 0 and off % 10 == 0)
+            if hit is not None and hit.shape[1] == c and blocks_ok:
                 srcs.append(hit)
             else:
                 tot = self.new_tot(B, c)
@@ -558,6 +572,7 @@ class Recorder:
                 self._op("bc_gn_stats", (x, c, B, HW, tot), "gn_stats", variant="gn_stats_kernel",
                          shape=("gn_stats", B, HW, c), bytes_=B * HW * c * 2)
                 self.tots[x.data_ptr()] = tot
+                self.tots_per_channel.add(id(tot))            # (a statistics pass writes one slot per channel whatever the width)
                 srcs.append(tot)
         return tuple(srcs)
 
@@ -569,7 +584,7 @@ class Recorder:
         if out is None:
             out = self.empty(B, HW, Cc)
         n_before = self.seg.kinds.get("gn_stats", 0)
-        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW)
+        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW, G)
         own_stats = self.seg.kinds.get("gn_stats", 0) > n_before
         fused = not os.environ.get("BC_GN_UNFUSED") and Cc // G <= 96          # (the fused kernel's LDS staging holds <= 256 channels)
         self.keep.append((x1, x2, t1, t2, gamma, beta, out))
@@ -593,7 +608,7 @@ class Recorder:
         c2 = C2 if x2 is not None else 0
         Cc = C1 + c2
         ab = self.empty(B, Cc, 2, dtype=torch.float32)
-        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW)
+        t1, t2 = self.gn_sources(x1, C1, x2, c2, B, HW, G)
         self.keep.append((x1, x2, t1, t2, ab, gamma, beta))
         self._op("bc_gn_finalize", (t1, C1, t2, c2, B, HW, G, eps, gamma, beta, ab), "gn_finalize",
                  variant="gn_finalize_kernel", shape=("gn_ab", B, HW, Cc))

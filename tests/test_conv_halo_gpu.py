@@ -107,11 +107,12 @@ def test_halo_conv_fused_groupnorm_concat_epilogue(rec, tile, B, H, W, C1, C2, C
     got = from_nhwc(out, B, H, W)
     close(got, ref, rtol=4e-3, what=f"fused GN conv {C1}+{C2}->{Cout}@{H}x{W} sk={sk}")
     # GroupNorm statistics of the fp16-rounded output: the totals every workgroup added its rows to
-    from blobctrl_amd.launch import decode_gn_tot
-    s = decode_gn_tot(part).float()                                           # [B][Cout][2]
+    from blobctrl_amd.launch import decode_gn_tot, gn_tot_slots
+    s = gn_tot_slots(decode_gn_tot(part).float())                             # [B][Cout / cg][2]: sums per totals block
     o = out.float().cpu().view(B, HW, Cout)
-    assert torch.allclose(s[..., 0], o.sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
-    assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * HW ** 0.5)
+    want = gn_tot_slots(torch.stack([o.sum(1), (o * o).sum(1)], -1))
+    assert torch.allclose(s[..., 0], want[..., 0], rtol=1e-3, atol=1e-2 * HW ** 0.5)
+    assert torch.allclose(s[..., 1], want[..., 1], rtol=1e-3, atol=1e-2 * HW ** 0.5)
 
 
 def test_halo_conv_matches_the_unfused_path_on_a_resblock_shape(rec, tile):

@@ -336,9 +336,10 @@ def test_groupnorm_totals_poison_survives_many_addends(rec, HW):
         return y, tot, rec.groupnorm(y, N, None, 0, B, HW, G, 1e-5, gamma.cuda(), beta.cuda(), True)
     y, tot, out = run(rec, fn)
     assert rec.seg.kinds.get("groupnorm_fused_stats") == 1
-    addends = int(tot.cpu()[0, 7, 2]) >> 50
-    print(f"HW {HW}: {addends} poisoned addends on channel 7")
-    assert addends >= 4 and torch.isnan(decode_gn_tot(tot)[0, 7]).all()
+    # (N = 320: channel 7's partials go into the ten slots of the block of channels 0 .. 9, one per producer row tile - bc_gn_cg)
+    addends = int((tot.cpu()[0, :10, 2] >> 50).sum())
+    print(f"HW {HW}: {addends} poisoned addends on the block of channel 7")
+    assert addends >= 4 and torch.isnan(decode_gn_tot(tot)[0, :10]).any()
     o = out.float().cpu().view(HW, N)
     assert torch.isnan(o[:, :10]).all(), "the poisoned group must read as NaN"
     assert torch.isfinite(o[:, 10:]).all(), "the other groups are untouched"
@@ -763,10 +764,10 @@ def test_gemm_wreg_modes(rec, cfg_i, mode):
     out = run(rec, lambda: rec.gemm(A=Ad, W=ws, M=M, N=N, K=K, out=rec.empty(M, n_out), bias=bq.cuda(), tile_cfg=cfg, **kw))
     close(out, ref, what=f"gemm_wreg {mode} nt={nt}")
     if mode == "res_r2_gn":
-        from blobctrl_amd.launch import decode_gn_tot
+        from blobctrl_amd.launch import decode_gn_tot, gn_tot_slots
         o = out.float().cpu().view(B, rows, N)
         want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
-        close(decode_gn_tot(rec.tots[out.data_ptr()]), want, rtol=1e-4, atol=1e-2, what="gemm_wreg GroupNorm statistics")
+        close(gn_tot_slots(decode_gn_tot(rec.tots[out.data_ptr()])), gn_tot_slots(want), rtol=1e-4, atol=1e-2, what="gemm_wreg GroupNorm statistics")
 
 
 def test_gemm_wreg_folded_layernorm_with_a_large_row_mean(rec):
@@ -1022,10 +1023,10 @@ def test_gemm256_modes(rec, mode, M, N, K):
     else:
         close(res, ref, what=f"gemm256 {mode} {M}x{N}x{K}")
     if kw.get("want_gn"):
-        from blobctrl_amd.launch import decode_gn_tot
+        from blobctrl_amd.launch import decode_gn_tot, gn_tot_slots
         o = res.float().cpu().view(B, rows, N)
         want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
-        close(decode_gn_tot(rec.tots[res.data_ptr()]), want, rtol=1e-4, atol=1e-2 * max(1.0, rows / 256), what="gemm256 GroupNorm statistics")
+        close(gn_tot_slots(decode_gn_tot(rec.tots[res.data_ptr()])), gn_tot_slots(want), rtol=1e-4, atol=1e-2 * max(1.0, rows / 256), what="gemm256 GroupNorm statistics")
 
 
 def test_gemm256_replays_are_bit_identical_and_equal_the_lds_dma_tiles(rec):

@@ -84,11 +84,12 @@ def test_rowchain_matches_the_unfused_block(monkeypatch, cross, B, H, W, with_r2
         print(f"   zero-conv residual: max-abs/scale {relz:.3e}")
         assert relz < 6e-3
     # GroupNorm statistics of the fused output: the totals equal the per-(image, channel) sums of the fp16 tensor
-    from blobctrl_amd.launch import decode_gn_tot
-    s = decode_gn_tot(part_f).float()
+    from blobctrl_amd.launch import decode_gn_tot, gn_tot_slots
+    s = gn_tot_slots(decode_gn_tot(part_f).float())
     o = out_f.t.float().cpu().view(B, H * W, C)
-    assert torch.allclose(s[..., 0], o.sum(1), rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
-    assert torch.allclose(s[..., 1], (o * o).sum(1), rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
+    want = gn_tot_slots(torch.stack([o.sum(1), (o * o).sum(1)], -1))
+    assert torch.allclose(s[..., 0], want[..., 0], rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
+    assert torch.allclose(s[..., 1], want[..., 1], rtol=1e-3, atol=1e-2 * (H * W) ** 0.5)
 
 
 @pytest.mark.parametrize("B,H,W,C,T", [(2, 16, 32, 320, 77), (1, 8, 24, 320, 80), (2, 8, 8, 320, 1), (2, 16, 32, 640, 77), (1, 8, 8, 640, 48),
