@@ -192,6 +192,12 @@ int bc_gemm_plan(int M, int N, int K, int fast, int* tile_cfg, int* splitk, int*
  * the result with integer atomics - integer sums do not depend on the arrival order, so results stay bit-reproducible - and a
  * consumer reads six words per channel.  A table must be zero before its producers run: bc_memset_zero (one per plan segment for
  * all tables of that segment).
+ * BLOCKS (round 6): in a table whose width C is a multiple of 320 the GEMM / convolution / row-chain epilogues add ONE partial per block of
+ * 10 consecutive channels, into slot block + (producer row tile % 10) - the block's ten channel slots are ten accumulators of the block's
+ * sums (atomics on one cache line execute one after the other: a tenth of the adds, a tenth of the chain).  Only sums over WHOLE blocks are
+ * meaningful in such a table: it serves a GroupNorm whose groups are unions of blocks - (C1 + C2) / G a multiple of 10 and C1 a multiple
+ * of 10, which holds for every GroupNorm of the UNet / BlobNet - and no other; for any other consumer run bc_gn_stats (always one slot per
+ * channel) into a table of its own.  Tables of other widths are per channel as before.
  *   bc_gn_stats    : statistics of ONE tensor added to tot[B][C][..].  Only needed when the producing GEMM did not emit them itself.
  *   bc_gn_finalize : per-channel affine of the concat (x1 | x2): ab[B][C1+C2][2] = (rstd*gamma, beta - mean*rstd*gamma),
  *                    from tot_i[B][C_i][..] (tot2 may be NULL)
