@@ -107,22 +107,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE))) 
     h16* Ob = O + (size_t)b * o_bs + (size_t)head * D;
 
     // ---- Q fragments (B operand): lane holds Q[q][16 s + 8 half .. +7], pre-scaled by scale*log2(e) ----
+    // (round 6: every chunk is requested from a clamped address before the first is converted.  With the loads under `if (q < Nq && dcol < D)` the
+    //  compiler kept each chunk's conversion in the load's block and awaited every request where it was made: D / 16 + 1 serial round trips to
+    //  memory in front of every workgroup's first key tile - ten of them at D = 160)
     h16x8 qf[QB][C::D16];
+    uint4 qraw[QB][C::D16];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + qb * QW + qcol, qc = q < Nq ? q : Nq - 1;
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s) {
+            const int dcol = 16 * s + 8 * half;
+            qraw[qb][s] = bc_ld16(Qb + (size_t)qc * ldq + (dcol < D ? dcol : 0));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int q = q0 + qb * QW + qcol;
 #pragma unroll
         for (int s = 0; s < C::D16; ++s) {
-            int dcol = 16 * s + 8 * half;
+            const bool ok = q < Nq && 16 * s + 8 * half < D;
+            const h16* h = reinterpret_cast<const h16*>(&qraw[qb][s]);
             h16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
-            if (q < Nq && dcol < D) {
-                uint4 raw = bc_ld16(Qb + (size_t)q * ldq + dcol);
-                const h16* h = reinterpret_cast<const h16*>(&raw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (h16)((float)h[j] * scale_log2e);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = ok ? (h16)((float)h[j] * scale_log2e) : (h16)0.f;
             qf[qb][s] = v;
         }
     }
