@@ -288,16 +288,33 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
             const float mean = ln ? stat[row * 2] : 0.f, rstd = ln ? stat[row * 2 + 1] : 1.f;
             float v[32];
             float mx = -3.0e38f;
+            // (round 6: the thread's 32 column sums and biases as sixteen 16-byte loads up front.  Read one by one inside the loop below - `if (ln)
+            //  ... csp[j]`, `if (bp) ... bp[j]` - they were 64 scalar loads, each awaited where it was made: most of this launch's 23 us)
+            float4 cs4[8], bb4[8];
+#pragma unroll
+            for (int j4 = 0; j4 < 8; ++j4) {
+                cs4[j4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bb4[j4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (ln) {
+#pragma unroll
+                for (int j4 = 0; j4 < 8; ++j4) cs4[j4] = *reinterpret_cast<const float4*>(csp + c0 + j4 * 4);
+            }
+            if (bp) {
+#pragma unroll
+                for (int j4 = 0; j4 < 8; ++j4) bb4[j4] = *reinterpret_cast<const float4*>(bp + c0 + j4 * 4);
+            }
 #pragma unroll
             for (int j4 = 0; j4 < 8; ++j4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, c0 + j4 * 4));
                 const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+                const float cv[4] = {cs4[j4].x, cs4[j4].y, cs4[j4].z, cs4[j4].w}, bv[4] = {bb4[j4].x, bb4[j4].y, bb4[j4].z, bb4[j4].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = c0 + j4 * 4 + e;
                     float x = tv[e];
-                    if (ln) x = rstd * (x - mean * csp[j]);
-                    if (bp) x += bp[j];
+                    if (ln) x = rstd * (x - mean * cv[e]);
+                    if (bp) x += bv[e];
                     x = j < valid ? x : -3.0e38f;
                     v[j4 * 4 + e] = x;
                     mx = fmaxf(mx, x);
