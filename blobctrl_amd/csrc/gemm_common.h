@@ -262,6 +262,60 @@ __device__ __forceinline__ void epi8_store(const GemmArgs& g, const Cols8& c, fl
     bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)m * p.ldc + c.n_first, outraw);
 }
 
+// epi8_store without its global LOADS, for the launches that need none (LD 0) or only the residual R (LD 1: `rraw`, requested by the caller
+// ahead of the stores); the arithmetic and its order are epi8_store's, bit for bit.  Why it exists (round 6): the compiler's s_waitcnt for a
+// load that sits under a branch - epi8_store's row vector / residual / right-half residual, taken or not - is vmcnt(0) at the join, and vmcnt
+// is in-order: every 8-column chunk waits for the previous chunk's STORE to be acknowledged, and a residual is requested and awaited chunk by
+// chunk.  Where another workgroup of the CU covers that (gemm_fast: measured, no gain) epi8_store stays; gemm_wreg.hip's launches at M <= 1024
+// have a CU to themselves.  The caller stores the returned 16 bytes.
+template <int LD>
+__device__ __forceinline__ uint4 epi8_apply(const GemmArgs& g, const Cols8& c, float (&v)[8], const float (&gt)[8], float (&gs)[8], float (&gq)[8],
+                                            const uint4 rraw) {
+    const BcGemm& p = g.p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += c.bias_v[j];
+    if (p.act == BC_ACT_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = bc_gelu_f2((f32x2){gt[j] + c.bias_g[j], gt[j + 1] + c.bias_g[j + 1]});
+            v[j] *= gl.x;
+            v[j + 1] *= gl.y;
+        }
+    } else if (p.act == BC_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = bc_gelu_f2((f32x2){v[j], v[j + 1]});
+            v[j] = gl.x;
+            v[j + 1] = gl.y;
+        }
+    } else if (p.act == BC_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_silu_f(v[j]);
+    } else if (p.act == BC_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bc_quick_gelu_f(v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= c.cs[j];
+    if (LD == 1) {
+        const h16* rh = reinterpret_cast<const h16*>(&rraw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh[j];
+    }
+    uint4 outraw;
+    h16* o = reinterpret_cast<h16*>(&outraw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        o[j] = (h16)v[j];
+        const float f = (float)o[j];
+        gs[j] += f;
+        gq[j] += f * f;
+    }
+    return outraw;
+}
+// which form a launch's row-major pass can take (launch-uniform): 2 = epi8_store
+__device__ __forceinline__ int epi8_load_kind(const BcGemm& p) { return (p.rowvec || p.R2 || p.alpha_bstride > 0) ? 2 : p.R ? 1 : 0; }
+
 // Transposed parking of the accumulators: tileT[n][m] with row stride ts (= BM + 4: the 32 lanes of a store hit 32 different
 // rows, the +4 floats keep them on different banks).  Lane holds column n = lane&31 and 4 consecutive rows per register group.
 template <int TM, int TN>

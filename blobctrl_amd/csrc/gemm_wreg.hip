@@ -29,6 +29,7 @@
 // XCD placement: consecutive workgroups of an XCD share a COLUMN tile (all its row blocks), so an XCD's L2 fetches each weight
 // stream once.
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_common.h"
 
 using namespace bcg;
@@ -391,28 +392,61 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(const GemmArgs g) {
     float gs[8], gq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
-    if (active) {
-        for (int row = rg; row < GW_BM; row += RG) {
+    const int lk = epi8_load_kind(p);               // (launch-uniform; gemm_common.h epi8_apply)
+    if (active && lk == 1 && !geglu) {
+        // residual launches (to_out, the two-source block end): the thread's residual chunks are all requested before the first is used - each
+        // wait then leaves the younger requests and every store in flight; a workgroup of these launches has its CU to itself at M <= 1024
+        constexpr int RGn = 256 / (BN / 8), NRW = (GW_BM + RGn - 1) / RGn;
+        uint4 rr[NRW];
+#pragma unroll
+        for (int k = 0; k < NRW; ++k)
+            rr[k] = bc_ld16(reinterpret_cast<const h16*>(p.R) + (size_t)(m0 + min(rg + k * RGn, GW_BM - 1)) * p.ldr + n_first);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NRW; ++k) {
+            const int row = rg + k * RGn;
+            if (NRW * RGn != GW_BM && row >= GW_BM) break;
             const float4 lo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv));
             const float4 hi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 4));
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (geglu) {
-                const float4 glo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 32));
-                const float4 ghi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 36));
-                gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
-                gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
-            }
             if (ln) {
                 const float mean = stat[row * 2], rstd = stat[row * 2 + 1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v[j] = rstd * (v[j] - mean * csv[j]);
-                    gt[j] = rstd * (gt[j] - mean * csg[j]);
-                }
+                for (int j = 0; j < 8; ++j) v[j] = rstd * (v[j] - mean * csv[j]);
             }
-            epi8_store(g, cols, v, gt, m0 + row, gs, gq);
+            bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)(m0 + row) * p.ldc + n_first, epi8_apply<1>(g, cols, v, v, gs, gq, rr[k]));
         }
+    } else if (active) {
+        // (two instantiations of the loop: launches without a load in this pass take the load-free one - with epi8_store's loads anywhere in the
+        //  loop body, taken or not, its joins make every chunk wait for the previous chunk's store)
+        auto rows = [&](auto NOLOAD) {
+            for (int row = rg; row < GW_BM; row += RG) {
+                const float4 lo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv));
+                const float4 hi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 4));
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (geglu) {
+                    const float4 glo = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 32));
+                    const float4 ghi = *reinterpret_cast<const float4*>(tile + tile_off<BN>(row, cv + 36));
+                    gt[0] = glo.x; gt[1] = glo.y; gt[2] = glo.z; gt[3] = glo.w;
+                    gt[4] = ghi.x; gt[5] = ghi.y; gt[6] = ghi.z; gt[7] = ghi.w;
+                }
+                if (ln) {
+                    const float mean = stat[row * 2], rstd = stat[row * 2 + 1];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = rstd * (v[j] - mean * csv[j]);
+                        gt[j] = rstd * (gt[j] - mean * csg[j]);
+                    }
+                }
+                if (decltype(NOLOAD)::value)
+                    bc_st16(reinterpret_cast<h16*>(p.C) + (size_t)(m0 + row) * p.ldc + n_first, epi8_apply<0>(g, cols, v, gt, gs, gq, make_uint4(0u, 0u, 0u, 0u)));
+                else
+                    epi8_store(g, cols, v, gt, m0 + row, gs, gq);
+            }
+        };
+        if (lk == 0) rows(std::true_type{});
+        else rows(std::false_type{});
     }
     if (p.gn_tot) {
         // per-channel (sum, sum of squares) of the fp16 output over the block's 64 rows: threads of equal col8 combine through LDS
