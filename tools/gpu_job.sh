@@ -1,14 +1,12 @@
 #!/bin/bash
-# scratch job: gemm_wreg row pass with the residual chunks requested together: tests + A/B batch 1 / 2
+# scratch job: round-6 final evidence on the final sources: warm-up, profiles (4 configurations), parity margins (full GPU suite, -s), critical path, default bench twice
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_blocks_gpu.py -x -q > gpurun_out/t_k.log 2>&1
-tail -3 gpurun_out/t_k.log
-for rep in 1 2 3; do
-for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
-  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --steps 3 --warmup 2 --no-calibration --no-cpu-baseline --no-e2e --no-configs > gpurun_out/b1.json 2> gpurun_out/b1.err || tail -5 gpurun_out/b1.err
-  python - "$lib" <<'PY'
-import json,sys
-d=json.loads(open('gpurun_out/b1.json').read().strip().splitlines()[-1]); print('batch1 lib[%s] ms/step %.3f'%(sys.argv[1][-12:], d['ms_per_step']/50))
-PY
-done; done
+timeout 600 python bench.py --steps 2 --warmup 1 --no-calibration --no-cpu-baseline --no-e2e --no-configs > /dev/null 2>&1
+bash tools/profile_round.sh "" > gpurun_out/prof_b1.log 2>&1
+bash tools/profile_round.sh c3 --batch 8 > gpurun_out/prof_c3.log 2>&1
+bash tools/profile_round.sh c5 --res 768 --batch 4 > gpurun_out/prof_c5.log 2>&1
+bash tools/profile_round.sh b2 --batch 2 > gpurun_out/prof_b2.log 2>&1
+( time timeout 1500 python -m pytest tests -q -m gpu -s ) > gpurun_out/r6_parity_margins.txt 2>&1
+tail -3 gpurun_out/r6_parity_margins.txt
+timeout 300 python tools/critical_path.py > gpurun_out/r6_critical_path.txt 2>&1
