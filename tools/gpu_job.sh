@@ -1,13 +1,22 @@
 #!/bin/bash
-# scratch job: default bench line twice on the final build
+# scratch job: row-chain staging with all row chunks requested first: tests + A/B batch 1 / 8
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 900 python bench.py > gpurun_out/bench_final_1.json 2> gpurun_out/bench_final_1.err
-timeout 900 python bench.py > gpurun_out/bench_final_2.json 2> gpurun_out/bench_final_2.err
-python - <<'PY'
-import json
-for i in (1,2):
-    d=json.loads(open(f'gpurun_out/bench_final_{i}.json').read().strip().splitlines()[-1])
-    c=d['configs']
-    print(i, round(d['value'],4), round(d['ms_per_step']/50,3), d['config'].get('denoise_step_ms_normalised'), d['roofline']['frac'], d['roofline']['full_grid_launches']['frac'], d['roofline'].get('traffic'), d['roofline'].get('mfma_busy'), d['roofline'].get('avg_launch_us'), d['box_calibration'], c['unipc_ms_per_step'], c['c3_batch8_mixed_ms_per_step'], c['c3_frac_of_peak'], c['c5_768_batch4_ms_per_step'], c['c5_frac_of_peak'], c['script_default']['denoise_step_ms'], c['script_default']['edit_ms_end_to_end'], c['script_default']['loop_frac_of_peak'], d.get('edit_ms_end_to_end'), d['cpu_baseline']['value'])
+timeout 1200 python -m pytest tests/test_rowchain_gpu.py tests/test_blocks_gpu.py -x -q > gpurun_out/t_k.log 2>&1
+tail -3 gpurun_out/t_k.log
+for rep in 1 2 3; do
+for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
+  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --steps 3 --warmup 2 --no-calibration --no-cpu-baseline --no-e2e --no-configs > gpurun_out/b1.json 2> gpurun_out/b1.err || tail -5 gpurun_out/b1.err
+  python - "$lib" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/b1.json').read().strip().splitlines()[-1]); print('batch1 lib[%s] ms/step %.3f'%(sys.argv[1][-12:], d['ms_per_step']/50))
 PY
+done; done
+for rep in 1 2; do
+for lib in "" "$GRAFT_REPO_ROOT/build/ab/lib_prev.so"; do
+  BLOBCTRL_HIP_LIB="$lib" timeout 600 python bench.py --batch 8 --steps 6 --warmup 2 --no-calibration > gpurun_out/b8.json 2> gpurun_out/b8.err || tail -5 gpurun_out/b8.err
+  python - "$lib" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/b8.json').read().strip().splitlines()[-1]); print('batch8 lib[%s] ms/step %.2f'%(sys.argv[1][-12:], d['ms_per_step']/50))
+PY
+done; done
