@@ -1,17 +1,9 @@
 #!/bin/bash
-# scratch job: pipelined attention (QK of tile t+1 ahead of tile t's softmax) for the D = 80 small-grid launches: correctness + the launch alone
+# scratch job (rewritten per gpurun call while developing): what the driver runs at round end - GPU suite, smoke, default bench line
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-python - <<'PY'
-import sys, os
-sys.path.insert(0, 'tools'); sys.path.insert(0, '.')
-import attn_probe
-from blobctrl_amd import _lib
-lib = _lib.load()
-for B in (1, 2):
-    attn_probe.run(lib, B, 8, 80, 2048, 2048, check=True)
-    attn_probe.run(lib, B, 8, 80, 1024, 1024, check=True)
-    attn_probe.run(lib, B, 8, 80, 256, 2048 + 64, check=True)
-PY
-timeout 1200 python -m pytest tests/test_kernels_gpu.py -x -q -k "attn or attention" > gpurun_out/t_k.log 2>&1
-tail -3 gpurun_out/t_k.log
+( time timeout 1500 python -m pytest tests -x -q -m gpu ) > gpurun_out/t_all.log 2>&1
+tail -6 gpurun_out/t_all.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_driver.json 2> gpurun_out/bench_driver.err
+tail -c 600 gpurun_out/bench_driver.json
